@@ -1,0 +1,116 @@
+/* vcloze_hip.h — C ABI of the MI355X (gfx950) denoising-path kernels for VisualCloze.
+ *
+ * The reference (lzyhha/VisualCloze) has no FFI layer: its hot path is Python calling torch /
+ * flash-attn.  This header is the boundary a maintainer would bind instead (ctypes stub in
+ * INTEGRATION.md).  Every entry point names the reference interface it replaces.
+ *
+ * Conventions: plain pointers are DEVICE pointers (HBM) unless marked host; bf16 = raw uint16;
+ * `stream` is a hipStream_t passed as void* (NULL = default stream).  Return 0 on success,
+ * negative VC_ERR_* otherwise; vc_last_error() returns the message for the calling thread.
+ * Not thread-safe per stream/graph handle.  No ownership is ever transferred.
+ */
+#ifndef VCLOZE_HIP_H
+#define VCLOZE_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VC_OK 0
+#define VC_ERR_ARG (-1)
+#define VC_ERR_HIP (-2)
+#define VC_ERR_STATE (-3)
+
+#define VC_ABI_VERSION 1
+int vc_abi_version(void);
+const char* vc_last_error(void);
+/* number of visible devices / name of device 0 ("" when none) — fails loudly, never falls back */
+int vc_device_count(void);
+int vc_device_info(int dev, char* name, int namelen, int* cu_count, int64_t* hbm_bytes);
+
+/* ---- GEMM epilogues ---- */
+#define VC_EPI_BIAS 0      /* y = bf16(acc + b)                         nn.Linear              */
+#define VC_EPI_GELU 1      /* y = bf16(gelu_tanh(bf16(acc + b)))        layers.py:141-145,229  */
+#define VC_EPI_GATE_RES 2  /* y = bf16(res + bf16(gate*bf16(acc + b)))  layers.py:190-195,245  */
+#define VC_EPI_SILU 3      /* y = bf16(silu(bf16(acc + b)))             layers.py:55-60        */
+
+typedef struct VcGemmProblem {
+  const void* A;    /* [M,K] bf16, row stride lda (elements) */
+  const void* W;    /* [N,K] bf16 contiguous (nn.Linear.weight layout) */
+  const void* bias; /* [N] bf16 or NULL */
+  void* C;          /* [M,N] bf16, row stride ldc */
+  const void* res;  /* GATE_RES: residual [M,N] bf16 (may alias C), row stride ldres */
+  const void* gate; /* GATE_RES: gate vector(s) bf16; row b of batch uses gate + b*gate_bstride */
+  int64_t lda, ldc, ldres, gate_bstride;
+  int32_t M, N, K;
+  int32_t rows_per_batch; /* GATE_RES: batch index of row m is m / rows_per_batch */
+  int32_t tiles_m, tiles_n, tile_start; /* filled by the launcher */
+  int32_t _pad;
+} VcGemmProblem;
+
+typedef struct VcGemmArgs {
+  VcGemmProblem p[2];
+  int32_t nprob; /* 1 or 2 problems in one grid (img+txt streams) */
+  int32_t epi;
+  const int32_t* step_ptr;  /* optional device step counter: gate += *step_ptr * gate_step_stride */
+  int64_t gate_step_stride;
+} VcGemmArgs;
+
+/* Replaces torch.nn.functional.linear (+ fused neighbours) on the hot path.
+ * tile_cfg: 0 auto, 1 = 128x128, 2 = 256x128, 3 = 256x256. */
+int vc_gemm(const VcGemmArgs* args, int tile_cfg, void* stream);
+
+/* LayerNorm(eps=1e-6, no affine) + AdaLN modulate: y = bf16((1+scale)*LN(x) + shift).
+ * Replaces layers.py:163-164,191,195,234 / 257.  x,y: [rows, D] bf16 (row strides ldx/ldy);
+ * shift/scale: bf16 vectors of D, batch b at +b*mod_bstride, step s at +s*mod_step_stride. */
+int vc_ln_modulate(const void* x, int64_t ldx, void* y, int64_t ldy, const void* shift, const void* scale,
+                   int64_t mod_bstride, int32_t rows, int32_t D, int32_t rows_per_batch,
+                   const int32_t* step_ptr, int64_t mod_step_stride, void* stream);
+
+/* QK-RMSNorm (layers.py:63-84) + RoPE (math.py:112-117) in place on q,k, and V transposed to
+ * vt[b][h][d][Lpad] for the attention kernel.  qkv: token rows of stride ld (elements) holding
+ * q | k | v at column offsets 0, H*128, 2*H*128 ("B L (K H D)", layers.py:166).
+ * rope: [B?][L][64][2] f32 (cos, sin) per pair; rope_bstride 0 = shared by the batch. */
+int vc_qknorm_rope_vt(void* qkv, int64_t ld, int64_t bstride, const void* q_scale, const void* k_scale,
+                      const float* rope, int64_t rope_bstride, void* vt, int32_t B, int32_t L, int32_t Lpad,
+                      int32_t H, void* stream);
+
+/* Joint text+image attention, non-causal, D=128, softmax scale 128^-0.5 (math.py:63-99 /
+ * flash_attn_varlen_func).  q,k from the qkv rows above; vt from vc_qknorm_rope_vt.
+ * kv_len[b] (host-visible semantics: keys >= kv_len masked, query rows >= kv_len written as 0,
+ * = pad_input of math.py:96); NULL = all L.  out: [B, L, H*128] bf16, row stride ldo. */
+int vc_attention(const void* qkv, int64_t ld, int64_t bstride, const void* vt, void* out, int64_t ldo,
+                 int64_t out_bstride, const int32_t* kv_len, int32_t B, int32_t L, int32_t Lpad, int32_t H,
+                 int32_t variant, void* stream);
+
+/* timestep_embedding (layers.py:28-49): out[b, 0:half]=cos(1000*t*f), [half:]=sin, f host table. */
+int vc_timestep_embedding(const float* t, const float* freqs, void* out_bf16, int32_t n, int32_t half,
+                          int32_t round_t_bf16, void* stream);
+/* elementwise helpers on bf16 vectors */
+int vc_silu(const void* x, void* y, int64_t n, void* stream);
+int vc_add3(const void* a, const void* b, const void* c, void* y, int64_t n, void* stream); /* bf16(bf16(a+b)+c); c NULL ok */
+/* x||cond -> [rows, cx+cc] (transport.py:195) */
+int vc_concat_cols(const void* x, int32_t cx, const void* cond, int32_t cc, void* out, int64_t rows, void* stream);
+/* Euler update of the fixed-grid solver: x = bf16(x + bf16(dt * (-v))), dt = dts[*step_ptr] (f32). */
+int vc_euler_step(void* x, const void* v, const float* dts, const int32_t* step_ptr, int64_t n, void* stream);
+int vc_step_advance(int32_t* step_ptr, void* stream);
+
+/* ---- hipGraph helpers: capture the launches issued on `stream` between begin/end ---- */
+int vc_stream_create(void** stream);
+int vc_stream_destroy(void* stream);
+int vc_stream_sync(void* stream);
+int vc_graph_begin(void* stream);
+int vc_graph_end(void* stream, void** graph_exec);
+int vc_graph_launch(void* graph_exec, void* stream);
+int vc_graph_destroy(void* graph_exec);
+
+/* ---- timing on the launch stream (HIP events), for bench.py's roofline leg ---- */
+int vc_event_create(void** ev);
+int vc_event_record(void* ev, void* stream);
+int vc_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms); /* synchronises on ev_stop */
+int vc_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

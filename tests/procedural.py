@@ -1,0 +1,77 @@
+"""Procedural (closed-form, RNG-free) tensors shared by the golden-vector generator and the tests.
+
+Every value is k * 2^-q with integer |k| <= 127, i.e. exactly representable in bfloat16, so the fp32
+reference, the oracle and the bf16 HIP path all see bit-identical weights and inputs on any machine."""
+from __future__ import annotations
+
+import math
+import zlib
+
+import numpy as np
+import torch
+
+
+def _hash(idx: np.ndarray, seed: int) -> np.ndarray:
+    h = (idx * np.uint64(2654435761) + np.uint64(seed) * np.uint64(40503) + np.uint64(12345)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(15)
+    h = (h * np.uint64(2246822519)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(13)
+    h = (h * np.uint64(3266489917)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(16)
+    return h
+
+
+def ptensor(shape, seed: int, q: int = 7, kmax: int = 127, offset: float = 0.0) -> torch.Tensor:
+    n = int(np.prod(shape))
+    h = _hash(np.arange(n, dtype=np.uint64), seed)
+    k = (h % np.uint64(2 * kmax + 1)).astype(np.int64) - kmax
+    return torch.tensor(k.astype(np.float32) * np.float32(2.0 ** -q) + np.float32(offset)).reshape(*shape)
+
+
+def key_seed(key: str) -> int:
+    return zlib.crc32(key.encode()) & 0x7FFFFFFF
+
+
+def procedural_param(key: str, shape) -> torch.Tensor:
+    """Weight for state-dict entry `key` (reference naming)."""
+    seed = key_seed(key)
+    shape = tuple(shape)
+    if key.endswith("norm.scale"):                       # RMSNorm scales ~ 1
+        return ptensor(shape, seed, q=9, kmax=64, offset=1.0)
+    if key.endswith(".bias"):
+        return ptensor(shape, seed, q=9, kmax=32)
+    fan_in = shape[-1]
+    q = int(round(math.log2(73.0 * math.sqrt(fan_in))))  # unit-variance outputs for unit-variance inputs
+    if ".lora_A." in key:
+        return ptensor(shape, seed, q=q, kmax=127)
+    if ".lora_B." in key:
+        return ptensor(shape, seed, q=q + 2, kmax=127)   # LoRA path live at ~25 % of the base magnitude
+    if "_mod.lin" in key or "modulation.lin" in key or "adaLN_modulation" in key:
+        return ptensor(shape, seed, q=q + 2, kmax=127)   # keep shift/scale/gate ~ 0.25
+    return ptensor(shape, seed, q=q, kmax=127)
+
+
+def procedural_state_dict(key_shapes) -> dict:
+    return {k: procedural_param(k, s) for k, s in key_shapes}
+
+
+TINY = dict(in_channels=384, out_channels=64, vec_in_dim=64, context_in_dim=128, hidden_size=256, mlp_ratio=4.0,
+            num_heads=2, depth=2, depth_single_blocks=2, axes_dim=[16, 56, 56], theta=10_000, qkv_bias=True,
+            guidance_embed=True)
+TINY_RANK = 8
+
+
+def tiny_inputs(B: int = 1, rows_hw=((4, 12), (4, 12)), T: int = 16, seed: int = 1):
+    """Synthetic Flux.forward inputs for the tiny geometry: a 2-row latent grid (row index+1 ids)."""
+    from oracle.flux_oracle import grid_img_ids
+    ids = grid_img_ids(list(rows_hw))
+    N = ids.shape[0]
+    x = ptensor((B, N, 64), seed + 1, q=6)
+    cond = torch.cat([ptensor((B, N, 64), seed + 2, q=6),
+                      (ptensor((B, N, 256), seed + 3, q=0, kmax=1).abs() > 0.5).float()], dim=-1)
+    return dict(
+        x=x, cond=cond, img_ids=ids[None].repeat(B, 1, 1), txt=ptensor((B, T, TINY["context_in_dim"]), seed + 4, q=6),
+        txt_ids=torch.zeros(B, T, 3), y=ptensor((B, TINY["vec_in_dim"]), seed + 5, q=6),
+        txt_mask=torch.ones(B, T, dtype=torch.int32), img_mask=torch.ones(B, N, dtype=torch.int32),
+        guidance=torch.full((B,), 30.0),
+    )

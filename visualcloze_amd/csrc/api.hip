@@ -1,0 +1,135 @@
+// C ABI of libvcloze_hip.so (declared in include/vcloze_hip.h): argument checks, per-thread error string,
+// stream / hipGraph / event helpers.  No torch types cross this boundary.
+#include "vcloze_internal.h"
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+#define ERRBUF g_err, (int)sizeof(g_err)
+static inline hipStream_t S(void* s) { return (hipStream_t)s; }
+static int hip_fail(const char* what, hipError_t e) {
+  snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+  return VC_ERR_HIP;
+}
+
+extern "C" {
+
+int vc_abi_version(void) { return VC_ABI_VERSION; }
+const char* vc_last_error(void) { return g_err; }
+
+int vc_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { hip_fail("hipGetDeviceCount", e); return 0; }
+  return n;
+}
+int vc_device_info(int dev, char* name, int namelen, int* cu_count, int64_t* hbm_bytes) {
+  hipDeviceProp_t p;
+  hipError_t e = hipGetDeviceProperties(&p, dev);
+  if (e != hipSuccess) return hip_fail("hipGetDeviceProperties", e);
+  if (name && namelen > 0) { strncpy(name, p.gcnArchName, namelen - 1); name[namelen - 1] = 0; }
+  if (cu_count) *cu_count = p.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = (int64_t)p.totalGlobalMem;
+  return VC_OK;
+}
+
+int vc_gemm(const VcGemmArgs* args, int tile_cfg, void* stream) {
+  if (!args) { snprintf(g_err, sizeof(g_err), "gemm: null args"); return VC_ERR_ARG; }
+  return vc_gemm_launch(*args, tile_cfg, S(stream), ERRBUF);
+}
+int vc_ln_modulate(const void* x, int64_t ldx, void* y, int64_t ldy, const void* shift, const void* scale,
+                   int64_t mod_bstride, int32_t rows, int32_t D, int32_t rows_per_batch, const int32_t* step_ptr,
+                   int64_t mod_step_stride, void* stream) {
+  return vc_ln_modulate_launch(x, ldx, y, ldy, shift, scale, mod_bstride, rows, D, rows_per_batch, step_ptr,
+                               mod_step_stride, S(stream), ERRBUF);
+}
+int vc_qknorm_rope_vt(void* qkv, int64_t ld, int64_t bstride, const void* q_scale, const void* k_scale,
+                      const float* rope, int64_t rope_bstride, void* vt, int32_t B, int32_t L, int32_t Lpad, int32_t H,
+                      void* stream) {
+  return vc_qknorm_rope_vt_launch(qkv, ld, bstride, q_scale, k_scale, rope, rope_bstride, vt, B, L, Lpad, H, S(stream), ERRBUF);
+}
+int vc_attention(const void* qkv, int64_t ld, int64_t bstride, const void* vt, void* out, int64_t ldo,
+                 int64_t out_bstride, const int32_t* kv_len, int32_t B, int32_t L, int32_t Lpad, int32_t H,
+                 int32_t variant, void* stream) {
+  return vc_attention_launch(qkv, ld, bstride, vt, out, ldo, out_bstride, kv_len, B, L, Lpad, H, variant, S(stream), ERRBUF);
+}
+int vc_timestep_embedding(const float* t, const float* freqs, void* out_bf16, int32_t n, int32_t half,
+                          int32_t round_t_bf16, void* stream) {
+  return vc_temb_launch(t, freqs, out_bf16, n, half, round_t_bf16, S(stream), ERRBUF);
+}
+int vc_silu(const void* x, void* y, int64_t n, void* stream) { return vc_silu_launch(x, y, n, S(stream), ERRBUF); }
+int vc_add3(const void* a, const void* b, const void* c, void* y, int64_t n, void* stream) {
+  return vc_add3_launch(a, b, c, y, n, S(stream), ERRBUF);
+}
+int vc_concat_cols(const void* x, int32_t cx, const void* cond, int32_t cc, void* out, int64_t rows, void* stream) {
+  return vc_concat_cols_launch(x, cx, cond, cc, out, rows, S(stream), ERRBUF);
+}
+int vc_euler_step(void* x, const void* v, const float* dts, const int32_t* step_ptr, int64_t n, void* stream) {
+  return vc_euler_launch(x, v, dts, step_ptr, n, S(stream), ERRBUF);
+}
+int vc_step_advance(int32_t* step_ptr, void* stream) { return vc_step_advance_launch(step_ptr, S(stream), ERRBUF); }
+
+/* ---- streams / graphs / events ---- */
+int vc_stream_create(void** stream) {
+  if (!stream) { snprintf(g_err, sizeof(g_err), "stream_create: null"); return VC_ERR_ARG; }
+  hipStream_t s;
+  hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+  if (e != hipSuccess) return hip_fail("hipStreamCreate", e);
+  *stream = (void*)s;
+  return VC_OK;
+}
+int vc_stream_destroy(void* stream) {
+  hipError_t e = hipStreamDestroy(S(stream));
+  return e == hipSuccess ? VC_OK : hip_fail("hipStreamDestroy", e);
+}
+int vc_stream_sync(void* stream) {
+  hipError_t e = hipStreamSynchronize(S(stream));
+  return e == hipSuccess ? VC_OK : hip_fail("hipStreamSynchronize", e);
+}
+int vc_graph_begin(void* stream) {
+  hipError_t e = hipStreamBeginCapture(S(stream), hipStreamCaptureModeThreadLocal);
+  return e == hipSuccess ? VC_OK : hip_fail("hipStreamBeginCapture", e);
+}
+int vc_graph_end(void* stream, void** graph_exec) {
+  if (!graph_exec) { snprintf(g_err, sizeof(g_err), "graph_end: null"); return VC_ERR_ARG; }
+  hipGraph_t g = nullptr;
+  hipError_t e = hipStreamEndCapture(S(stream), &g);
+  if (e != hipSuccess) return hip_fail("hipStreamEndCapture", e);
+  hipGraphExec_t ge = nullptr;
+  e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (e != hipSuccess) return hip_fail("hipGraphInstantiate", e);
+  *graph_exec = (void*)ge;
+  return VC_OK;
+}
+int vc_graph_launch(void* graph_exec, void* stream) {
+  hipError_t e = hipGraphLaunch((hipGraphExec_t)graph_exec, S(stream));
+  return e == hipSuccess ? VC_OK : hip_fail("hipGraphLaunch", e);
+}
+int vc_graph_destroy(void* graph_exec) {
+  hipError_t e = hipGraphExecDestroy((hipGraphExec_t)graph_exec);
+  return e == hipSuccess ? VC_OK : hip_fail("hipGraphExecDestroy", e);
+}
+int vc_event_create(void** ev) {
+  if (!ev) { snprintf(g_err, sizeof(g_err), "event_create: null"); return VC_ERR_ARG; }
+  hipEvent_t e_;
+  hipError_t e = hipEventCreate(&e_);
+  if (e != hipSuccess) return hip_fail("hipEventCreate", e);
+  *ev = (void*)e_;
+  return VC_OK;
+}
+int vc_event_record(void* ev, void* stream) {
+  hipError_t e = hipEventRecord((hipEvent_t)ev, S(stream));
+  return e == hipSuccess ? VC_OK : hip_fail("hipEventRecord", e);
+}
+int vc_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms) {
+  hipError_t e = hipEventSynchronize((hipEvent_t)ev_stop);
+  if (e != hipSuccess) return hip_fail("hipEventSynchronize", e);
+  e = hipEventElapsedTime(ms, (hipEvent_t)ev_start, (hipEvent_t)ev_stop);
+  return e == hipSuccess ? VC_OK : hip_fail("hipEventElapsedTime", e);
+}
+int vc_event_destroy(void* ev) {
+  hipError_t e = hipEventDestroy((hipEvent_t)ev);
+  return e == hipSuccess ? VC_OK : hip_fail("hipEventDestroy", e);
+}
+
+}  // extern "C"

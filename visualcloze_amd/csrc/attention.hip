@@ -1,0 +1,236 @@
+// Joint text+image flash attention for gfx950 (non-causal, head_dim 128, bf16 MFMA, f32 online softmax).
+//
+// Replaces models/math.py:63-99 (`attention` -> flash_attn_varlen_func, scale 128^-0.5, p_drop 0) for the
+// stitched grid sequence cat(txt, img).  q,k are read straight out of the "B L (K H D)" qkv rows the QKV
+// GEMM wrote (already QK-normed + RoPE'd in place by vc_qknorm_rope_vt); V comes pre-transposed as
+// vt[b][h][d][Lpad] so that both MFMA operands are K-contiguous and no transpose happens in the loop.
+//
+// Work split: one workgroup = NW waves x 32 queries of one (batch, head); KV tiles of 64 keys stream through
+// a double-buffered LDS ring by global_load_lds.  Per wave and KV tile:
+//   S^T[u] = K_u . Q^T      2 x 8  v_mfma_f32_32x32x16_bf16   (swapped operands: a lane owns ONE query column,
+//                                                              so row max / row sum are lane-local + one xor-32)
+//   P = exp2(c*S - m)       f32, online max/sum, O rescaled by exp2(m_old - m_new)
+//   O^T += Vt . P^T         4 x 4  v_mfma_f32_32x32x16_bf16
+// K rows are fed to the MFMA with bits 2<->3 of the row index swapped, which makes the S^T accumulator
+// registers of a lane line up with 8 CONTIGUOUS keys per 16-key step -> P feeds PV with no cross-lane moves.
+// LDS images are lane-linear (DMA) with XOR slot swizzles applied on the source address and on the
+// ds_read_b128 address (K: slot ^= row&15 on 256-B rows; Vt: slot ^= (row>>1)&7 on 128-B rows).
+#include "common.h"
+#include "vcloze_internal.h"
+
+namespace {
+
+struct AttnArgs {
+  const bf16_t* qkv;
+  const bf16_t* vt;
+  bf16_t* out;
+  const int32_t* kv_len;
+  int64_t ld, bstride, ldo, out_bstride;
+  int32_t B, L, Lpad, H, qblocks;
+};
+
+constexpr int KVB = 64;               // keys per tile
+constexpr int K_TILE = KVB * 256;     // bytes
+constexpr int V_TILE = 128 * KVB * 2; // bytes
+constexpr int STAGE = K_TILE + V_TILE;
+
+VC_DEV int swap23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs a) {
+  constexpr int NT = NW * 64;
+  constexpr int K_IT = (K_TILE / 16) / NT, V_IT = (V_TILE / 16) / NT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lq = lane & 31, hh = lane >> 5;
+
+  int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int qb = id % a.qblocks;
+  const int bh = id / a.qblocks;
+  const int h = bh % a.H, b = bh / a.H;
+  const int L = a.L;
+  const int kvlen = a.kv_len ? a.kv_len[b] : L;
+
+  const bf16_t* __restrict__ qbase = a.qkv + (long)b * a.bstride + h * 128;
+  const bf16_t* __restrict__ kbase = qbase + a.H * 128;
+  const bf16_t* __restrict__ vbase = a.vt + ((long)(b * a.H + h) * 128) * a.Lpad;
+
+  // ---- staging offsets ----
+  uint32_t k_row[K_IT], k_col[K_IT], v_off[V_IT];
+#pragma unroll
+  for (int i = 0; i < K_IT; ++i) {
+    const int c = i * NT + tid;
+    const int row = c >> 4;
+    k_row[i] = row;
+    k_col[i] = (((c & 15) ^ (row & 15)) << 3);
+  }
+#pragma unroll
+  for (int i = 0; i < V_IT; ++i) {
+    const int c = i * NT + tid;
+    const int d = c >> 3;
+    v_off[i] = (uint32_t)d * (uint32_t)a.Lpad + ((((c & 7) ^ ((d >> 1) & 7))) << 3);
+  }
+  auto stage = [&](int buf, int kt) {
+    char* sk = smem + buf * STAGE;
+    char* sv = sk + K_TILE;
+#pragma unroll
+    for (int i = 0; i < K_IT; ++i) {
+      const int key = min(kt * KVB + (int)k_row[i], L - 1);
+      glds16(kbase + (long)key * a.ld + k_col[i], sk + (i * NT + wave * 64) * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < V_IT; ++i) glds16(vbase + v_off[i] + kt * KVB, sv + (i * NT + wave * 64) * 16);
+  };
+
+  const int nkt = (kvlen + KVB - 1) / KVB;
+  stage(0, 0);
+
+  // ---- Q fragments (B operand): lane = query lq, d = t*16 + hh*8 .. +7 ----
+  const int q0 = qb * (NW * 32) + wave * 32;
+  const int qrow = min(q0 + lq, L - 1);
+  bf16x8 qf[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) qf[t] = *(const bf16x8*)(qbase + (long)qrow * a.ld + t * 16 + hh * 8);
+
+  // ---- LDS read offsets ----
+  int k_rd[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int row = u * 32 + swap23(lq);
+    k_rd[u] = row * 256 + ((hh ^ (row & 15)) << 4);  // slot = 2t + hh  ->  ^ (t*32) per d-step
+  }
+  int v_rd[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    const int d = dt * 32 + lq;
+    v_rd[dt] = K_TILE + d * 128 + ((hh ^ ((d >> 1) & 7)) << 4);  // slot = 2s + hh -> ^ (s*32)
+  }
+
+  f32x16 o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float c_scale = 0.08838834764831845f * 1.4426950408889634f;  // 128^-0.5 * log2(e)
+
+  __syncthreads();
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nkt) stage(cur ^ 1, kt + 1);
+    const char* base = smem + cur * STAGE;
+
+    // S^T = K . Q^T
+    f32x16 s[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[u][r] = 0.f;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const bf16x8 kf = *(const bf16x8*)(base + (k_rd[u] ^ (t * 32)));
+        s[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[t], s[u], 0, 0, 0);
+      }
+    }
+    // mask keys beyond kv_len (only the last tile can hold any)
+    if (kt * KVB + KVB > kvlen) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * KVB + u * 32 + ((r >> 3) << 4) + hh * 8 + (r & 7);
+          if (key >= kvlen) s[u][r] = -INFINITY;
+        }
+    }
+    // online softmax (log2 domain)
+    float mx = s[0][0];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[u][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx * c_scale);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+    bf16x8 pf[4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(s[u][r] * c_scale - m_new);
+        psum += p;
+        pf[u * 2 + (r >> 3)][r & 7] = (__bf16)p;
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+
+    // O^T += Vt . P^T
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int sI = 0; sI < 4; ++sI) {
+        const bf16x8 vf = *(const bf16x8*)(base + (v_rd[dt] ^ (sI * 32)));
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[sI], o[dt], 0, 0, 0);
+      }
+    __syncthreads();
+  }
+
+  // ---- epilogue ----
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const int q = q0 + lq;
+  if (q < L) {
+    const float inv = (q < kvlen) ? 1.0f / l_tot : 0.0f;  // padded query rows -> 0 (pad_input, math.py:96)
+    bf16_t* orow = a.out + (long)b * a.out_bstride + (long)q * a.ldo + h * 128;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2 w;
+        w[0] = pack2bf(o[dt][g * 4 + 0] * inv, o[dt][g * 4 + 1] * inv);
+        w[1] = pack2bf(o[dt][g * 4 + 2] * inv, o[dt][g * 4 + 3] * inv);
+        *(u32x2*)(orow + dt * 32 + g * 8 + hh * 4) = w;
+      }
+  }
+}
+
+}  // namespace
+
+int vc_attention_launch(const void* qkv, int64_t ld, int64_t bstride, const void* vt, void* out, int64_t ldo,
+                        int64_t out_bstride, const int32_t* kv_len, int32_t B, int32_t L, int32_t Lpad,
+                        int32_t H, int32_t variant, hipStream_t s, char* err, int errlen) {
+  if (!qkv || !vt || !out) { snprintf(err, errlen, "attention: null pointer"); return VC_ERR_ARG; }
+  if (B <= 0 || L <= 0 || H <= 0) { snprintf(err, errlen, "attention: empty problem B=%d L=%d H=%d", B, L, H); return VC_ERR_ARG; }
+  if (Lpad < L || Lpad % KVB) { snprintf(err, errlen, "attention: Lpad=%d must be a multiple of %d and >= L=%d", Lpad, KVB, L); return VC_ERR_ARG; }
+  if (ld % 8 || ldo % 4 || bstride % 8) { snprintf(err, errlen, "attention: strides must keep 16-B row alignment"); return VC_ERR_ARG; }
+  if ((uint64_t)128 * (uint64_t)Lpad >= (1ull << 31)) { snprintf(err, errlen, "attention: Lpad too large"); return VC_ERR_ARG; }
+  AttnArgs a;
+  a.qkv = (const bf16_t*)qkv; a.vt = (const bf16_t*)vt; a.out = (bf16_t*)out; a.kv_len = kv_len;
+  a.ld = ld; a.bstride = bstride; a.ldo = ldo; a.out_bstride = out_bstride;
+  a.B = B; a.L = L; a.Lpad = Lpad; a.H = H;
+  const int lds = 2 * STAGE;
+  hipError_t e;
+  if (variant == 1) {  // 4 waves x 32 queries
+    a.qblocks = (L + 127) / 128;
+    static bool done = false;
+    if (!done) { e = hipFuncSetAttribute((const void*)attn_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) goto fail; done = true; }
+    hipLaunchKernelGGL(attn_fwd_kernel<4>, dim3(a.qblocks * H * B), dim3(256), lds, s, a);
+  } else {  // 8 waves x 32 queries
+    a.qblocks = (L + 255) / 256;
+    static bool done8 = false;
+    if (!done8) { e = hipFuncSetAttribute((const void*)attn_fwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) goto fail; done8 = true; }
+    hipLaunchKernelGGL(attn_fwd_kernel<8>, dim3(a.qblocks * H * B), dim3(512), lds, s, a);
+  }
+  e = hipGetLastError();
+  if (e == hipSuccess) return VC_OK;
+fail:
+  snprintf(err, errlen, "attention launch: %s", hipGetErrorString(e));
+  return VC_ERR_HIP;
+}

@@ -1,0 +1,56 @@
+// Shared device helpers for the gfx950 (CDNA4) kernels of the VisualCloze denoising path.
+// Everything here is wave64 / MI355X-only by design (no portability layer).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short bf16_t;  // raw bf16 bits in HBM
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define VC_DEV __device__ __forceinline__
+
+// round-to-nearest-even f32 -> bf16 (v_cvt_pk_bf16_f32 on gfx950)
+VC_DEV bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+VC_DEV float bf2f(bf16_t u) { return __builtin_bit_cast(float, ((uint32_t)u) << 16); }
+// round an f32 through bf16 (mimics a bf16 tensor materialised by the reference under autocast)
+VC_DEV float rbf(float f) { return bf2f(f2bf(f)); }
+VC_DEV uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+VC_DEV float lo_bf(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
+VC_DEV float hi_bf(uint32_t u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+
+VC_DEV float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// GELU(tanh) exactly as torch.nn.GELU(approximate="tanh") evaluates it in f32.
+VC_DEV float gelu_tanh(float x) {
+  const float k0 = 0.7978845608028654f;  // sqrt(2/pi)
+  const float k1 = 0.044715f;
+  float u = k0 * (x + k1 * x * x * x);
+  // tanh(u) = 1 - 2/(1+exp(2u)); saturates cleanly for |u| large
+  float t = 1.0f - 2.0f / (1.0f + __expf(2.0f * u));
+  return 0.5f * x * (1.0f + t);
+}
+VC_DEV float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+// async HBM -> LDS copy, 16 B per lane; LDS destination = wave-uniform base + lane*16
+VC_DEV void glds16(const void* g, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+
+// XCD-aware bijective block remap: hardware places block b on XCD b%8; give every XCD a contiguous
+// chunk of logical ids so neighbouring tiles share that XCD's L2 (speed only, never correctness).
+VC_DEV int xcd_remap(int bid, int nb) {
+  const int q = nb >> 3, r = nb & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return start + idx;
+}

@@ -1,0 +1,96 @@
+// Small elementwise kernels of the denoising path (all HBM/launch-bound, bf16 storage, f32 math).
+//   timestep_embedding  layers.py:28-49      silu / add3   MLPEmbedder + vec sum, model.py:102-107
+//   concat_cols         transport.py:193-196 (x || cond)   euler_step   torchdiffeq fixed-grid Euler update
+#include "common.h"
+#include "vcloze_internal.h"
+
+namespace {
+
+__global__ void temb_kernel(const float* __restrict__ t, const float* __restrict__ freqs, bf16_t* __restrict__ out,
+                            int n, int half, int round_t) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * half) return;
+  const int b = i / half, k = i % half;
+  float tt = 1000.0f * t[b];
+  if (round_t) tt = rbf(1000.0f * rbf(t[b]));  // reference multiplies a bf16 tensor: product rounds to bf16
+  const float arg = tt * freqs[k];
+  out[(long)b * 2 * half + k] = f2bf(cosf(arg));
+  out[(long)b * 2 * half + half + k] = f2bf(sinf(arg));
+}
+
+__global__ void silu_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = f2bf(silu_f(bf2f(x[i])));
+}
+
+__global__ void add3_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, const bf16_t* __restrict__ c,
+                            bf16_t* __restrict__ y, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v = rbf(bf2f(a[i]) + bf2f(b[i]));
+  if (c) v = v + bf2f(c[i]);
+  y[i] = f2bf(v);
+}
+
+// 16-B chunks; cx, cc multiples of 8
+__global__ void concat_cols_kernel(const u32x4* __restrict__ x, int cxc, const u32x4* __restrict__ cond, int ccc,
+                                   u32x4* __restrict__ out, long rows) {
+  const int w = cxc + ccc;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * w) return;
+  const long r = i / w;
+  const int c = (int)(i % w);
+  out[i] = (c < cxc) ? x[r * cxc + c] : cond[r * ccc + (c - cxc)];
+}
+
+__global__ void euler_kernel(bf16_t* __restrict__ x, const bf16_t* __restrict__ v, const float* __restrict__ dts,
+                             const int* __restrict__ step_ptr, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float dt = dts[step_ptr ? *step_ptr : 0];
+  const float dy = rbf(dt * (-bf2f(v[i])));
+  x[i] = f2bf(bf2f(x[i]) + dy);
+}
+
+__global__ void step_advance_kernel(int* step_ptr) { if (threadIdx.x == 0 && blockIdx.x == 0) *step_ptr += 1; }
+
+}  // namespace
+
+#define VC_CHECK_LAUNCH(name)                                                                     \
+  do {                                                                                            \
+    hipError_t e_ = hipGetLastError();                                                            \
+    if (e_ != hipSuccess) { snprintf(err, errlen, name " launch: %s", hipGetErrorString(e_)); return VC_ERR_HIP; } \
+    return VC_OK;                                                                                 \
+  } while (0)
+
+int vc_temb_launch(const float* t, const float* freqs, void* out, int n, int half, int round_t, hipStream_t s, char* err, int errlen) {
+  if (!t || !freqs || !out || n <= 0 || half <= 0) { snprintf(err, errlen, "timestep_embedding: bad args"); return VC_ERR_ARG; }
+  hipLaunchKernelGGL(temb_kernel, dim3((n * half + 255) / 256), dim3(256), 0, s, t, freqs, (bf16_t*)out, n, half, round_t);
+  VC_CHECK_LAUNCH("timestep_embedding");
+}
+int vc_silu_launch(const void* x, void* y, int64_t n, hipStream_t s, char* err, int errlen) {
+  if (!x || !y || n <= 0) { snprintf(err, errlen, "silu: bad args"); return VC_ERR_ARG; }
+  hipLaunchKernelGGL(silu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, (long)n);
+  VC_CHECK_LAUNCH("silu");
+}
+int vc_add3_launch(const void* a, const void* b, const void* c, void* y, int64_t n, hipStream_t s, char* err, int errlen) {
+  if (!a || !b || !y || n <= 0) { snprintf(err, errlen, "add3: bad args"); return VC_ERR_ARG; }
+  hipLaunchKernelGGL(add3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)b, (const bf16_t*)c, (bf16_t*)y, (long)n);
+  VC_CHECK_LAUNCH("add3");
+}
+int vc_concat_cols_launch(const void* x, int cx, const void* cond, int cc, void* out, int64_t rows, hipStream_t s, char* err, int errlen) {
+  if (!x || !cond || !out || rows <= 0 || cx <= 0 || cc <= 0 || cx % 8 || cc % 8) { snprintf(err, errlen, "concat_cols: need cx, cc positive multiples of 8"); return VC_ERR_ARG; }
+  const long n = rows * ((cx + cc) / 8);
+  hipLaunchKernelGGL(concat_cols_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const u32x4*)x, cx / 8, (const u32x4*)cond, cc / 8, (u32x4*)out, (long)rows);
+  VC_CHECK_LAUNCH("concat_cols");
+}
+int vc_euler_launch(void* x, const void* v, const float* dts, const int32_t* step_ptr, int64_t n, hipStream_t s, char* err, int errlen) {
+  if (!x || !v || !dts || n <= 0) { snprintf(err, errlen, "euler_step: bad args"); return VC_ERR_ARG; }
+  hipLaunchKernelGGL(euler_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (bf16_t*)x, (const bf16_t*)v, dts, step_ptr, (long)n);
+  VC_CHECK_LAUNCH("euler_step");
+}
+int vc_step_advance_launch(int32_t* step_ptr, hipStream_t s, char* err, int errlen) {
+  if (!step_ptr) { snprintf(err, errlen, "step_advance: null"); return VC_ERR_ARG; }
+  hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, s, step_ptr);
+  VC_CHECK_LAUNCH("step_advance");
+}

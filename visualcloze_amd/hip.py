@@ -1,0 +1,289 @@
+"""ctypes binding of libvcloze_hip.so (the C ABI in include/vcloze_hip.h).
+
+torch is used here only for device memory and streams: every wrapper takes torch CUDA tensors, checks
+dtype / contiguity on the host and hands raw device pointers to the library.  There is NO fallback:
+a missing library or a missing GPU raises (`VclozeHipError`)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+import torch  # noqa: F401  (must be imported first so the process shares torch's HIP runtime)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvcloze_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+EPI_BIAS, EPI_GELU, EPI_GATE_RES, EPI_SILU = 0, 1, 2, 3
+
+
+class VclozeHipError(RuntimeError):
+    pass
+
+
+class GemmProblem(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p), ("C", C.c_void_p),
+        ("res", C.c_void_p), ("gate", C.c_void_p),
+        ("lda", C.c_int64), ("ldc", C.c_int64), ("ldres", C.c_int64), ("gate_bstride", C.c_int64),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("rows_per_batch", C.c_int32),
+        ("tiles_m", C.c_int32), ("tiles_n", C.c_int32), ("tile_start", C.c_int32), ("_pad", C.c_int32),
+    ]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("p", GemmProblem * 2), ("nprob", C.c_int32), ("epi", C.c_int32),
+        ("step_ptr", C.c_void_p), ("gate_step_stride", C.c_int64),
+    ]
+
+
+# every symbol include/vcloze_hip.h declares: name -> (restype, argtypes)
+_vp, _i32, _i64 = C.c_void_p, C.c_int32, C.c_int64
+SYMBOLS = {
+    "vc_abi_version": (C.c_int, []),
+    "vc_last_error": (C.c_char_p, []),
+    "vc_device_count": (C.c_int, []),
+    "vc_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
+    "vc_gemm": (C.c_int, [C.POINTER(GemmArgs), C.c_int, _vp]),
+    "vc_ln_modulate": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp]),
+    "vc_qknorm_rope_vt": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "vc_attention": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "vc_timestep_embedding": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "vc_silu": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "vc_add3": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
+    "vc_concat_cols": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i64, _vp]),
+    "vc_euler_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
+    "vc_step_advance": (C.c_int, [_vp, _vp]),
+    "vc_stream_create": (C.c_int, [C.POINTER(_vp)]),
+    "vc_stream_destroy": (C.c_int, [_vp]),
+    "vc_stream_sync": (C.c_int, [_vp]),
+    "vc_graph_begin": (C.c_int, [_vp]),
+    "vc_graph_end": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "vc_graph_launch": (C.c_int, [_vp, _vp]),
+    "vc_graph_destroy": (C.c_int, [_vp]),
+    "vc_event_create": (C.c_int, [C.POINTER(_vp)]),
+    "vc_event_record": (C.c_int, [_vp, _vp]),
+    "vc_event_elapsed_ms": (C.c_int, [_vp, _vp, C.POINTER(C.c_float)]),
+    "vc_event_destroy": (C.c_int, [_vp]),
+}
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 into lib/libvcloze_hip.so (hipcc cross-compiles without a GPU)."""
+    if force or not os.path.exists(LIB_PATH) or any(
+        os.path.getmtime(os.path.join(CSRC, f)) > os.path.getmtime(LIB_PATH)
+        for f in os.listdir(CSRC) if f.endswith((".hip", ".h", "Makefile"))
+    ):
+        r = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise VclozeHipError("building libvcloze_hip.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    return LIB_PATH
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VclozeHipError(
+                f"{LIB_PATH} is missing — run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(the HIP extension is mandatory; there is no CPU fallback)")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(l, name)  # AttributeError if the ABI lost a symbol
+            fn.restype, fn.argtypes = res, args
+        if l.vc_abi_version() != 1:
+            raise VclozeHipError("libvcloze_hip.so ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise VclozeHipError(f"{what} failed ({rc}): {lib().vc_last_error().decode()}")
+
+
+def require_gpu() -> None:
+    if lib().vc_device_count() < 1:
+        raise VclozeHipError("no ROCm device visible: " + lib().vc_last_error().decode())
+
+
+def cur_stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _bf16(t: torch.Tensor, name: str) -> None:
+    if t.dtype != torch.bfloat16 or not t.is_cuda:
+        raise VclozeHipError(f"{name}: expected a CUDA bf16 tensor, got {t.dtype} on {t.device}")
+
+
+# ------------------------------------------------------------------------------------------------
+# op wrappers (2-D row-major views; the last dim must be contiguous)
+# ------------------------------------------------------------------------------------------------
+def make_problem(a, w, bias, out, res=None, gate=None, rows_per_batch=None, gate_bstride=0) -> GemmProblem:
+    for n, t in (("A", a), ("W", w), ("C", out)):
+        _bf16(t, n)
+        if t.dim() != 2 or t.stride(1) != 1:
+            raise VclozeHipError(f"gemm {n}: need a 2-D tensor with contiguous last dim")
+    if not w.is_contiguous():
+        raise VclozeHipError("gemm W must be contiguous [N,K]")
+    M, K = a.shape
+    N = w.shape[0]
+    if w.shape[1] != K or tuple(out.shape) != (M, N):
+        raise VclozeHipError(f"gemm shape mismatch A{tuple(a.shape)} W{tuple(w.shape)} C{tuple(out.shape)}")
+    p = GemmProblem()
+    p.A, p.W, p.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
+    p.bias = _p(bias)
+    p.lda, p.ldc = a.stride(0), out.stride(0)
+    p.M, p.N, p.K = M, N, K
+    p.rows_per_batch = rows_per_batch or M
+    if res is not None:
+        _bf16(res, "res")
+        p.res, p.ldres = res.data_ptr(), res.stride(0)
+    if gate is not None:
+        _bf16(gate, "gate")
+        p.gate, p.gate_bstride = gate.data_ptr(), gate_bstride
+    return p
+
+
+def gemm(problems, epi=EPI_BIAS, tile_cfg=0, step_ptr=None, gate_step_stride=0, stream=None) -> None:
+    args = GemmArgs()
+    if isinstance(problems, GemmProblem):
+        problems = [problems]
+    args.nprob = len(problems)
+    for i, p in enumerate(problems):
+        args.p[i] = p
+    args.epi = epi
+    args.step_ptr = _p(step_ptr)
+    args.gate_step_stride = gate_step_stride
+    _check(lib().vc_gemm(C.byref(args), tile_cfg, stream if stream is not None else cur_stream()), "vc_gemm")
+
+
+def linear(a, w, bias=None, out=None, epi=EPI_BIAS, res=None, gate=None, tile_cfg=0, stream=None):
+    if out is None:
+        out = torch.empty(a.shape[0], w.shape[0], dtype=torch.bfloat16, device=a.device)
+    gemm(make_problem(a, w, bias, out, res=res, gate=gate), epi=epi, tile_cfg=tile_cfg, stream=stream)
+    return out
+
+
+def ln_modulate(x, shift, scale, out=None, step_ptr=None, mod_step_stride=0, stream=None):
+    _bf16(x, "x")
+    rows, D = x.shape
+    if out is None:
+        out = torch.empty(rows, D, dtype=torch.bfloat16, device=x.device)
+    _check(lib().vc_ln_modulate(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), shift.data_ptr(),
+                                scale.data_ptr(), 0, rows, D, rows, _p(step_ptr), mod_step_stride,
+                                stream if stream is not None else cur_stream()), "vc_ln_modulate")
+    return out
+
+
+def qknorm_rope_vt(qkv, q_scale, k_scale, rope, vt, L, H, stream=None):
+    """qkv: [L, >=3*H*128] rows (q|k|v at column 0, H*128, 2*H*128); rope: [L,64,2] f32; vt: [H,128,Lpad]."""
+    _bf16(qkv, "qkv")
+    if rope.dtype != torch.float32 or not rope.is_contiguous():
+        raise VclozeHipError("rope table must be contiguous f32 [L,64,2]")
+    Lpad = vt.shape[-1]
+    _check(lib().vc_qknorm_rope_vt(qkv.data_ptr(), qkv.stride(0), 0, q_scale.data_ptr(), k_scale.data_ptr(),
+                                   rope.data_ptr(), 0, vt.data_ptr(), 1, L, Lpad, H,
+                                   stream if stream is not None else cur_stream()), "vc_qknorm_rope_vt")
+
+
+def attention(qkv, vt, out, L, H, kv_len=None, variant=0, stream=None):
+    """out: [L, >=H*128] rows (B L (H D)); kv_len: optional int32 device tensor [1]."""
+    _bf16(qkv, "qkv"); _bf16(vt, "vt"); _bf16(out, "out")
+    Lpad = vt.shape[-1]
+    _check(lib().vc_attention(qkv.data_ptr(), qkv.stride(0), 0, vt.data_ptr(), out.data_ptr(), out.stride(0), 0,
+                              _p(kv_len), 1, L, Lpad, H, variant,
+                              stream if stream is not None else cur_stream()), "vc_attention")
+
+
+def timestep_embedding(t_f32, freqs_f32, out_bf16, round_t_bf16=False, stream=None):
+    n, half = t_f32.numel(), freqs_f32.numel()
+    _check(lib().vc_timestep_embedding(t_f32.data_ptr(), freqs_f32.data_ptr(), out_bf16.data_ptr(), n, half,
+                                       int(round_t_bf16), stream if stream is not None else cur_stream()),
+           "vc_timestep_embedding")
+
+
+def silu(x, out=None, stream=None):
+    out = torch.empty_like(x) if out is None else out
+    _check(lib().vc_silu(x.data_ptr(), out.data_ptr(), x.numel(), stream if stream is not None else cur_stream()), "vc_silu")
+    return out
+
+
+def add3(a, b, c=None, out=None, stream=None):
+    out = torch.empty_like(a) if out is None else out
+    _check(lib().vc_add3(a.data_ptr(), b.data_ptr(), _p(c), out.data_ptr(), a.numel(),
+                         stream if stream is not None else cur_stream()), "vc_add3")
+    return out
+
+
+def concat_cols(x, cond, out, stream=None):
+    rows = x.shape[0]
+    _check(lib().vc_concat_cols(x.data_ptr(), x.shape[1], cond.data_ptr(), cond.shape[1], out.data_ptr(), rows,
+                                stream if stream is not None else cur_stream()), "vc_concat_cols")
+    return out
+
+
+def euler_step(x, v, dts, step_ptr=None, stream=None):
+    _check(lib().vc_euler_step(x.data_ptr(), v.data_ptr(), dts.data_ptr(), _p(step_ptr), x.numel(),
+                               stream if stream is not None else cur_stream()), "vc_euler_step")
+
+
+def step_advance(step_ptr, stream=None):
+    _check(lib().vc_step_advance(step_ptr.data_ptr(), stream if stream is not None else cur_stream()), "vc_step_advance")
+
+
+class Graph:
+    """hipGraph captured from the launches issued on `stream` inside the with-block."""
+
+    def __init__(self, stream: int):
+        self.stream = stream
+        self.exec = C.c_void_p()
+
+    def __enter__(self):
+        _check(lib().vc_graph_begin(self.stream), "vc_graph_begin")
+        return self
+
+    def __exit__(self, et, ev, tb):
+        rc = lib().vc_graph_end(self.stream, C.byref(self.exec))
+        if et is None:
+            _check(rc, "vc_graph_end")
+        return False
+
+    def launch(self, stream: Optional[int] = None):
+        _check(lib().vc_graph_launch(self.exec, stream if stream is not None else self.stream), "vc_graph_launch")
+
+    def __del__(self):
+        try:
+            if self.exec:
+                lib().vc_graph_destroy(self.exec)
+        except Exception:
+            pass
+
+
+class Event:
+    def __init__(self):
+        self.h = C.c_void_p()
+        _check(lib().vc_event_create(C.byref(self.h)), "vc_event_create")
+
+    def record(self, stream=None):
+        _check(lib().vc_event_record(self.h, stream if stream is not None else cur_stream()), "vc_event_record")
+
+    def elapsed_ms(self, stop: "Event") -> float:
+        ms = C.c_float()
+        _check(lib().vc_event_elapsed_ms(self.h, stop.h, C.byref(ms)), "vc_event_elapsed_ms")
+        return ms.value
+
+    def __del__(self):
+        try:
+            lib().vc_event_destroy(self.h)
+        except Exception:
+            pass

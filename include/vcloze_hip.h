@@ -70,10 +70,12 @@ int vc_ln_modulate(const void* x, int64_t ldx, void* y, int64_t ldy, const void*
 /* QK-RMSNorm (layers.py:63-84) + RoPE (math.py:112-117) in place on q,k, and V transposed to
  * vt[b][h][d][Lpad] for the attention kernel.  qkv: token rows of stride ld (elements) holding
  * q | k | v at column offsets 0, H*128, 2*H*128 ("B L (K H D)", layers.py:166).
- * rope: [B?][L][64][2] f32 (cos, sin) per pair; rope_bstride 0 = shared by the batch. */
+ * rope: [B?][L][64][2] f32 (cos, sin) per pair; rope_bstride 0 = shared by the batch.
+ * Token rows < split use (q_scale, k_scale), rows >= split use (q_scale2, k_scale2): the text and image
+ * streams of a DoubleStreamBlock own separate QKNorm scales (layers.py:167,174); NULL scale2 = one set. */
 int vc_qknorm_rope_vt(void* qkv, int64_t ld, int64_t bstride, const void* q_scale, const void* k_scale,
-                      const float* rope, int64_t rope_bstride, void* vt, int32_t B, int32_t L, int32_t Lpad,
-                      int32_t H, void* stream);
+                      const void* q_scale2, const void* k_scale2, int32_t split, const float* rope,
+                      int64_t rope_bstride, void* vt, int32_t B, int32_t L, int32_t Lpad, int32_t H, void* stream);
 
 /* Joint text+image attention, non-causal, D=128, softmax scale 128^-0.5 (math.py:63-99 /
  * flash_attn_varlen_func).  q,k from the qkv rows above; vt from vc_qknorm_rope_vt.
@@ -88,7 +90,10 @@ int vc_timestep_embedding(const float* t, const float* freqs, void* out_bf16, in
                           int32_t round_t_bf16, void* stream);
 /* elementwise helpers on bf16 vectors */
 int vc_silu(const void* x, void* y, int64_t n, void* stream);
-int vc_add3(const void* a, const void* b, const void* c, void* y, int64_t n, void* stream); /* bf16(bf16(a+b)+c); c NULL ok */
+/* y[i] = bf16(bf16(a[i] + b[i % bn]) + c[i % cn]); c may be NULL (model.py:102-107: vec = time + guidance + vector) */
+int vc_add3(const void* a, const void* b, const void* c, void* y, int64_t n, int64_t bn, int64_t cn, void* stream);
+/* device-to-device copy on `stream` (captured as a memcpy node): restores the step-invariant txt rows */
+int vc_copy(void* dst, const void* src, int64_t bytes, void* stream);
 /* x||cond -> [rows, cx+cc] (transport.py:195) */
 int vc_concat_cols(const void* x, int32_t cx, const void* cond, int32_t cc, void* out, int64_t rows, void* stream);
 /* Euler update of the fixed-grid solver: x = bf16(x + bf16(dt * (-v))), dt = dts[*step_ptr] (f32). */

@@ -1,0 +1,103 @@
+"""CPU: host-side mirror of the reference interface, the C-ABI surface, and the oracle-vs-host time grids."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_exports_every_declared_symbol():
+    from visualcloze_amd import hip
+    if not os.path.exists(hip.LIB_PATH):
+        hip.build()
+    lib = ctypes.CDLL(hip.LIB_PATH)
+    hdr = open(os.path.join(REPO, "include", "vcloze_hip.h")).read()
+    declared = set(re.findall(r"\b(vc_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(hip.SYMBOLS), declared ^ set(hip.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert hip.lib().vc_abi_version() == 1
+
+
+def test_struct_layout_matches_header():
+    from visualcloze_amd import hip
+    assert ctypes.sizeof(hip.GemmProblem) == 6 * 8 + 4 * 8 + 8 * 4
+    assert ctypes.sizeof(hip.GemmArgs) == 2 * ctypes.sizeof(hip.GemmProblem) + 8 + 8 + 8
+
+
+def test_no_gpu_fails_loudly():
+    from visualcloze_amd import hip
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(hip.VclozeHipError):
+        hip.require_gpu()
+    from visualcloze_amd.model import FluxLoraWrapper, FluxParams
+    from tests.procedural import TINY
+    m = FluxLoraWrapper(lora_rank=4, params=FluxParams(**TINY))
+    with pytest.raises(hip.VclozeHipError):                       # no CPU fallback
+        m(torch.zeros(1, 8, 384), torch.zeros(1, 8, 3), torch.zeros(1, 4, 128), torch.zeros(1, 4, 3),
+          torch.ones(1), torch.zeros(1, 64), guidance=torch.ones(1))
+
+
+def test_state_dict_contract(golden):
+    """B3: parameter names, shapes and order equal the reference's FluxLoraWrapper."""
+    from visualcloze_amd.model import FluxLoraWrapper, FluxParams
+    from tests.procedural import TINY, TINY_RANK
+    m = FluxLoraWrapper(lora_rank=TINY_RANK, lora_scale=1.0, params=FluxParams(**TINY))
+    mine = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    ref = list(zip([str(k) for k in golden["keys"]],
+                   [tuple(int(x) for x in str(s).split(",")) for s in golden["shapes"]]))
+    assert mine == ref
+    lora_only = {k: v for k, v in m.state_dict().items() if "lora" in k}
+    missing, unexpected = m.load_state_dict(lora_only, strict=False)    # visualcloze.py:111-112
+    assert not unexpected and all("lora" not in k for k in missing)
+    assert m.double_blocks[0].img_attn.qkv.lora_B.weight.abs().sum() == 0   # lora_B zero-init (lora.py:84-86)
+
+
+def test_constructor_errors():
+    from visualcloze_amd.model import Flux, FluxParams
+    from tests.procedural import TINY
+    with pytest.raises(ValueError):
+        Flux(FluxParams(**{**TINY, "hidden_size": 250}))
+    with pytest.raises(ValueError):
+        Flux(FluxParams(**{**TINY, "axes_dim": [16, 56, 48]}))
+
+
+@pytest.mark.parametrize("args", [dict(num_steps=30, n=3456, do_shift=True, tsf=1, strength=None),
+                                  dict(num_steps=4, n=1152, do_shift=True, tsf=1, strength=None),
+                                  dict(num_steps=10, n=4096, do_shift=False, tsf=1.0, strength=0.4)])
+def test_host_time_grid_equals_oracle(args):
+    import oracle.flux_oracle as O
+    from visualcloze_amd.transport import solver_time_grid
+    t0 = 0 if args["strength"] is None else args["strength"]
+    mine = solver_time_grid(args["num_steps"], args["n"], t0, 1, args["do_shift"], args["tsf"])
+    ref = O.time_grid(args["num_steps"], args["n"], args["do_shift"], args["tsf"], args["strength"])
+    assert torch.equal(mine, ref)
+
+
+def test_transport_surface():
+    from visualcloze_amd.transport import Sampler, create_transport
+    s = Sampler(create_transport("Linear", "velocity", do_shift=True))
+    with pytest.raises(NotImplementedError):
+        s.sample_ode(sampling_method="dopri5")
+    with pytest.raises(NotImplementedError):
+        create_transport("VP", "noise")
+    with pytest.raises(AssertionError):
+        s.sample_ode(sampling_method="euler", strength=1.0)
+    fn = s.sample_ode(sampling_method="euler", num_steps=4, atol=1e-6, rtol=1e-3, reverse=False, do_shift=True,
+                      time_shifting_factor=1)
+    # foreign callable path (CPU-capable): 3 evaluations at 1 - t, cond concatenated, kwargs not mutated
+    seen = []
+
+    def model(x, timesteps, **kw):
+        seen.append((float(timesteps[0]), x.shape[-1]))
+        return torch.ones_like(x[..., :2])
+    kw = dict(cond=torch.zeros(1, 1152, 3), foo=1)
+    out = fn(torch.zeros(1, 1152, 2), model, kw)
+    assert out.shape == (1, 1, 1152, 2) and len(seen) == 3 and "cond" in kw
+    # first evaluation at 1 - t[0]; the reference's own shifted grid starts at 6e-8, not exactly 0 (golden vectors)
+    assert abs(seen[0][0] - 1.0) < 1e-6 and seen[0][1] == 5
+    assert torch.allclose(out, torch.full_like(out, -1.0), atol=1e-6)     # integral of -1 over [0,1]

@@ -1,0 +1,200 @@
+"""-m gpu: every HIP kernel behind the C ABI against a plain PyTorch f32 reference of the same op
+(tests/ref_ops.py), on seeded inputs, including ragged / tail / strided / empty-input cases.
+Tolerance: outputs are bf16, so |err| <= 2e-2 * max|ref| elementwise and rel-L2 <= 2e-2 (bf16 eps = 7.8e-3)."""
+import pytest
+import torch
+
+from tests import ref_ops as R
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16).to(DEV)
+
+
+def check(got, ref, tol=2e-2):
+    got, ref = got.float(), ref.float()
+    assert torch.isfinite(got).all()
+    denom = ref.abs().max().item() + 1e-12
+    assert (got - ref).abs().max().item() <= tol * denom
+    if ref.norm() > 0:
+        assert ((got - ref).norm() / ref.norm()).item() <= tol
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from visualcloze_amd import hip as h
+    h.require_gpu()
+    return h
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 3])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3])
+@pytest.mark.parametrize("shape", [(128, 128, 64), (200, 192, 128), (37, 64, 256), (513, 260, 384), (1, 512, 256)])
+def test_gemm(hip, cfg, epi, shape):
+    M, N, K = shape
+    a_full = rnd(M, K + 64, seed=1)
+    a = a_full[:, :K]                       # strided A (lda != K)
+    w, bias = rnd(N, K, scale=K ** -0.5, seed=2), rnd(N, seed=3)
+    res, gate = rnd(M, N, seed=4), rnd(N, seed=5)
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    p = hip.make_problem(a, w, bias, out, res=res if epi == 2 else None, gate=gate if epi == 2 else None)
+    hip.gemm(p, epi=epi, tile_cfg=cfg)
+    torch.cuda.synchronize()
+    check(out, R.gemm_ref(a, w, bias, epi, res, gate))
+
+
+def test_gemm_transpose_detecting(hip):
+    """A = I with an asymmetric W: a transposed C write cannot pass."""
+    n = 128
+    a = torch.eye(n, dtype=torch.bfloat16, device=DEV)
+    w = (torch.arange(n * n, device=DEV).reshape(n, n) % 61).to(torch.bfloat16)
+    out = hip.linear(a, w)
+    torch.cuda.synchronize()
+    assert torch.equal(out.float(), w.float().t())
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
+def test_gemm_grouped_and_inplace_residual(hip, cfg):
+    M1, M2, N, K = 300, 136, 384, 256
+    a1, a2 = rnd(M1, K, seed=1), rnd(M2, K, seed=2)
+    w1, w2 = rnd(N, K, scale=K ** -0.5, seed=3), rnd(N, K, scale=K ** -0.5, seed=4)
+    b1, b2 = rnd(N, seed=5), rnd(N, seed=6)
+    x = rnd(M1 + M2, N, seed=7)
+    x0 = x.clone()
+    g1, g2 = rnd(N, seed=8), rnd(N, seed=9)
+    p1 = hip.make_problem(a1, w1, b1, x[M2:], res=x[M2:], gate=g1)
+    p2 = hip.make_problem(a2, w2, b2, x[:M2], res=x[:M2], gate=g2)
+    hip.gemm([p1, p2], epi=hip.EPI_GATE_RES, tile_cfg=cfg)
+    torch.cuda.synchronize()
+    ref = torch.cat([R.gemm_ref(a2, w2, b2, 2, x0[:M2], g2), R.gemm_ref(a1, w1, b1, 2, x0[M2:], g1)])
+    check(x, ref)
+
+
+def test_gemm_rejects_bad_arguments(hip):
+    a, w = rnd(8, 100), rnd(16, 100)
+    with pytest.raises(hip.VclozeHipError):          # K not a multiple of 64
+        hip.linear(a, w)
+    with pytest.raises(hip.VclozeHipError):          # empty input
+        hip.linear(rnd(0, 64), rnd(16, 64))
+    with pytest.raises(hip.VclozeHipError):          # dtype
+        hip.linear(torch.zeros(8, 64, device=DEV), rnd(16, 64))
+
+
+@pytest.mark.parametrize("rows,D", [(10, 256), (1000, 3072), (7, 4096), (3, 8)])
+def test_ln_modulate(hip, rows, D):
+    x = rnd(rows, D, scale=2.0, seed=1) + 0.5
+    sh, sc = rnd(D, seed=2), rnd(D, scale=0.3, seed=3)
+    out = hip.ln_modulate(x, sh, sc)
+    torch.cuda.synchronize()
+    check(out, R.ln_modulate_ref(x, sh, sc))
+
+
+def rope_table(L):
+    pos = torch.arange(L, dtype=torch.float64)[:, None] * torch.linspace(0.01, 1.0, 64, dtype=torch.float64)[None]
+    return torch.stack([torch.cos(pos), torch.sin(pos)], -1).float().to(DEV).contiguous()
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("L,H,extra,kv_len,split", [(64, 2, 0, None, 0), (40, 2, 0, None, 16), (200, 3, 256, None, 0),
+                                                    (333, 2, 0, 301, 128), (1, 1, 0, None, 0), (1664, 4, 0, None, 512)])
+def test_qknorm_rope_vt_and_attention(hip, variant, L, H, extra, kv_len, split):
+    ld = 3 * H * 128 + extra
+    qkv = rnd(L, ld, seed=7)
+    qs, ks = (1 + 0.1 * rnd(128, seed=8)).to(torch.bfloat16), (1 + 0.1 * rnd(128, seed=9)).to(torch.bfloat16)
+    qs2, ks2 = (1 + 0.1 * rnd(128, seed=10)).to(torch.bfloat16), (1 + 0.1 * rnd(128, seed=11)).to(torch.bfloat16)
+    rope = rope_table(L)
+    Lpad = (L + 63) // 64 * 64
+    vt = torch.full((H, 128, Lpad), float("nan"), dtype=torch.bfloat16, device=DEV)
+    qa, ka, vtref = R.qknorm_rope_ref(qkv, qs, ks, rope, H)
+    qb, kb, _ = R.qknorm_rope_ref(qkv, qs2, ks2, rope, H)
+    qref, kref = torch.cat([qa[:split], qb[split:]]), torch.cat([ka[:split], kb[split:]])
+    work = qkv.clone()
+    hip.qknorm_rope_vt(work, qs, ks, rope, vt, L, H, q_scale2=qs2, k_scale2=ks2, split=split)
+    torch.cuda.synchronize()
+    got = work[:, : 3 * H * 128].float().reshape(L, 3, H, 128)
+    check(got[:, 0], qref); check(got[:, 1], kref)
+    assert torch.equal(vt[:, :, :L].float(), vtref)                     # exact: pure data movement
+    assert float(vt[:, :, L:].float().abs().sum()) == 0.0               # padded keys zero-filled
+    assert torch.equal(work[:, 2 * H * 128:], qkv[:, 2 * H * 128:])      # v and trailing columns untouched
+    out = torch.full((L, H * 128), float("nan"), dtype=torch.bfloat16, device=DEV)
+    kvl = None if kv_len is None else torch.tensor([kv_len], dtype=torch.int32, device=DEV)
+    hip.attention(work, vt, out, L, H, kv_len=kvl, variant=variant)
+    torch.cuda.synchronize()
+    v = qkv[:, 2 * H * 128: 3 * H * 128].float().reshape(L, H, 128)
+    check(out, R.attention_ref(got[:, 0], got[:, 1], v, kv_len))
+    if kv_len is not None:
+        assert float(out[kv_len:].float().abs().sum()) == 0.0           # pad_input semantics (math.py:96)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_attention_softmax_rescale_branch(hip, variant):
+    """Force the online-softmax running max to jump late (a spiked key in the LAST tile) and early."""
+    L, H = 256, 1
+    q = torch.zeros(L, 3 * 128, device=DEV)
+    g = torch.Generator().manual_seed(3)
+    q.copy_(torch.randn(L, 384, generator=g) * 0.5)
+    q[:, 128:256][200] = q[:, 0:128][7] * 40.0          # key 200 aligned with query 7 -> huge logit
+    q[:, 128:256][3] = q[:, 0:128][100] * 40.0          # key 3 aligned with query 100
+    qkv = q.to(torch.bfloat16)
+    vt = qkv[:, 256:].t().contiguous().reshape(1, 128, L)
+    out = torch.empty(L, 128, dtype=torch.bfloat16, device=DEV)
+    hip.attention(qkv, vt, out, L, H, variant=variant)
+    torch.cuda.synchronize()
+    x = qkv.float().reshape(L, 3, 1, 128)
+    check(out, R.attention_ref(x[:, 0], x[:, 1], x[:, 2]))
+
+
+def test_elementwise(hip):
+    import oracle.flux_oracle as O
+    t = torch.tensor([0.0, 0.348, 1.0], device=DEV)
+    fr = O.temb_freqs().to(DEV)
+    out = torch.empty(3, 256, dtype=torch.bfloat16, device=DEV)
+    hip.timestep_embedding(t, fr, out)
+    check(out, O.timestep_embedding(t.cpu()).to(DEV), 1e-2)
+    g = torch.tensor([30.0], device=DEV)
+    out = torch.empty(1, 256, dtype=torch.bfloat16, device=DEV)
+    hip.timestep_embedding(g, fr, out, round_t_bf16=True)
+    check(out, O.timestep_embedding(g.cpu(), t_is_bf16=True).to(DEV), 1e-2)
+    x = rnd(1000, seed=1)
+    check(hip.silu(x), R.rb(torch.nn.functional.silu(x.float())))
+    a, b, c = rnd(4, 777, seed=2), rnd(777, seed=3), rnd(777, seed=4)
+    check(hip.add3(a, b, c), R.rb(R.rb(a.float() + b.float()) + c.float()))      # b, c broadcast over rows
+    check(hip.add3(a, b), R.rb(a.float() + b.float()))
+    xx, cc = rnd(50, 64, seed=5), rnd(50, 320, seed=6)
+    o = torch.empty(50, 384, dtype=torch.bfloat16, device=DEV)
+    hip.concat_cols(xx, cc, o)
+    assert torch.equal(o, torch.cat([xx, cc], -1))
+    xs, v = rnd(999, seed=7), rnd(999, seed=8)
+    dts = torch.tensor([0.1, 0.037, 0.2], device=DEV)
+    step = torch.tensor([1], dtype=torch.int32, device=DEV)
+    ref = R.rb(xs.float() + R.rb(0.037 * (-v.float())))
+    hip.euler_step(xs, v, dts, step)
+    check(xs, ref, 1e-6)
+    hip.step_advance(step)
+    assert step.item() == 2
+    d = torch.empty_like(a)
+    hip.copy(d, a)
+    assert torch.equal(d, a)
+
+
+def test_graph_replay_with_device_step_counter(hip):
+    st = torch.cuda.Stream()
+    a, w, bias = rnd(256, 128, seed=1), rnd(128, 128, scale=0.1, seed=2), rnd(128, seed=3)
+    out = torch.zeros(256, 128, dtype=torch.bfloat16, device=DEV)
+    gates, res = rnd(3, 128, seed=4), rnd(256, 128, seed=5)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    p = hip.make_problem(a, w, bias, out, res=res, gate=gates)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(st):
+        s = st.cuda_stream
+        with hip.Graph(s) as g:
+            hip.gemm(p, epi=2, step_ptr=step, gate_step_stride=128, stream=s)
+            hip.step_advance(step, stream=s)
+        for i in range(3):
+            g.launch()
+            st.synchronize()
+            check(out, R.gemm_ref(a, w, bias, 2, res, gates[i]))

@@ -1,0 +1,149 @@
+"""CPU: the oracle (oracle/flux_oracle.py) against the golden vectors produced by the REFERENCE ITSELF
+(tests/golden/make_golden.py ran /root/reference under shims in the build container)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle.flux_oracle as O
+from tests.procedural import TINY, procedural_param, ptensor, tiny_inputs
+
+G = O.FluxGeometry(**TINY)
+F32 = O.Prec("fp32")
+
+
+def close(a, b, tol=2e-5):
+    a, b = torch.as_tensor(a).float(), torch.as_tensor(b).float()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a - b).abs().max().item()
+    assert err <= tol * max(1.0, b.abs().max().item()), err
+
+
+def test_rope_table_and_apply(golden):
+    ids = torch.tensor(golden["pe_ids"])
+    cs = O.rope_cos_sin(ids, G.axes_dim, G.theta)                  # [B,L,64,2]
+    pe = torch.tensor(golden["pe"])[:, 0]                          # [B,L,64,2,2] = [[cos,-sin],[sin,cos]]
+    close(cs[..., 0], pe[..., 0, 0]); close(cs[..., 1], pe[..., 1, 0]); close(-cs[..., 1], pe[..., 0, 1])
+    assert float(ids[0, -1, 0]) == 2.0                             # row index + 1 (sampling.py:57)
+    q = torch.tensor(golden["rope_q_in"])
+    close(O.apply_rope(q, cs, F32), golden["rope_q_out"])
+    close(O.apply_rope(ptensor(q.shape, 12, q=6), cs, F32), golden["rope_k_out"])
+
+
+def test_timestep_embedding(golden):
+    close(O.timestep_embedding(torch.tensor(golden["temb_t"])), golden["temb"], 1e-4)
+    close(O.timestep_embedding(torch.tensor([30.0])), golden["temb_g30"], 1e-3)
+
+
+def test_qknorm_and_modulation(golden, tiny_sd):
+    L = golden["pe_ids"].shape[1]
+    q, k = ptensor((1, 2, L, 128), 11, q=6), ptensor((1, 2, L, 128), 12, q=6)
+    pf = "double_blocks.0.img_attn.norm"
+    close(O.rms_norm(q, tiny_sd[pf + ".query_norm.scale"], F32), golden["qknorm_q"])
+    close(O.rms_norm(k, tiny_sd[pf + ".key_norm.scale"], F32), golden["qknorm_k"])
+    vec = torch.tensor(golden["mod_vec"])
+    out = torch.cat(O.modulation(tiny_sd, "double_blocks.0.img_mod", vec, 6, F32), dim=-1)
+    close(out, golden["mod_out"])                                  # chunk order shift,scale,gate x2
+
+
+def test_attention_full_and_ragged(golden):
+    L = golden["pe_ids"].shape[1]
+    cs = O.rope_cos_sin(torch.tensor(golden["pe_ids"]), G.axes_dim, G.theta).repeat(2, 1, 1, 1)
+    q, k, v = (ptensor((2, 2, L, 128), s, q=6) for s in (21, 22, 23))
+    rq, rk = O.apply_rope(q, cs, F32), O.apply_rope(k, cs, F32)
+    close(O.sdpa(rq, rk, v, F32), golden["attn_full"])
+    kv = [int(x) for x in golden["attn_ragged_mask"].sum(1)]
+    got = O.sdpa(rq, rk, v, F32, kv_len=kv)
+    close(got, golden["attn_ragged"])
+    assert float(got[1, kv[1]:].abs().max()) == 0.0               # padded query rows -> zeros (pad_input)
+
+
+def test_lora_rank_clip(golden):
+    keys = [str(k) for k in golden["lora_clip_keys"]]
+    shapes = [tuple(int(x) for x in str(s).split(",")) for s in golden["lora_clip_shapes"]]
+    assert dict(zip(keys, shapes))["lora_A.weight"] == (4, 12)     # rank clipped to min(in, out)
+    sd = {"l." + k: procedural_param("lltest." + k, s) for k, s in zip(keys, shapes)}
+    close(O.linear(sd, "l", torch.tensor(golden["lora_clip_in"]), F32, lora_scale=0.5), golden["lora_clip_out"])
+    close(O.linear(sd, "l", torch.tensor(golden["lora_clip_in"]), O.Prec("fp32", "merged"), lora_scale=0.5),
+          golden["lora_clip_out"])
+
+
+def test_blocks(golden, tiny_sd):
+    cs = O.rope_cos_sin(torch.tensor(golden["pe_ids"]), G.axes_dim, G.theta)
+    img, txt = torch.tensor(golden["blk_img_in"]), torch.tensor(golden["blk_txt_in"])
+    vec = torch.tensor(golden["mod_vec"])
+    di, dt = O.double_block(tiny_sd, "double_blocks.0", img, txt, vec, cs, G, F32)
+    close(di, golden["double0_img"]); close(dt, golden["double0_txt"])
+    close(O.single_block(tiny_sd, "single_blocks.0", torch.cat((txt, img), 1), vec, cs, G, F32), golden["single0"])
+    close(O.last_layer(tiny_sd, img, vec, F32), golden["last"])
+
+
+def _fwd(sd, inp, t, P):
+    return O.flux_forward(sd, G, torch.cat((inp["x"], inp["cond"]), -1), inp["img_ids"], inp["txt"], inp["txt_ids"], t,
+                          inp["y"], inp["txt_mask"], inp["img_mask"], inp["guidance"], P=P)
+
+
+def test_flux_forward(golden, tiny_sd):
+    close(_fwd(tiny_sd, tiny_inputs(B=1), torch.tensor(golden["flux_b1_t"]), F32), golden["flux_b1"])
+    close(_fwd(tiny_sd, tiny_inputs(B=1), torch.tensor(golden["flux_b1_t"]), O.Prec("fp32", "merged")), golden["flux_b1"])
+    inp2 = tiny_inputs(B=2, seed=7)
+    inp2["img_mask"][1, -12:] = 0
+    close(_fwd(tiny_sd, inp2, torch.tensor(golden["flux_b2_t"]), F32), golden["flux_b2"])
+
+
+def test_errors(tiny_sd):
+    inp = tiny_inputs(B=1)
+    with pytest.raises(ValueError):
+        O.flux_forward(tiny_sd, G, inp["x"][0], inp["img_ids"], inp["txt"], inp["txt_ids"], torch.ones(1), inp["y"])
+    with pytest.raises(ValueError):
+        O.flux_forward(tiny_sd, G, torch.cat((inp["x"], inp["cond"]), -1), inp["img_ids"], inp["txt"], inp["txt_ids"],
+                       torch.ones(1), inp["y"], guidance=None)
+
+
+@pytest.mark.parametrize("n_tok", [1152, 3456, 6144, 6912])
+@pytest.mark.parametrize("steps", [4, 30, 50])
+def test_time_grids(golden, n_tok, steps):
+    t = O.time_grid(steps, n_tok, do_shift=True, time_shifting_factor=1)
+    close(t[:-1].double(), golden[f"grid_{n_tok}_{steps}_solver_t"], 1e-6)
+    close((1 - t[:-1]).double(), golden[f"grid_{n_tok}_{steps}_model_t"], 1e-6)
+    assert len(golden[f"grid_{n_tok}_{steps}_model_t"]) == steps - 1     # N points -> N-1 model evaluations
+    assert abs(float(t[0])) < 1e-7 and float(t[-1]) == 1.0   # endpoints survive the shift via inf arithmetic
+
+
+def test_time_grid_upsample(golden):
+    t = O.time_grid(10, 4096, do_shift=False, time_shifting_factor=1.0, strength=0.4)
+    close((1 - t[:-1]).double(), golden["grid_upsample_model_t"], 1e-6)
+
+
+def test_sampler_trajectory(golden, tiny_sd):
+    inp = tiny_inputs(B=1)
+    kw = dict(P=F32)
+
+    def model_fn(xin, tm):
+        return O.flux_forward(tiny_sd, G, xin, inp["img_ids"], inp["txt"], inp["txt_ids"], tm, inp["y"], inp["txt_mask"],
+                              inp["img_mask"], inp["guidance"], **kw)
+    states, evals = O.sample_euler(model_fn, inp["x"], inp["cond"], O.time_grid(5, inp["x"].shape[1], True, 1))
+    assert len(evals) == 4
+    ref = golden["traj_states"]
+    for i in range(5):
+        close(states[i], ref[i], 5e-5)
+    st2, _ = O.sample_euler(model_fn, inp["x"], inp["cond"], O.time_grid(4, inp["x"].shape[1], False, 1.0, strength=0.4))
+    close(st2[-1], golden["traj_sdedit_last"], 5e-5)
+
+
+def test_bf16_noise_floor(golden, tiny_sd):
+    """How far bf16 execution moves the result (states the tolerance the GPU tests use)."""
+    inp = tiny_inputs(B=1)
+    ref = torch.tensor(golden["flux_b1"])
+    orig = O.compute_vec
+    O.compute_vec = lambda *a, **k: orig(*a, **{**k, "guidance_is_bf16": False})
+    try:
+        yb = _fwd(tiny_sd, inp, torch.tensor([0.7]), O.Prec("bf16", "ref"))
+        ym = _fwd(tiny_sd, inp, torch.tensor([0.7]), O.Prec("bf16", "merged"))
+    finally:
+        O.compute_vec = orig
+    rel = lambda a: ((a - ref).norm() / ref.norm()).item()  # noqa: E731
+    assert 1e-3 < rel(yb) < 1.5e-2 and 1e-3 < rel(ym) < 1.5e-2
+    # with guidance in bf16 (the production dtype) the oracle tracks the reference's own bf16 run
+    yg = _fwd(tiny_sd, inp, torch.tensor([0.7]), O.Prec("bf16", "ref"))
+    rb = torch.tensor(golden["flux_b1_ref_bf16"])
+    assert ((yg - rb).norm() / rb.norm()).item() < 5e-2

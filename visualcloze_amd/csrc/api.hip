@@ -43,9 +43,9 @@ int vc_ln_modulate(const void* x, int64_t ldx, void* y, int64_t ldy, const void*
                                mod_step_stride, S(stream), ERRBUF);
 }
 int vc_qknorm_rope_vt(void* qkv, int64_t ld, int64_t bstride, const void* q_scale, const void* k_scale,
-                      const float* rope, int64_t rope_bstride, void* vt, int32_t B, int32_t L, int32_t Lpad, int32_t H,
-                      void* stream) {
-  return vc_qknorm_rope_vt_launch(qkv, ld, bstride, q_scale, k_scale, rope, rope_bstride, vt, B, L, Lpad, H, S(stream), ERRBUF);
+                      const void* q_scale2, const void* k_scale2, int32_t split, const float* rope,
+                      int64_t rope_bstride, void* vt, int32_t B, int32_t L, int32_t Lpad, int32_t H, void* stream) {
+  return vc_qknorm_rope_vt_launch(qkv, ld, bstride, q_scale, k_scale, q_scale2, k_scale2, split, rope, rope_bstride, vt, B, L, Lpad, H, S(stream), ERRBUF);
 }
 int vc_attention(const void* qkv, int64_t ld, int64_t bstride, const void* vt, void* out, int64_t ldo,
                  int64_t out_bstride, const int32_t* kv_len, int32_t B, int32_t L, int32_t Lpad, int32_t H,
@@ -57,8 +57,13 @@ int vc_timestep_embedding(const float* t, const float* freqs, void* out_bf16, in
   return vc_temb_launch(t, freqs, out_bf16, n, half, round_t_bf16, S(stream), ERRBUF);
 }
 int vc_silu(const void* x, void* y, int64_t n, void* stream) { return vc_silu_launch(x, y, n, S(stream), ERRBUF); }
-int vc_add3(const void* a, const void* b, const void* c, void* y, int64_t n, void* stream) {
-  return vc_add3_launch(a, b, c, y, n, S(stream), ERRBUF);
+int vc_add3(const void* a, const void* b, const void* c, void* y, int64_t n, int64_t bn, int64_t cn, void* stream) {
+  return vc_add3_launch(a, b, c, y, n, bn, cn, S(stream), ERRBUF);
+}
+int vc_copy(void* dst, const void* src, int64_t bytes, void* stream) {
+  if (!dst || !src || bytes <= 0) { snprintf(g_err, sizeof(g_err), "copy: bad args"); return VC_ERR_ARG; }
+  hipError_t e = hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, S(stream));
+  return e == hipSuccess ? VC_OK : hip_fail("hipMemcpyAsync", e);
 }
 int vc_concat_cols(const void* x, int32_t cx, const void* cond, int32_t cc, void* out, int64_t rows, void* stream) {
   return vc_concat_cols_launch(x, cx, cond, cc, out, rows, S(stream), ERRBUF);

@@ -23,12 +23,13 @@ __global__ void silu_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y
   if (i < n) y[i] = f2bf(silu_f(bf2f(x[i])));
 }
 
+// y[i] = bf16(bf16(a[i] + b[i % bn]) + c[i % cn]): b, c broadcast over rows (vec = time + guidance + vector)
 __global__ void add3_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, const bf16_t* __restrict__ c,
-                            bf16_t* __restrict__ y, long n) {
+                            bf16_t* __restrict__ y, long n, long bn, long cn) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  float v = rbf(bf2f(a[i]) + bf2f(b[i]));
-  if (c) v = v + bf2f(c[i]);
+  float v = rbf(bf2f(a[i]) + bf2f(b[i % bn]));
+  if (c) v = v + bf2f(c[i % cn]);
   y[i] = f2bf(v);
 }
 
@@ -73,9 +74,9 @@ int vc_silu_launch(const void* x, void* y, int64_t n, hipStream_t s, char* err, 
   hipLaunchKernelGGL(silu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, (long)n);
   VC_CHECK_LAUNCH("silu");
 }
-int vc_add3_launch(const void* a, const void* b, const void* c, void* y, int64_t n, hipStream_t s, char* err, int errlen) {
-  if (!a || !b || !y || n <= 0) { snprintf(err, errlen, "add3: bad args"); return VC_ERR_ARG; }
-  hipLaunchKernelGGL(add3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)b, (const bf16_t*)c, (bf16_t*)y, (long)n);
+int vc_add3_launch(const void* a, const void* b, const void* c, void* y, int64_t n, int64_t bn, int64_t cn, hipStream_t s, char* err, int errlen) {
+  if (!a || !b || !y || n <= 0 || bn <= 0 || (c && cn <= 0)) { snprintf(err, errlen, "add3: bad args"); return VC_ERR_ARG; }
+  hipLaunchKernelGGL(add3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)b, (const bf16_t*)c, (bf16_t*)y, (long)n, (long)bn, (long)(c ? cn : 1));
   VC_CHECK_LAUNCH("add3");
 }
 int vc_concat_cols_launch(const void* x, int cx, const void* cond, int cc, void* out, int64_t rows, hipStream_t s, char* err, int errlen) {

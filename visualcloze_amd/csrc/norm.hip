@@ -74,6 +74,8 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const bf16_t* __restri
 __global__ __launch_bounds__(256) void qknorm_rope_vt_kernel(bf16_t* __restrict__ qkv, long ld, long bstride,
                                                              const bf16_t* __restrict__ q_scale,
                                                              const bf16_t* __restrict__ k_scale,
+                                                             const bf16_t* __restrict__ q_scale2,
+                                                             const bf16_t* __restrict__ k_scale2, int split,
                                                              const float* __restrict__ rope, long rope_bstride,
                                                              bf16_t* __restrict__ vt, int L, int Lpad, int H) {
   __shared__ uint32_t tl[128 * 33];
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_vt_kernel(bf16_t* __restrict_
 #pragma unroll
     for (int o = 1; o < 16; o <<= 1) ss += __shfl_xor(ss, o, 64);
     const float rrms = 1.0f / sqrtf(ss * (1.0f / 128.0f) + 1e-6f);
-    const bf16_t* sc = (which ? k_scale : q_scale) + sub * 8;
+    const bf16_t* sc = (tok < split ? (which ? k_scale : q_scale) : (which ? k_scale2 : q_scale2)) + sub * 8;
     const u32x4 sw = *(const u32x4*)sc;
     float g[8];
 #pragma unroll
@@ -180,14 +182,16 @@ int vc_ln_modulate_launch(const void* x, int64_t ldx, void* y, int64_t ldy, cons
 }
 
 int vc_qknorm_rope_vt_launch(void* qkv, int64_t ld, int64_t bstride, const void* q_scale, const void* k_scale,
-                             const float* rope, int64_t rope_bstride, void* vt, int32_t B, int32_t L, int32_t Lpad,
+                             const void* q_scale2, const void* k_scale2, int32_t split, const float* rope, int64_t rope_bstride, void* vt, int32_t B, int32_t L, int32_t Lpad,
                              int32_t H, hipStream_t s, char* err, int errlen) {
   if (!qkv || !q_scale || !k_scale || !rope || !vt) { snprintf(err, errlen, "qknorm_rope_vt: null pointer"); return VC_ERR_ARG; }
+  if (!q_scale2 || !k_scale2) { q_scale2 = q_scale; k_scale2 = k_scale; split = L; }
   if (B <= 0 || L <= 0 || H <= 0) { snprintf(err, errlen, "qknorm_rope_vt: empty problem"); return VC_ERR_ARG; }
   if (Lpad < L || Lpad % 64 || ld % 8 || bstride % 8) { snprintf(err, errlen, "qknorm_rope_vt: Lpad=%d must be a multiple of 64 >= L=%d; ld, bstride multiples of 8", Lpad, L); return VC_ERR_ARG; }
   const dim3 grid((L + 63) / 64, H, B), block(256);
   hipLaunchKernelGGL(qknorm_rope_vt_kernel, grid, block, 0, s, (bf16_t*)qkv, (long)ld, (long)bstride,
-                     (const bf16_t*)q_scale, (const bf16_t*)k_scale, rope, (long)rope_bstride, (bf16_t*)vt, L, Lpad, H);
+                     (const bf16_t*)q_scale, (const bf16_t*)k_scale, (const bf16_t*)q_scale2, (const bf16_t*)k_scale2, split,
+                     rope, (long)rope_bstride, (bf16_t*)vt, L, Lpad, H);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { snprintf(err, errlen, "qknorm_rope_vt launch: %s", hipGetErrorString(e)); return VC_ERR_HIP; }
   return VC_OK;

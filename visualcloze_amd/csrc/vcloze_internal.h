@@ -12,11 +12,11 @@ int vc_ln_modulate_launch(const void* x, int64_t ldx, void* y, int64_t ldy, cons
                           int64_t mod_bstride, int32_t rows, int32_t D, int32_t rows_per_batch,
                           const int32_t* step_ptr, int64_t mod_step_stride, hipStream_t s, char* err, int errlen);
 int vc_qknorm_rope_vt_launch(void* qkv, int64_t ld, int64_t bstride, const void* q_scale, const void* k_scale,
-                             const float* rope, int64_t rope_bstride, void* vt, int32_t B, int32_t L, int32_t Lpad,
+                             const void* q_scale2, const void* k_scale2, int32_t split, const float* rope, int64_t rope_bstride, void* vt, int32_t B, int32_t L, int32_t Lpad,
                              int32_t H, hipStream_t s, char* err, int errlen);
 int vc_temb_launch(const float* t, const float* freqs, void* out, int n, int half, int round_t, hipStream_t s, char* err, int errlen);
 int vc_silu_launch(const void* x, void* y, int64_t n, hipStream_t s, char* err, int errlen);
-int vc_add3_launch(const void* a, const void* b, const void* c, void* y, int64_t n, hipStream_t s, char* err, int errlen);
+int vc_add3_launch(const void* a, const void* b, const void* c, void* y, int64_t n, int64_t bn, int64_t cn, hipStream_t s, char* err, int errlen);
 int vc_concat_cols_launch(const void* x, int cx, const void* cond, int cc, void* out, int64_t rows, hipStream_t s, char* err, int errlen);
 int vc_euler_launch(void* x, const void* v, const float* dts, const int32_t* step_ptr, int64_t n, hipStream_t s, char* err, int errlen);
 int vc_step_advance_launch(int32_t* step_ptr, hipStream_t s, char* err, int errlen);

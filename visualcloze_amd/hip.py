@@ -49,11 +49,12 @@ SYMBOLS = {
     "vc_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "vc_gemm": (C.c_int, [C.POINTER(GemmArgs), C.c_int, _vp]),
     "vc_ln_modulate": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp]),
-    "vc_qknorm_rope_vt": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "vc_qknorm_rope_vt": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp]),
     "vc_attention": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vc_timestep_embedding": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "vc_silu": (C.c_int, [_vp, _vp, _i64, _vp]),
-    "vc_add3": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
+    "vc_add3": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
+    "vc_copy": (C.c_int, [_vp, _vp, _i64, _vp]),
     "vc_concat_cols": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i64, _vp]),
     "vc_euler_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
     "vc_step_advance": (C.c_int, [_vp, _vp]),
@@ -185,14 +186,15 @@ def ln_modulate(x, shift, scale, out=None, step_ptr=None, mod_step_stride=0, str
     return out
 
 
-def qknorm_rope_vt(qkv, q_scale, k_scale, rope, vt, L, H, stream=None):
-    """qkv: [L, >=3*H*128] rows (q|k|v at column 0, H*128, 2*H*128); rope: [L,64,2] f32; vt: [H,128,Lpad]."""
+def qknorm_rope_vt(qkv, q_scale, k_scale, rope, vt, L, H, stream=None, q_scale2=None, k_scale2=None, split=0):
+    """qkv: [L, >=3*H*128] rows (q|k|v at column 0, H*128, 2*H*128); rope: [L,64,2] f32; vt: [H,128,Lpad].
+    rows < split use (q_scale, k_scale), the rest (q_scale2, k_scale2) when given."""
     _bf16(qkv, "qkv")
     if rope.dtype != torch.float32 or not rope.is_contiguous():
         raise VclozeHipError("rope table must be contiguous f32 [L,64,2]")
     Lpad = vt.shape[-1]
     _check(lib().vc_qknorm_rope_vt(qkv.data_ptr(), qkv.stride(0), 0, q_scale.data_ptr(), k_scale.data_ptr(),
-                                   rope.data_ptr(), 0, vt.data_ptr(), 1, L, Lpad, H,
+                                   _p(q_scale2), _p(k_scale2), split, rope.data_ptr(), 0, vt.data_ptr(), 1, L, Lpad, H,
                                    stream if stream is not None else cur_stream()), "vc_qknorm_rope_vt")
 
 
@@ -220,9 +222,16 @@ def silu(x, out=None, stream=None):
 
 def add3(a, b, c=None, out=None, stream=None):
     out = torch.empty_like(a) if out is None else out
-    _check(lib().vc_add3(a.data_ptr(), b.data_ptr(), _p(c), out.data_ptr(), a.numel(),
-                         stream if stream is not None else cur_stream()), "vc_add3")
+    _check(lib().vc_add3(a.data_ptr(), b.data_ptr(), _p(c), out.data_ptr(), a.numel(), b.numel(),
+                         c.numel() if c is not None else 1, stream if stream is not None else cur_stream()), "vc_add3")
     return out
+
+
+def copy(dst, src, stream=None):
+    if dst.numel() * dst.element_size() != src.numel() * src.element_size() or not (dst.is_contiguous() and src.is_contiguous()):
+        raise VclozeHipError("copy: size/contiguity mismatch")
+    _check(lib().vc_copy(dst.data_ptr(), src.data_ptr(), src.numel() * src.element_size(),
+                         stream if stream is not None else cur_stream()), "vc_copy")
 
 
 def concat_cols(x, cond, out, stream=None):

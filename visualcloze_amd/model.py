@@ -1,0 +1,295 @@
+"""Host-side mirror of the reference's model interface for the denoising path.
+
+`Flux`, `FluxLoraWrapper` and `FluxParams` keep the reference's constructor, `state_dict` key/shape contract
+and `forward` keyword surface (models/model.py:18-175), so `visualcloze.py` /
+`sample.py` can construct, `.to()`, `load_state_dict(strict=False)` and call `model.forward` unchanged.
+The modules below are PARAMETER HOLDERS: every FLOP of `forward` runs in libvcloze_hip.so via
+`FluxEngine`.  There is no torch fallback — without a GPU or without the library, forward raises.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+from torch import Tensor, nn
+
+from . import hip
+from .engine import FluxEngine, PreparedWeights
+
+
+@dataclass
+class FluxParams:
+    in_channels: int
+    out_channels: int
+    vec_in_dim: int
+    context_in_dim: int
+    hidden_size: int
+    mlp_ratio: float
+    num_heads: int
+    depth: int
+    depth_single_blocks: int
+    axes_dim: list
+    theta: int
+    qkv_bias: bool
+    guidance_embed: bool
+
+
+# "flux-dev-fill-lora" hyper-parameters (models/util.py:132-165)
+FLUX_DEV_FILL = dict(in_channels=384, out_channels=64, vec_in_dim=768, context_in_dim=4096, hidden_size=3072,
+                     mlp_ratio=4.0, num_heads=24, depth=19, depth_single_blocks=38, axes_dim=[16, 56, 56],
+                     theta=10_000, qkv_bias=True, guidance_embed=True)
+
+
+class _NoTorchForward(nn.Module):
+    def forward(self, *a, **k):  # pragma: no cover
+        raise hip.VclozeHipError(f"{type(self).__name__} is a parameter holder; the denoising path runs in "
+                                 "libvcloze_hip.so through Flux.forward (no torch fallback)")
+
+
+class Linear(_NoTorchForward):
+    """nn.Linear-shaped holder (`weight [out,in]`, `bias [out]`); LoRA factors are added by `add_lora`."""
+
+    def __init__(self, in_features: int, out_features: int, bias: bool = True):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.empty(out_features)) if bias else None
+        self.scale = 1.0
+        self.rank = 0
+        bound = 1 / math.sqrt(in_features)
+        with torch.no_grad():
+            self.weight.uniform_(-bound, bound)
+            if self.bias is not None:
+                self.bias.uniform_(-bound, bound)
+
+    def add_lora(self, max_rank: int, scale: float) -> None:
+        """LinearLora.__init__ (models/modules/lora.py:34-90): rank clipped to min(in,out), lora_B has a bias,
+        lora_B initialised to zero."""
+        assert isinstance(scale, float), "scale must be a float"
+        self.rank = min(max_rank, self.in_features, self.out_features)
+        self.scale = scale
+        self.lora_A = Linear(self.in_features, self.rank, bias=False)
+        self.lora_B = Linear(self.rank, self.out_features, bias=True)
+        with torch.no_grad():
+            self.lora_A.to(self.weight.device, self.weight.dtype)
+            self.lora_B.to(self.weight.device, self.weight.dtype)
+            self.lora_B.weight.zero_()
+            self.lora_B.bias.zero_()
+
+    def set_scale(self, scale: float) -> None:
+        assert isinstance(scale, float), "scalar value must be a float"
+        self.scale = scale
+
+
+class MLPEmbedder(_NoTorchForward):
+    def __init__(self, in_dim: int, hidden_dim: int):
+        super().__init__()
+        self.in_layer = Linear(in_dim, hidden_dim)
+        self.out_layer = Linear(hidden_dim, hidden_dim)
+
+
+class RMSNorm(_NoTorchForward):
+    def __init__(self, dim: int):
+        super().__init__()
+        self.scale = nn.Parameter(torch.ones(dim))
+
+
+class QKNorm(_NoTorchForward):
+    def __init__(self, dim: int):
+        super().__init__()
+        self.query_norm, self.key_norm = RMSNorm(dim), RMSNorm(dim)
+
+
+class SelfAttention(_NoTorchForward):
+    def __init__(self, dim: int, num_heads: int, qkv_bias: bool):
+        super().__init__()
+        self.qkv = Linear(dim, dim * 3, bias=qkv_bias)
+        self.norm = QKNorm(dim // num_heads)
+        self.proj = Linear(dim, dim)
+
+
+class Modulation(_NoTorchForward):
+    def __init__(self, dim: int, double: bool):
+        super().__init__()
+        self.is_double = double
+        self.multiplier = 6 if double else 3
+        self.lin = Linear(dim, self.multiplier * dim)
+
+
+class _Seq(nn.Sequential, _NoTorchForward):
+    pass
+
+
+class _Empty(_NoTorchForward):
+    """stands in for parameter-free members (nn.GELU / nn.SiLU / LayerNorm without affine) to keep indices"""
+
+
+class DoubleStreamBlock(_NoTorchForward):
+    def __init__(self, hidden_size: int, num_heads: int, mlp_ratio: float, qkv_bias: bool = False):
+        super().__init__()
+        mlp = int(hidden_size * mlp_ratio)
+        self.img_mod = Modulation(hidden_size, True)
+        self.img_attn = SelfAttention(hidden_size, num_heads, qkv_bias)
+        self.img_mlp = _Seq(Linear(hidden_size, mlp), _Empty(), Linear(mlp, hidden_size))
+        self.txt_mod = Modulation(hidden_size, True)
+        self.txt_attn = SelfAttention(hidden_size, num_heads, qkv_bias)
+        self.txt_mlp = _Seq(Linear(hidden_size, mlp), _Empty(), Linear(mlp, hidden_size))
+
+
+class SingleStreamBlock(_NoTorchForward):
+    def __init__(self, hidden_size: int, num_heads: int, mlp_ratio: float = 4.0):
+        super().__init__()
+        self.mlp_hidden_dim = int(hidden_size * mlp_ratio)
+        self.linear1 = Linear(hidden_size, hidden_size * 3 + self.mlp_hidden_dim)
+        self.linear2 = Linear(hidden_size + self.mlp_hidden_dim, hidden_size)
+        self.norm = QKNorm(hidden_size // num_heads)
+        self.modulation = Modulation(hidden_size, False)
+
+
+class LastLayer(_NoTorchForward):
+    def __init__(self, hidden_size: int, patch_size: int, out_channels: int):
+        super().__init__()
+        self.linear = Linear(hidden_size, patch_size * patch_size * out_channels)
+        self.adaLN_modulation = _Seq(_Empty(), Linear(hidden_size, 2 * hidden_size))
+
+
+class Flux(nn.Module):
+    """Drop-in for models/model.py:35-151 (inference surface)."""
+
+    def __init__(self, params: FluxParams):
+        super().__init__()
+        self.params = params
+        self.in_channels, self.out_channels = params.in_channels, params.out_channels
+        if params.hidden_size % params.num_heads != 0:
+            raise ValueError(f"Hidden size {params.hidden_size} must be divisible by num_heads {params.num_heads}")
+        pe_dim = params.hidden_size // params.num_heads
+        if sum(params.axes_dim) != pe_dim:
+            raise ValueError(f"Got {params.axes_dim} but expected positional dim {pe_dim}")
+        if pe_dim != 128:
+            raise ValueError("the gfx950 attention kernel is specialised for head_dim 128 (FLUX)")
+        self.hidden_size, self.num_heads = params.hidden_size, params.num_heads
+        self.img_in = Linear(self.in_channels, self.hidden_size)
+        self.time_in = MLPEmbedder(256, self.hidden_size)
+        self.vector_in = MLPEmbedder(params.vec_in_dim, self.hidden_size)
+        self.guidance_in = MLPEmbedder(256, self.hidden_size) if params.guidance_embed else nn.Identity()
+        self.txt_in = Linear(params.context_in_dim, self.hidden_size)
+        self.double_blocks = nn.ModuleList(
+            [DoubleStreamBlock(self.hidden_size, self.num_heads, params.mlp_ratio, params.qkv_bias)
+             for _ in range(params.depth)])
+        self.single_blocks = nn.ModuleList(
+            [SingleStreamBlock(self.hidden_size, self.num_heads, params.mlp_ratio)
+             for _ in range(params.depth_single_blocks)])
+        self.final_layer = LastLayer(self.hidden_size, 1, self.out_channels)
+        self._engine: Optional[FluxEngine] = None
+        self._fingerprint = None
+
+    # ------------------------------------------------------------------ weights -> engine
+    def _linears(self):
+        for name, m in self.named_modules():
+            if isinstance(m, Linear) and ".lora_" not in name:
+                yield name, m
+
+    def _weights_fingerprint(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters()) + tuple(
+            m.scale for _, m in self._linears())
+
+    @torch.no_grad()
+    def prepare(self) -> FluxEngine:
+        """(Re)build the engine's device weights: bf16, contiguous, LoRA merged as W + s*B@A, b + s*b_B
+        (exact in f32, rounded to bf16 once — DESIGN.md §numerics).  One-time preprocessing; uses torch ops."""
+        hip.require_gpu()
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise hip.VclozeHipError("Flux weights must live on the GPU (model.to('cuda')) — there is no CPU path")
+        w, b = {}, {}
+        for name, m in self._linears():
+            W32 = m.weight.detach().float()
+            B32 = None if m.bias is None else m.bias.detach().float()
+            if m.rank:
+                W32 = W32 + m.scale * (m.lora_B.weight.detach().float() @ m.lora_A.weight.detach().float())
+                if m.lora_B.bias is not None:
+                    B32 = (B32 if B32 is not None else 0) + m.scale * m.lora_B.bias.detach().float()
+            w[name] = W32.to(torch.bfloat16).contiguous()
+            b[name] = None if B32 is None else B32.to(torch.bfloat16).contiguous()
+        for name, p in self.named_parameters():
+            if name.endswith("norm.scale"):
+                w[name] = p.detach().to(torch.bfloat16).contiguous()
+        D = self.hidden_size
+        for i in range(self.params.depth_single_blocks):
+            n = f"single_blocks.{i}.linear1"
+            w[n + ".qkv"], w[n + ".mlp"] = w[n][: 3 * D], w[n][3 * D:]
+            b[n + ".qkv"], b[n + ".mlp"] = b[n][: 3 * D], b[n][3 * D:]
+        # all modulation projections stacked: one GEMM yields every shift/scale/gate of a step
+        mods: List[str] = []
+        for i in range(self.params.depth):
+            mods += [f"double_blocks.{i}.img_mod.lin", f"double_blocks.{i}.txt_mod.lin"]
+        mods += [f"single_blocks.{i}.modulation.lin" for i in range(self.params.depth_single_blocks)]
+        mods.append("final_layer.adaLN_modulation.1")
+        off, o = {}, 0
+        for n in mods:
+            off[n] = o
+            o += w[n].shape[0]
+        mod_w = torch.cat([w.pop(n) for n in mods], dim=0).contiguous()
+        mod_b = torch.cat([b.pop(n) for n in mods], dim=0).contiguous()
+        half = 128
+        freqs = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half).to(dev)
+        pw = PreparedWeights(w=w, b=b, mod_w=mod_w, mod_b=mod_b, mod_off=off, n_mod=o, temb_freqs=freqs)
+        self._engine = FluxEngine(self.params, pw, dev)
+        self._fingerprint = self._weights_fingerprint()
+        return self._engine
+
+    def engine(self) -> FluxEngine:
+        if self._engine is None or self._fingerprint != self._weights_fingerprint():
+            self.prepare()
+        return self._engine
+
+    # ------------------------------------------------------------------ the B1 boundary
+    @staticmethod
+    def _kv_len(txt_mask, img_mask, b, T, N) -> int:
+        if txt_mask is None or img_mask is None:
+            return T + N
+        joint = torch.cat((txt_mask[b], img_mask[b]), 0).to("cpu")
+        n = int(joint.sum())
+        if not bool(joint[:n].all()):
+            raise hip.VclozeHipError("only prefix (right-padded) masks are supported — all models/sampling.py emits")
+        return n
+
+    @torch.no_grad()
+    def forward(self, img: Tensor, img_ids: Tensor, txt: Tensor, txt_ids: Tensor, timesteps: Tensor, y: Tensor,
+                txt_mask: Tensor = None, img_mask: Tensor = None, guidance: Optional[Tensor] = None) -> Tensor:
+        if img.ndim != 3 or txt.ndim != 3:
+            raise ValueError("Input img and txt tensors must have 3 dimensions.")
+        if self.params.guidance_embed and guidance is None:
+            raise ValueError("Didn't get guidance strength for guidance distilled model.")
+        eng = self.engine()
+        B, N, _ = img.shape
+        T = txt.shape[1]
+        dev = eng.dev
+        out = torch.empty(B, N, self.out_channels, dtype=torch.bfloat16, device=dev)
+        bf = lambda t: t.to(dev, torch.bfloat16).contiguous()  # noqa: E731
+        for b in range(B):
+            ws = eng.workspace(T, N, 1)
+            g_b = None if guidance is None else guidance[b:b + 1]
+            eng.prepare_sample(ws, bf(txt[b]), bf(y[b]), g_b, guidance is not None and guidance.dtype == torch.bfloat16,
+                               img_ids[b], txt_ids[b], timesteps[b:b + 1].float(),
+                               self._kv_len(txt_mask, img_mask, b, T, N))
+            ws.XIN.copy_(bf(img[b]))
+            eng.eval_once(ws, None, euler=False, concat=False)
+            out[b].copy_(ws.V)
+        return out.to(img.dtype) if img.dtype.is_floating_point else out
+
+
+class FluxLoraWrapper(Flux):
+    """models/model.py:154-175: Flux with a LoRA pair on EVERY Linear (`replace_linear_with_lora`)."""
+
+    def __init__(self, lora_rank: int = 128, lora_scale: float = 1.0, *args, **kwargs) -> None:
+        super().__init__(*args, **kwargs)
+        self.lora_rank = lora_rank
+        for _, m in list(self._linears()):
+            m.add_lora(lora_rank, lora_scale)
+
+    def set_lora_scale(self, scale: float) -> None:
+        for _, m in self._linears():
+            m.set_scale(scale=scale)

@@ -1,0 +1,155 @@
+"""Host-side mirror of the reference's sampler interface (transport/__init__.py:4-62,
+transport/transport.py:236-410, transport/integrators.py:79-120, transport/utils.py:33-44):
+
+    sampler = Sampler(create_transport("Linear", "velocity", do_shift=True))
+    sample_fn = sampler.sample_ode(sampling_method="euler", num_steps=30, ...)
+    latents = sample_fn(x, model.forward, model_kwargs)[-1]
+
+Only the configuration the inference pipeline uses is implemented (Linear path, velocity prediction,
+fixed-grid Euler); anything else raises NotImplementedError.  When `model` is the bound `forward` of a
+`visualcloze_amd.Flux`, the whole loop runs as hipGraph replays of one captured evaluation + Euler update
+with zero host synchronisation inside the loop; a foreign callable is stepped eagerly with the same grid.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Optional
+
+import torch
+
+from . import hip
+
+
+def time_shift(mu: float, sigma: float, t: torch.Tensor) -> torch.Tensor:
+    """transport/utils.py:33-39 (endpoints 0 -> 0 and 1 -> 1 through inf arithmetic, as the reference)."""
+    t = 1 - t
+    t = math.exp(mu) / (math.exp(mu) + (1 / t - 1) ** sigma)
+    return 1 - t
+
+
+def get_lin_function(x1: float = 256, y1: float = 0.5, x2: float = 4096, y2: float = 1.15) -> Callable:
+    m = (y2 - y1) / (x2 - x1)
+    b = y1 - m * x1
+    return lambda x: m * x + b
+
+
+def solver_time_grid(num_steps: int, n_tokens: int, t0: float, t1: float, do_shift: bool,
+                     time_shifting_factor: Optional[float]) -> torch.Tensor:
+    """ode.__init__ + ode.sample (integrators.py:99-101,113-116): the solver's time POINTS (f32, CPU)."""
+    assert t0 < t1, "ODE sampler has to be in forward time"
+    t = torch.linspace(t0, t1, num_steps)
+    if time_shifting_factor:
+        t = t / (t + time_shifting_factor - time_shifting_factor * t)
+    if do_shift:
+        mu = get_lin_function(y1=0.5, y2=1.15)(n_tokens)
+        t = time_shift(mu, 1.0, t)
+    return t
+
+
+class Transport:
+    def __init__(self, path_type: str, prediction: str, do_shift: bool):
+        self.path_type, self.prediction, self.do_shift = path_type, prediction, do_shift
+        self.train_eps = self.sample_eps = 0  # velocity & Linear is stable everywhere (transport/__init__.py:46-48)
+
+    def check_interval(self, reverse: bool = False):
+        t0, t1 = 0, 1  # transport.py:70-96 for Linear + velocity, sde=False
+        if reverse:
+            t0, t1 = 1 - t0, 1 - t1
+        return t0, t1
+
+
+def create_transport(path_type="Linear", prediction="velocity", loss_weight=None, train_eps=None, sample_eps=None,
+                     snr_type="uniform", loss_type="mse", do_shift=True) -> Transport:
+    if path_type != "Linear" or prediction != "velocity":
+        raise NotImplementedError("the MI355X denoising path implements Linear path + velocity prediction only")
+    return Transport(path_type, prediction, do_shift)
+
+
+class Sampler:
+    def __init__(self, transport: Transport):
+        self.transport = transport
+
+    def sample_ode(self, *, sampling_method="dopri5", num_steps=50, atol=1e-6, rtol=1e-3, reverse=False,
+                   do_shift=True, time_shifting_factor=None, strength=None, return_trajectory: bool = False):
+        if sampling_method != "euler":
+            raise NotImplementedError("only the fixed-grid 'euler' solver (the inference default) is implemented")
+        t0, t1 = self.transport.check_interval(reverse=reverse)
+        if strength is not None:
+            t0 = (t1 - t0) * strength + t0
+        assert t0 < t1, "ODE sampler has to be in forward time"
+
+        def _sample(x: torch.Tensor, model: Callable, model_kwargs: dict) -> torch.Tensor:
+            t = solver_time_grid(num_steps, x.shape[1], t0, t1, do_shift, time_shifting_factor)
+            from .model import Flux
+            owner = getattr(model, "__self__", None)
+            if isinstance(owner, Flux) and getattr(model, "__name__", "") == "forward":
+                return _sample_fused(owner, x, dict(model_kwargs), t, return_trajectory)
+            return _sample_foreign(model, x, dict(model_kwargs), t, return_trajectory)
+
+        return _sample
+
+
+def _sample_foreign(model, x, kw, t, return_trajectory):
+    """Any other callable: the same grid and update rule, one host-driven call per interval."""
+    cond = kw.pop("cond", None)
+    states = [x]
+    for i in range(len(t) - 1):
+        tt = torch.ones(x.size(0), device=x.device) * t[i].to(x.device)
+        xin = torch.cat((x, cond), dim=-1) if cond is not None else x
+        v = model(xin, timesteps=torch.ones_like(tt) * (1 - tt), **kw)
+        assert v.shape == x.shape, "Output shape from ODE solver must match input shape"
+        x = x + (t[i + 1] - t[i]).to(x.device) * (-v)
+        if return_trajectory:
+            states.append(x)
+    return torch.stack(states) if return_trajectory else x[None]
+
+
+@torch.no_grad()
+def _sample_fused(flux, x, kw, t, return_trajectory):
+    eng = flux.engine()
+    dev = eng.dev
+    B, N, C = x.shape
+    cond = kw.get("cond")
+    if cond is None:
+        raise hip.VclozeHipError("fused sampler expects model_kwargs['cond'] (x || cond feeds img_in)")
+    if C + cond.shape[-1] != flux.in_channels:
+        raise hip.VclozeHipError(f"x ({C}) || cond ({cond.shape[-1]}) does not match in_channels {flux.in_channels}")
+    txt, y, guidance = kw["txt"], kw["y"], kw.get("guidance")
+    if flux.params.guidance_embed and guidance is None:
+        raise ValueError("Didn't get guidance strength for guidance distilled model.")
+    T = txt.shape[1]
+    S = len(t) - 1
+    t32 = t.to(torch.float32)
+    eval_t = torch.ones(S) * (1 - t32[:-1])        # Flux sees 1 - t (transport.py:384)
+    dts = (t32[1:] - t32[:-1]).contiguous()        # torchdiffeq fixed grid: dt = t1 - t0
+    bf = lambda a: a.to(dev, torch.bfloat16).contiguous()  # noqa: E731
+    out = torch.empty(B, N, C, dtype=torch.bfloat16, device=dev)
+    traj = []
+    st = eng.stream
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        s = st.cuda_stream
+        for b in range(B):
+            ws = eng.workspace(T, N, S)
+            kv_len = flux._kv_len(kw.get("txt_mask"), kw.get("img_mask"), b, T, N)
+            eng.prepare_sample(ws, bf(txt[b]), bf(y[b]), None if guidance is None else guidance[b:b + 1],
+                               guidance is not None and guidance.dtype == torch.bfloat16, kw["img_ids"][b],
+                               kw["txt_ids"][b], eval_t, kv_len, s=s)
+            ws.DTS.copy_(dts, non_blocking=True)
+            ws.STEP.zero_()
+            ws.XS.copy_(bf(x[b]))
+            ws.COND.copy_(bf(cond[b]))
+            graph = eng.step_graph(ws, s)
+            states = []
+            for _ in range(S):
+                graph.launch(s)          # one Flux evaluation + Euler update + step counter increment
+                if return_trajectory:
+                    states.append(ws.XS.clone())
+            if return_trajectory:
+                traj.append(torch.stack(states))
+            out[b].copy_(ws.XS)
+    torch.cuda.current_stream().wait_stream(st)
+    if return_trajectory:
+        full = torch.cat((x.to(dev, torch.bfloat16)[None], torch.stack(traj, dim=1)), dim=0)
+        return full.to(x.dtype)
+    return out[None].to(x.dtype)

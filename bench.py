@@ -1,0 +1,334 @@
+#!/usr/bin/env python
+"""bench.py — denoising-steps/s of the MI355X-native VisualCloze sampling loop (BASELINE.json metric).
+
+A "step" is one solver step of the hot path for one grid: a full Flux evaluation (19 double + 38 single
+blocks, L = 512 text + 3456 image tokens for the 384-grid 2x3 layout = BASELINE configs[1]) plus the Euler
+update, replayed as one hipGraph.  Every rank (one process per GPU) runs its own independent grid: weak
+scaling, no collective inside the step; the frozen weights are broadcast once over RCCL before timing.
+Per-sample precomputation (txt_in, vec path, all 29x1.06M modulation rows, RoPE table) is INSIDE the timed
+region whenever a new sample starts, inputs already resident in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel = the bf16
+MFMA GEMM with the gate/residual epilogue, timed live with HIP events on its launch stream) and
+`cpu_baseline` (the CPU oracle — a "port" — timed on a bounded sample on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+WORKLOADS = {
+    # name: (resolution, rows, cols) -> per-row latent (h, w) = (res/8, cols*res/8)
+    "384-grid-2x3": dict(rows=2, row_latent=(48, 144), steps=30),
+    "512-grid-2x3": dict(rows=2, row_latent=(64, 192), steps=30),
+    "384-grid-1x2": dict(rows=1, row_latent=(48, 96), steps=4),
+    "384-grid-3x4": dict(rows=3, row_latent=(48, 192), steps=50),
+}
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense, MI355X_MICROARCH.md
+
+
+def grid_img_ids(rows, h, w):
+    """models/sampling.py:56-59: axis0 = row index + 1, axis1 = y, axis2 = x (per concatenated row)."""
+    out = []
+    for j in range(rows):
+        ids = torch.zeros(h // 2, w // 2, 3)
+        ids[..., 0] = j + 1
+        ids[..., 1] = torch.arange(h // 2)[:, None]
+        ids[..., 2] = torch.arange(w // 2)[None, :]
+        out.append(ids.reshape(-1, 3))
+    return torch.cat(out, 0)
+
+
+def build_model(dev, rank, world, lora_rank=256):
+    from visualcloze_amd.model import FLUX_DEV_FILL, FluxLoraWrapper, FluxParams
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        with torch.device(dev):
+            model = FluxLoraWrapper(lora_rank=lora_rank, lora_scale=1.0, params=FluxParams(**FLUX_DEV_FILL))
+    finally:
+        torch.set_default_dtype(old)
+    model.eval()
+    g = torch.Generator(device=dev).manual_seed(1234)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if rank != 0:
+                continue                      # filled by the broadcast below
+            if name.endswith("norm.scale"):
+                p.fill_(1.0)
+            elif name.endswith(".bias"):
+                p.zero_()
+            else:                             # matrices incl. LoRA A/B: N(0, 0.02) so the LoRA path is live
+                p.normal_(0.0, 0.02, generator=g)
+    bcast_s = 0.0
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for p in model.parameters():          # one-time RCCL broadcast of the frozen weights over xGMI
+            dist.broadcast(p.data, src=0)
+        torch.cuda.synchronize()
+        bcast_s = time.time() - t0
+    return model, bcast_s
+
+
+def make_inputs(dev, wl, seed):
+    h, w = wl["row_latent"]
+    ids = grid_img_ids(wl["rows"], h, w)
+    N = ids.shape[0]
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.randn(1, N, 64, generator=g)
+    cond = torch.randn(1, N, 320, generator=g)
+    mask = torch.zeros(N)
+    per_row = N // wl["rows"]
+    mask[(wl["rows"] - 1) * per_row + per_row * 2 // 3:] = 1          # last cell(s) of the last row masked
+    cond[..., 64:] = mask[None, :, None]
+    kw = dict(txt=torch.randn(1, 512, 4096, generator=g).to(dev, torch.bfloat16), txt_ids=torch.zeros(1, 512, 3, device=dev),
+              txt_mask=torch.ones(1, 512, dtype=torch.int32, device=dev),
+              y=torch.randn(1, 768, generator=g).to(dev, torch.bfloat16), img_ids=ids[None].to(dev),
+              img_mask=torch.ones(1, N, dtype=torch.int32, device=dev), cond=cond.to(dev, torch.bfloat16),
+              guidance=torch.full((1,), 30.0, device=dev, dtype=torch.bfloat16))
+    return x.to(dev, torch.bfloat16), kw
+
+
+class Job:
+    """Drives the engine exactly as transport._sample_fused does, but one solver step per call."""
+
+    def __init__(self, model, x, kw, num_points):
+        from visualcloze_amd.transport import solver_time_grid
+        self.model, self.eng = model, model.engine()
+        self.x, self.kw = x, kw
+        N, T = x.shape[1], kw["txt"].shape[1]
+        t = solver_time_grid(num_points, N, 0, 1, True, 1)
+        self.S = num_points - 1
+        self.eval_t = torch.ones(self.S) * (1 - t[:-1])
+        self.dts = (t[1:] - t[:-1]).contiguous()
+        self.ws = self.eng.workspace(T, N, self.S)
+        self.s = self.eng.stream.cuda_stream
+        self.step_in_sample = self.S   # forces a prepare on the first step
+
+    def begin_sample(self):
+        eng, ws, kw = self.eng, self.ws, self.kw
+        eng.prepare_sample(ws, kw["txt"][0], kw["y"][0], kw["guidance"], True, kw["img_ids"][0], kw["txt_ids"][0],
+                           self.eval_t, ws.L, s=self.s)
+        ws.DTS.copy_(self.dts, non_blocking=True)
+        ws.STEP.zero_()
+        ws.XS.copy_(self.x[0])
+        ws.COND.copy_(kw["cond"][0])
+        self.graph = eng.step_graph(ws, self.s)
+        self.step_in_sample = 0
+
+    def step(self):
+        if self.step_in_sample >= self.S:
+            self.begin_sample()
+        self.graph.launch(self.s)
+        self.step_in_sample += 1
+
+
+def flops_per_eval(T, N, D=3072, H=24, mlp=12288, depth=19, single=38, in_ch=384, out_ch=64):
+    L = T + N
+    lin = 2 * L * (depth * 12 * D * D + single * 12 * D * D) + 2 * N * in_ch * D + 2 * N * D * out_ch
+    attn = (depth + single) * 4 * L * L * D
+    return lin, attn
+
+
+def roofline_gemm(job, iters=3):
+    """Time the dominant kernel — gemm_bf16_kernel<.., EPI_GATE_RES> (attn.proj, mlp.2, linear2: 76 launches and
+    21.2 TFLOP per evaluation at cfg 2) — launch by launch on the engine stream with HIP events."""
+    from visualcloze_amd import hip
+    eng, ws = job.eng, job.ws
+    D, T, N, L = eng.D, ws.T, ws.N, ws.L
+    X, CAT = ws.X, ws.CAT
+    Xt, Xi, ATT, HID = X[:T], X[T:], CAT[:, :D], CAT[:, D:]
+    mss = eng.W.n_mod
+    launches, flops = [], 0.0
+    for i in range(eng.g.depth):
+        pf = f"double_blocks.{i}"
+        im, tm = pf + ".img_mod.lin", pf + ".txt_mod.lin"
+        launches.append(((pf + ".img_attn.proj", pf + ".txt_attn.proj"), (ATT[T:], ATT[:T]), (Xi, Xt),
+                         (eng._mod(ws, im, 2), eng._mod(ws, tm, 2))))
+        launches.append(((pf + ".img_mlp.2", pf + ".txt_mlp.2"), (HID[T:], HID[:T]), (Xi, Xt),
+                         (eng._mod(ws, im, 5), eng._mod(ws, tm, 5))))
+        flops += 2.0 * L * D * D + 2.0 * L * D * eng.mlp
+    for i in range(eng.g.depth_single_blocks):
+        pf = f"single_blocks.{i}"
+        launches.append(((pf + ".linear2",), (CAT,), (X,), (eng._mod(ws, pf + ".modulation.lin", 2),)))
+        flops += 2.0 * L * D * (D + eng.mlp)
+    s = job.s
+
+    def run():
+        for names, As, outs, gates in launches:
+            if len(names) == 2:
+                eng._lin2(names, As, outs, epi=hip.EPI_GATE_RES, ress=outs, gates=gates, step_ptr=ws.STEP,
+                          gate_step_stride=mss, s=s)
+            else:
+                eng._lin(names[0], As[0], outs[0], epi=hip.EPI_GATE_RES, res=outs[0], gate=gates[0], step_ptr=ws.STEP,
+                         gate_step_stride=mss, s=s)
+    ws.STEP.zero_()
+    with torch.cuda.stream(job.eng.stream):
+        run()
+        e0, e1 = hip.Event(), hip.Event()
+        e0.record(s)
+        for _ in range(iters):
+            run()
+        e1.record(s)
+        ms = e0.elapsed_ms(e1) / iters
+    n = len(launches)
+    achieved = flops / (ms * 1e-3) / 1e12
+    return dict(bound="mfma", achieved=round(achieved, 1), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
+                frac=round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), traffic=None,
+                kernel="gemm_bf16_kernel<EPI_GATE_RES>", launches_per_eval=n,
+                flops_per_launch=flops / n, avg_launch_us=round(ms * 1e3 / n, 2))
+
+
+def roofline_attention(job, iters=3):
+    from visualcloze_amd import hip
+    eng, ws = job.eng, job.ws
+    s = job.s
+    with torch.cuda.stream(eng.stream):
+        hip.attention(ws.QKV, ws.VT, ws.CAT[:, :eng.D], ws.L, eng.H, variant=eng.attn_variant, stream=s)
+        e0, e1 = hip.Event(), hip.Event()
+        e0.record(s)
+        for _ in range(iters * 10):
+            hip.attention(ws.QKV, ws.VT, ws.CAT[:, :eng.D], ws.L, eng.H, variant=eng.attn_variant, stream=s)
+        e1.record(s)
+        ms = e0.elapsed_ms(e1) / (iters * 10)
+    fl = 4.0 * ws.L * ws.L * eng.D
+    return dict(kernel="attn_fwd_kernel", avg_launch_us=round(ms * 1e3, 2), achieved=round(fl / ms / 1e9, 1),
+                unit="TFLOP/s", frac=round(fl / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4))
+
+
+def cpu_baseline(T, N, wl):
+    """The CPU oracle (a port of the reference path) on the host cores: one DoubleStreamBlock + one
+    SingleStreamBlock at full width, fp32, extrapolated x(19, 38) to one evaluation."""
+    import oracle.flux_oracle as O
+    G = O.FluxGeometry()
+    D, L = G.hidden_size, T + N
+    cores = torch.get_num_threads()
+    g = torch.Generator().manual_seed(0)
+    r = lambda *s: torch.randn(*s, generator=g) * 0.02  # noqa: E731
+    sd = {}
+    for st in ("img", "txt"):
+        sd.update({f"d.{st}_mod.lin.weight": r(6 * D, D), f"d.{st}_mod.lin.bias": torch.zeros(6 * D),
+                   f"d.{st}_attn.qkv.weight": r(3 * D, D), f"d.{st}_attn.qkv.bias": torch.zeros(3 * D),
+                   f"d.{st}_attn.norm.query_norm.scale": torch.ones(128), f"d.{st}_attn.norm.key_norm.scale": torch.ones(128),
+                   f"d.{st}_attn.proj.weight": r(D, D), f"d.{st}_attn.proj.bias": torch.zeros(D),
+                   f"d.{st}_mlp.0.weight": r(4 * D, D), f"d.{st}_mlp.0.bias": torch.zeros(4 * D),
+                   f"d.{st}_mlp.2.weight": r(D, 4 * D), f"d.{st}_mlp.2.bias": torch.zeros(D)})
+    sd.update({"s.modulation.lin.weight": r(3 * D, D), "s.modulation.lin.bias": torch.zeros(3 * D),
+               "s.linear1.weight": r(7 * D, D), "s.linear1.bias": torch.zeros(7 * D),
+               "s.linear2.weight": r(D, 5 * D), "s.linear2.bias": torch.zeros(D),
+               "s.norm.query_norm.scale": torch.ones(128), "s.norm.key_norm.scale": torch.ones(128)})
+    img, txt, vec = torch.randn(1, N, D, generator=g), torch.randn(1, T, D, generator=g), torch.randn(1, D, generator=g)
+    ids = torch.cat((torch.zeros(T, 3), grid_img_ids(wl['rows'], *wl['row_latent'])))[None]
+    cs = O.rope_cos_sin(ids, G.axes_dim, G.theta)
+    P = O.Prec("fp32")
+    with torch.no_grad():
+        t0 = time.time(); O.double_block(sd, "d", img, txt, vec, cs, G, P); td = time.time() - t0
+        t0 = time.time(); O.double_block(sd, "d", img, txt, vec, cs, G, P); td = min(td, time.time() - t0)
+        x = torch.cat((txt, img), 1)
+        t0 = time.time(); O.single_block(sd, "s", x, vec, cs, G, P); ts = time.time() - t0
+        t0 = time.time(); O.single_block(sd, "s", x, vec, cs, G, P); ts = min(ts, time.time() - t0)
+    per_eval = G.depth * td + G.depth_single_blocks * ts
+    return dict(value=round(1.0 / per_eval, 5), unit="denoising-steps/sec", cores=cores, kind="port",
+                sample=f"oracle fp32: 1 DoubleStreamBlock ({td:.2f}s) + 1 SingleStreamBlock ({ts:.2f}s) at L={L}, D={D}, "
+                       f"extrapolated x(19,38) to one evaluation; best of 2")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=29)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="384-grid-2x3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tile-cfg", type=int, default=None)
+    ap.add_argument("--attn-variant", type=int, default=None)
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    from visualcloze_amd import hip
+    hip.require_gpu()                       # fails loudly: there is no CPU path to fall back to
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+    wl = WORKLOADS[a.workload]
+    model, bcast_s = build_model(dev, rank, world)
+    eng = model.engine()
+    if a.tile_cfg is not None:
+        eng.tile_cfg = a.tile_cfg
+    if a.attn_variant is not None:
+        eng.attn_variant = a.attn_variant
+    x, kw = make_inputs(dev, wl, seed=rank)            # per-rank seed: independent grids
+    job = Job(model, x, kw, wl["steps"])
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    with torch.cuda.stream(eng.stream):
+        for _ in range(a.warmup):
+            job.step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            job.step()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(te, op=torch.distributed.ReduceOp.MAX)
+        elapsed = te.item()
+        torch.distributed.barrier()
+    final = job.ws.XS.float()
+    assert torch.isfinite(final).all(), "non-finite latent"
+
+    T, N = 512, x.shape[1]
+    lin, attn = flops_per_eval(T, N)
+    value = world * a.steps / elapsed
+    rec = {
+        "metric": "denoising-steps/sec", "value": round(value, 4), "unit": "denoising-steps/sec", "n_gpus": world,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"{a.workload} in-context, {wl['steps']} solver points = {wl['steps'] - 1} Flux evaluations "
+                               f"per grid, L={T}+{N} tokens, FLUX.1-Fill-dev geometry + LoRA r256 (merged), random-init "
+                               "weights, 1 independent grid per GPU (data-parallel, no in-step collective)",
+                   "global_batch": world, "seq_len": T + N, "parallelism": f"dp{world}"},
+        "img_per_sec": round(value / (wl["steps"] - 1), 5),
+        "model_tflops_per_eval": round((lin + attn) / 1e12, 2),
+        "achieved_model_tflops_per_gpu": round((lin + attn) / 1e12 * value / world, 1),
+        "weight_broadcast_s": round(bcast_s, 3),
+    }
+    if rank == 0:
+        rec["roofline"] = roofline_gemm(job)
+        rec["attention_kernel"] = roofline_attention(job)
+        if world == 1 and not a.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(T, N, wl)
+            rec["gpu_over_cpu"] = round(value / rec["cpu_baseline"]["value"], 1)
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

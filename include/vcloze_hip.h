@@ -36,12 +36,12 @@ int vc_device_info(int dev, char* name, int namelen, int* cu_count, int64_t* hbm
 
 typedef struct VcGemmProblem {
   const void* A;    /* [M,K] bf16, row stride lda (elements) */
-  const void* W;    /* [N,K] bf16 contiguous (nn.Linear.weight layout) */
+  const void* W;    /* [N,K] bf16, row stride ldw (nn.Linear.weight layout; rows may be padded) */
   const void* bias; /* [N] bf16 or NULL */
   void* C;          /* [M,N] bf16, row stride ldc */
   const void* res;  /* GATE_RES: residual [M,N] bf16 (may alias C), row stride ldres */
   const void* gate; /* GATE_RES: gate vector(s) bf16; row b of batch uses gate + b*gate_bstride */
-  int64_t lda, ldc, ldres, gate_bstride;
+  int64_t lda, ldw, ldc, ldres, gate_bstride;
   int32_t M, N, K;
   int32_t rows_per_batch; /* GATE_RES: batch index of row m is m / rows_per_batch */
   int32_t tiles_m, tiles_n, tile_start; /* filled by the launcher */
@@ -54,6 +54,7 @@ typedef struct VcGemmArgs {
   int32_t epi;
   const int32_t* step_ptr;  /* optional device step counter: gate += *step_ptr * gate_step_stride */
   int64_t gate_step_stride;
+  uint64_t* debug_ts;       /* NULL in production; profiling: per-segment s_memtime stamps of block 0 (tools/) */
 } VcGemmArgs;
 
 /* Replaces torch.nn.functional.linear (+ fused neighbours) on the hot path.

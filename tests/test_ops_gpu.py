@@ -31,9 +31,9 @@ def hip():
     return h
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 19, 20, 35, 36, 51, 52, 67, 68])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
-@pytest.mark.parametrize("shape", [(128, 128, 64), (200, 192, 128), (37, 64, 256), (513, 260, 384), (1, 512, 256)])
+@pytest.mark.parametrize("shape", [(128, 128, 64), (200, 192, 128), (37, 64, 256), (513, 264, 384), (1, 512, 256)])
 def test_gemm(hip, cfg, epi, shape):
     M, N, K = shape
     a_full = rnd(M, K + 64, seed=1)
@@ -57,7 +57,7 @@ def test_gemm_transpose_detecting(hip):
     assert torch.equal(out.float(), w.float().t())
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
 def test_gemm_grouped_and_inplace_residual(hip, cfg):
     M1, M2, N, K = 300, 136, 384, 256
     a1, a2 = rnd(M1, K, seed=1), rnd(M2, K, seed=2)

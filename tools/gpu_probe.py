@@ -67,10 +67,12 @@ def guard(fn):
 
 
 @guard
-def probe_gemm(M, N, K, epi, cfg, lda_pad=0, time_it=False):
+def probe_gemm(M, N, K, epi, cfg, lda_pad=0, time_it=False, ldw_pad=0):
     a_full = rnd(M, K + lda_pad, seed=1)
     a = a_full[:, :K]
-    w = rnd(N, K, scale=K ** -0.5, seed=2)
+    if lda_pad < 0:
+        a = rnd(1, K, seed=1).expand(M, K)      # stride-0 rows: the A operand stays cache-hot (traffic experiment)
+    w = rnd(N, K + ldw_pad, scale=K ** -0.5, seed=2)[:, :K]
     bias = rnd(N, seed=3)
     res = rnd(M, N, seed=4)
     gate = rnd(N, seed=5)
@@ -83,7 +85,7 @@ def probe_gemm(M, N, K, epi, cfg, lda_pad=0, time_it=False):
     if time_it:
         ms = timeit(lambda: hip.gemm(p, epi=epi, tile_cfg=cfg))
         extra = dict(ms=ms, tflops=2.0 * M * N * K / ms / 1e9)
-    report(f"gemm M{M} N{N} K{K} epi{epi} cfg{cfg} pad{lda_pad}", out, ref, extra=extra)
+    report(f"gemm M{M} N{N} K{K} epi{epi} cfg{cfg} pad{lda_pad}/{ldw_pad}", out, ref, extra=extra)
 
 
 @guard
@@ -207,13 +209,15 @@ def probe_graph():
 def main():
     print("device:", torch.cuda.get_device_name(0), "lib:", hip.LIB_PATH)
     hip.require_gpu()
-    for cfg in (1, 2, 3):
+    for cfg in (1, 2, 3, 4, 19, 20, 35, 36, 51, 52, 67, 68):
         for epi in (0, 1, 2, 3):
             probe_gemm(128, 128, 64, epi, cfg)
         probe_gemm(200, 192, 128, 0, cfg)
         probe_gemm(37, 64, 256, 2, cfg, lda_pad=64)
-        probe_gemm(513, 260, 384, 1, cfg)
+        probe_gemm(513, 264, 384, 1, cfg)
         probe_gemm_grouped(cfg)
+    if "--gemm-only" in sys.argv:
+        return perf()
     probe_ln(10, 256); probe_ln(1000, 3072); probe_ln(7, 4096)
     probe_elementwise()
     for var in (0, 1):
@@ -223,13 +227,18 @@ def main():
         probe_qknorm_attn(333, 2, kv_len=301, variant=var)
         probe_qknorm_attn(1664, 4, variant=var)
     probe_graph()
+    perf()
+
+
+def perf():
     if "--perf" in sys.argv:
-        for cfg in (1, 2, 3):
-            probe_gemm(3968, 9216, 3072, 0, cfg, time_it=True)
+        for cfg in (0, 20, 19):
+            for pa, pw in ((0, 0),):
+                probe_gemm(3968, 9216, 3072, 0, cfg, time_it=True, lda_pad=pa, ldw_pad=pw)
             probe_gemm(3968, 3072, 3072, 2, cfg, time_it=True)
             probe_gemm(3968, 12288, 3072, 1, cfg, time_it=True)
             probe_gemm(3968, 3072, 15360, 2, cfg, time_it=True)
-        for var in (0, 1):
+        for var in (() if "--gemm-only" in sys.argv else (0, 1)):
             probe_qknorm_attn(3968, 24, variant=var, time_it=True)
             probe_qknorm_attn(3968, 24, extra_cols=12288, variant=var, time_it=True)
     nfail = sum(1 for r in RESULTS if not r.get("ok"))

@@ -28,16 +28,19 @@ VC_DEV float wave_sum(float v) {
   return v;
 }
 
-// GELU(tanh) exactly as torch.nn.GELU(approximate="tanh") evaluates it in f32.
+// GELU(tanh) as torch.nn.GELU(approximate="tanh") defines it, 0.5*x*(1+tanh(u)) with u = sqrt(2/pi)*(x+0.044715x^3),
+// evaluated in the algebraically identical form x * sigmoid(2u) = x / (1 + 2^(-2u*log2 e)): one v_exp_f32 + one
+// v_rcp_f32 (1 ulp) instead of an IEEE divide; the result is rounded to bf16 (8 bits) right after.
 VC_DEV float gelu_tanh(float x) {
   const float k0 = 0.7978845608028654f;  // sqrt(2/pi)
   const float k1 = 0.044715f;
-  float u = k0 * (x + k1 * x * x * x);
-  // tanh(u) = 1 - 2/(1+exp(2u)); saturates cleanly for |u| large
-  float t = 1.0f - 2.0f / (1.0f + __expf(2.0f * u));
-  return 0.5f * x * (1.0f + t);
+  const float u = k0 * (x + k1 * x * x * x);
+  const float e = __builtin_amdgcn_exp2f(-2.0f * 1.4426950408889634f * u);
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
-VC_DEV float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+VC_DEV float silu_f(float x) {
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;

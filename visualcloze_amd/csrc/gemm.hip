@@ -21,7 +21,7 @@ namespace {
 
 constexpr int BK = 64;
 
-template <int BM, int BN, int WM, int WN, int EPI>
+template <int BM, int BN, int WM, int WN, int EPI, int PP>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const VcGemmArgs args) {
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / WM, TN = BN / WN;
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const VcGemmArgs
     const int c = i * NT + tid;
     const int row = c >> 3, slot = (c & 7) ^ (row & 7);
     const int grow = min(n0 + row, N - 1);
-    b_off[i] = (uint32_t)grow * (uint32_t)K + slot * 8;
+    b_off[i] = (uint32_t)grow * (uint32_t)P.ldw + slot * 8;
   }
 
   auto stage = [&](int buf, int k0) {
@@ -94,84 +94,202 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const VcGemmArgs
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = K / BK;
-  stage(0, 0);
-  __syncthreads();
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * BK);
-    const char* base = smem + cur * STAGE_BYTES;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 af[MI], bfr[NI];
-#pragma unroll
-      for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(base + ((a_rd + i * 16 * 128) ^ (kk * 64)));
-#pragma unroll
-      for (int j = 0; j < NI; ++j) bfr[j] = *(const bf16x8*)(base + ((b_rd + j * 16 * 128) ^ (kk * 64)));
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-    }
+  if constexpr (PP == 0) {
+    // ---- simple schedule: double-buffered LDS, one barrier per K-tile ----
+    stage(0, 0);
     __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * BK);
+      const char* base = smem + cur * STAGE_BYTES;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8 af[MI], bfr[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(base + ((a_rd + i * 16 * 128) ^ (kk * 64)));
+#pragma unroll
+        for (int j = 0; j < NI; ++j) bfr[j] = *(const bf16x8*)(base + ((b_rd + j * 16 * 128) ^ (kk * 64)));
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+  } else {
+    // ---- ping-pong schedule (8 waves = 2 per SIMD): the two waves of a SIMD alternate between a MEMORY segment
+    // (ds_read the next K=32 slice of fragments) and a COMPUTE segment (MI*NI MFMAs), separated by workgroup
+    // barriers; the younger half (waves 4-7, group 1) runs one barrier interval behind, so every SIMD always has
+    // one wave feeding the matrix pipe while its partner loads.
+    //   interval  4t       4t+1   4t+2   4t+3   4t+4        M(t,kk) = reads of tile t slice kk, C = its MFMAs
+    //   group 0   M(t,0)   C(t,0) M(t,1) C(t,1) M(t+1,0)
+    //   group 1   C(t-1,1) M(t,0) C(t,0) M(t,1) C(t,1)
+    // Tile t+1's LDS-DMA (A part = A_IT pieces, B part = B_IT pieces per thread) may be issued from interval 4t on
+    // (its buffer's last readers, group 1's M(t-1,1), retired their ds_reads with lgkmcnt(0) before the barrier
+    // ending interval 4t-1) and every wave waits for its own pieces (vmcnt(0)) before the barrier ending interval
+    // 4t+3, one full interval before the first read.  PP selects WHERE in that window the pieces are issued
+    // (the DMA issue cost, not its latency, is what a segment pays):
+    //   PP  group 0                      group 1
+    //   1   M0: A+B                      M0: A+B
+    //   2   M0: A, C0: B                 C1(prev tile): A, M0: B
+    //   3   C0: A, M1: B                 C1(prev tile): A, C0: B
+    //   4   M0: A, M1: B                 C1(prev tile): A, M0: B
+    static_assert(WM * WN == 8, "ping-pong schedule needs 8 waves");
+    const int grp = wave >> 2;
+    auto bar = [&]() {
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto stageA = [&](int buf, int k0) {
+      char* sa = smem + buf * STAGE_BYTES;
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) glds16(Ab + a_off[i] + k0, sa + (i * NT + wave * 64) * 16);
+    };
+    auto stageB = [&](int buf, int k0) {
+      char* sb = smem + buf * STAGE_BYTES + A_BYTES;
+#pragma unroll
+      for (int i = 0; i < B_IT; ++i) glds16(Wb + b_off[i] + k0, sb + (i * NT + wave * 64) * 16);
+    };
+    // what each (group, segment) issues: 0 none, 1 = A(t+1), 2 = B(t+1), 3 = A+B(t+1), 5 = A(t+2)
+    constexpr int G0_M0 = (PP == 1) ? 3 : (PP == 2 || PP == 4) ? 1 : 0;
+    constexpr int G0_C0 = (PP == 2) ? 2 : (PP == 3) ? 1 : 0;
+    constexpr int G0_M1 = (PP == 3 || PP == 4) ? 2 : 0;
+    constexpr int G1_M0 = (PP == 1) ? 3 : (PP == 2 || PP == 4) ? 2 : 0;
+    constexpr int G1_C0 = (PP == 3) ? 2 : 0;
+    constexpr int G1_C1 = (PP == 1) ? 0 : 5;
+    auto issue = [&](int what, int kt, int cur) {
+      if (what == 0) return;
+      if (what == 5) { if (kt + 2 < nk) stageA(cur, (kt + 2) * BK); return; }
+      if (kt + 1 >= nk) return;
+      if (what & 1) stageA(cur ^ 1, (kt + 1) * BK);
+      if (what & 2) stageB(cur ^ 1, (kt + 1) * BK);
+    };
+    // profiling hook: block 0, lane 0 of waves 0 and 4 stamp s_memtime at 6 points per segment pair
+#ifdef VC_GEMM_TIMESTAMPS
+    uint64_t* ts = (args.debug_ts && blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4))
+                       ? args.debug_ts + (wave >> 2) * 4096 : nullptr;
+    int tsi = 0;
+    auto stamp = [&]() { if (ts && tsi < 4096) ts[tsi++] = __builtin_amdgcn_s_memtime(); };
+#else
+    auto stamp = [&]() {};
+#endif
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bar();
+    if (grp == 1) {
+      if (G1_C1 == 5 && nk > 1) stageA(1, BK);   // what C1 of "tile -1" would have issued
+      bar();
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      const char* base = smem + cur * STAGE_BYTES;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        // ---- memory segment
+        stamp();
+        if (kk == 0) { if (grp == 0) issue(G0_M0, kt, cur); else issue(G1_M0, kt, cur); }
+        else if (grp == 0) issue(G0_M1, kt, cur);
+        bf16x8 af[MI], bfr[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(base + ((a_rd + i * 16 * 128) ^ (kk * 64)));
+#pragma unroll
+        for (int j = 0; j < NI; ++j) bfr[j] = *(const bf16x8*)(base + ((b_rd + j * 16 * 128) ^ (kk * 64)));
+        stamp();
+        if (kk == 1 && grp == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        stamp();
+        bar();
+        stamp();
+        // ---- compute segment
+        if (kk == 0) { if (grp == 0) issue(G0_C0, kt, cur); else issue(G1_C0, kt, cur); }
+        else if (grp == 1) issue(G1_C1, kt, cur);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        stamp();
+        if (kk == 1 && grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp();
+        bar();
+      }
+    }
+    if (grp == 0) bar();
   }
 
-  // ---- epilogue: lane holds C[m = ..+fr][n = ..+fq*4 .. +3] ----
+  // ---- epilogue, pass 1: lane holds C[m = ..+fr][n = ..+fq*4 .. +3]; t = bf16(acc + bias) -> LDS tile ----
+  // (the K loop ended on a barrier, so the staging buffers are free).  Rows are padded by 16 B: the 16 rows a
+  // ds_write_b64 lane group touches then land on distinct bank pairs (2-way at worst).
+  constexpr int EP_LD = BN * 2 + 16;
   const bf16_t* __restrict__ bias = (const bf16_t*)P.bias;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int row = wm * TM + i * 16 + fr;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int col = wn * TN + j * 16 + fq * 4;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (bias && n0 + col < N) {
+        const u32x2 bb = *(const u32x2*)(bias + n0 + col);
+        v[0] += lo_bf(bb[0]); v[1] += hi_bf(bb[0]); v[2] += lo_bf(bb[1]); v[3] += hi_bf(bb[1]);
+      }
+      u32x2 o;
+      o[0] = pack2bf(v[0], v[1]);
+      o[1] = pack2bf(v[2], v[3]);
+      *(u32x2*)(smem + row * EP_LD + col * 2) = o;
+    }
+  }
+  __syncthreads();
+
+  // ---- pass 2: row-major, 16 B per lane, whole rows per wave-instruction -> coalesced HBM traffic ----
   bf16_t* __restrict__ C = (bf16_t*)P.C;
   const bf16_t* __restrict__ res = (const bf16_t*)P.res;
   const bf16_t* __restrict__ gate = (const bf16_t*)P.gate;
   long gate_step = 0;
   if (EPI == VC_EPI_GATE_RES && args.step_ptr) gate_step = (long)(*args.step_ptr) * args.gate_step_stride;
-
+  constexpr int CPR = BN / 8;  // 16-B chunks per tile row
+#pragma unroll 4
+  for (int c = tid; c < BM * CPR; c += NT) {
+    const int row = c / CPR, cc = c % CPR;
+    const int m = m0 + row, n = n0 + cc * 8;
+    if (m >= M || n >= N) continue;
+    const u32x4 tw = *(const u32x4*)(smem + row * EP_LD + cc * 16);
+    float v[8];
 #pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    const int m = m0 + wm * TM + i * 16 + fr;
-    if (m >= M) continue;
-    const bf16_t* grow_ptr = nullptr;
-    if (EPI == VC_EPI_GATE_RES) grow_ptr = gate + gate_step + (long)(m / P.rows_per_batch) * P.gate_bstride;
+    for (int e = 0; e < 4; ++e) { v[2 * e] = lo_bf(tw[e]); v[2 * e + 1] = hi_bf(tw[e]); }
+    u32x4 o = tw;
+    if (EPI == VC_EPI_GELU) {
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int n = n0 + wn * TN + j * 16 + fq * 4;
-      if (n >= N) continue;
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      if (bias) {
-        const u32x2 bb = *(const u32x2*)(bias + n);
-        v[0] += lo_bf(bb[0]); v[1] += hi_bf(bb[0]); v[2] += lo_bf(bb[1]); v[3] += hi_bf(bb[1]);
-      }
-      if (EPI == VC_EPI_GELU) {
+      for (int e = 0; e < 4; ++e) o[e] = pack2bf(gelu_tanh(v[2 * e]), gelu_tanh(v[2 * e + 1]));
+    } else if (EPI == VC_EPI_SILU) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(rbf(v[e]));
-      } else if (EPI == VC_EPI_SILU) {
+      for (int e = 0; e < 4; ++e) o[e] = pack2bf(silu_f(v[2 * e]), silu_f(v[2 * e + 1]));
+    } else if (EPI == VC_EPI_GATE_RES) {
+      const u32x4 gg = *(const u32x4*)(gate + gate_step + (long)(m / P.rows_per_batch) * P.gate_bstride + n);
+      const u32x4 rr = *(const u32x4*)(res + (long)m * P.ldres + n);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = silu_f(rbf(v[e]));
-      } else if (EPI == VC_EPI_GATE_RES) {
-        const u32x2 gg = *(const u32x2*)(grow_ptr + n);
-        const u32x2 rr = *(const u32x2*)(res + (long)m * P.ldres + n);
-        const float g[4] = {lo_bf(gg[0]), hi_bf(gg[0]), lo_bf(gg[1]), hi_bf(gg[1])};
-        const float r[4] = {lo_bf(rr[0]), hi_bf(rr[0]), lo_bf(rr[1]), hi_bf(rr[1])};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = r[e] + rbf(g[e] * rbf(v[e]));
-      }
-      u32x2 o;
-      o[0] = pack2bf(v[0], v[1]);
-      o[1] = pack2bf(v[2], v[3]);
-      *(u32x2*)(C + (long)m * P.ldc + n) = o;
+      for (int e = 0; e < 4; ++e)
+        o[e] = pack2bf(lo_bf(rr[e]) + rbf(lo_bf(gg[e]) * v[2 * e]), hi_bf(rr[e]) + rbf(hi_bf(gg[e]) * v[2 * e + 1]));
     }
+    *(u32x4*)(C + (long)m * P.ldc + n) = o;
   }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int PP>
 hipError_t launch_cfg(const VcGemmArgs& a, int total_tiles, hipStream_t s) {
   constexpr int NT = WM * WN * 64;
-  constexpr int LDS = 2 * (BM + BN) * BK * 2;
+  constexpr int LDS_STAGES = 2 * (BM + BN) * BK * 2, LDS_EPI = BM * (BN * 2 + 16);
+  constexpr int LDS = LDS_STAGES > LDS_EPI ? LDS_STAGES : LDS_EPI;
   void (*fn)(const VcGemmArgs) = nullptr;
   switch (a.epi) {
-    case VC_EPI_BIAS: fn = gemm_bf16_kernel<BM, BN, WM, WN, VC_EPI_BIAS>; break;
-    case VC_EPI_GELU: fn = gemm_bf16_kernel<BM, BN, WM, WN, VC_EPI_GELU>; break;
-    case VC_EPI_GATE_RES: fn = gemm_bf16_kernel<BM, BN, WM, WN, VC_EPI_GATE_RES>; break;
-    case VC_EPI_SILU: fn = gemm_bf16_kernel<BM, BN, WM, WN, VC_EPI_SILU>; break;
+    case VC_EPI_BIAS: fn = gemm_bf16_kernel<BM, BN, WM, WN, VC_EPI_BIAS, PP>; break;
+    case VC_EPI_GELU: fn = gemm_bf16_kernel<BM, BN, WM, WN, VC_EPI_GELU, PP>; break;
+    case VC_EPI_GATE_RES: fn = gemm_bf16_kernel<BM, BN, WM, WN, VC_EPI_GATE_RES, PP>; break;
+    case VC_EPI_SILU: fn = gemm_bf16_kernel<BM, BN, WM, WN, VC_EPI_SILU, PP>; break;
     default: return hipErrorInvalidValue;
   }
   static bool attr_done[4] = {false, false, false, false};
@@ -186,37 +304,46 @@ hipError_t launch_cfg(const VcGemmArgs& a, int total_tiles, hipStream_t s) {
 
 }  // namespace
 
-// tile_cfg: 0 = auto, 1 = 128x128 (4 waves), 2 = 256x128 (8 waves), 3 = 256x256 (8 waves)
+// tile_cfg: 0 = auto, 1 = 128x128 (4 waves), 2 = 256x128, 3 = 256x256, 4 = 256x192 (8 waves each)
 int vc_gemm_launch(VcGemmArgs a, int tile_cfg, hipStream_t s, char* err, int errlen) {
   if (a.nprob < 1 || a.nprob > 2) { snprintf(err, errlen, "gemm: nprob must be 1 or 2"); return VC_ERR_ARG; }
   for (int i = 0; i < a.nprob; ++i) {
     const VcGemmProblem& p = a.p[i];
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) { snprintf(err, errlen, "gemm: empty problem %d (M=%d N=%d K=%d)", i, p.M, p.N, p.K); return VC_ERR_ARG; }
     if (p.K % BK) { snprintf(err, errlen, "gemm: K=%d must be a multiple of %d", p.K, BK); return VC_ERR_ARG; }
-    if (p.N % 4 || p.ldc % 4 || p.lda % 8) { snprintf(err, errlen, "gemm: need N%%4==0, ldc%%4==0, lda%%8==0 (N=%d ldc=%ld lda=%ld)", p.N, (long)p.ldc, (long)p.lda); return VC_ERR_ARG; }
+    if (p.N % 8 || p.ldc % 8 || p.lda % 8) { snprintf(err, errlen, "gemm: need N, ldc, lda multiples of 8 (N=%d ldc=%ld lda=%ld)", p.N, (long)p.ldc, (long)p.lda); return VC_ERR_ARG; }
     if (!p.A || !p.W || !p.C) { snprintf(err, errlen, "gemm: null operand"); return VC_ERR_ARG; }
-    if ((uint64_t)p.M * (uint64_t)p.lda >= (1ull << 32) || (uint64_t)p.N * (uint64_t)p.K >= (1ull << 32)) {
+    if ((uint64_t)p.M * (uint64_t)p.lda >= (1ull << 32) || (uint64_t)p.N * (uint64_t)p.ldw >= (1ull << 32) || p.ldw < p.K || p.ldw % 8) {
       snprintf(err, errlen, "gemm: operand exceeds 32-bit element offsets"); return VC_ERR_ARG; }
-    if (a.epi == VC_EPI_GATE_RES && (!p.res || !p.gate || p.rows_per_batch <= 0 || p.ldres % 4)) {
+    if (a.epi == VC_EPI_GATE_RES && (!p.res || !p.gate || p.rows_per_batch <= 0 || p.ldres % 8 || p.gate_bstride % 8 || a.gate_step_stride % 8)) {
       snprintf(err, errlen, "gemm: gate/residual epilogue needs res, gate, rows_per_batch"); return VC_ERR_ARG; }
   }
+  // + 16*PP selects a ping-pong main-loop schedule PP = 1..4 (8-wave tiles 256x256 / 256x192 only)
+  int pp = (tile_cfg >> 4) & 7;
+  tile_cfg &= 15;
+  static const int cfg_bm[5] = {0, 128, 256, 256, 256}, cfg_bn[5] = {0, 128, 128, 256, 192};
   if (tile_cfg == 0) {
-    // pick the tile that keeps >= ~2 block-waves of work on 256 CUs
-    long t256 = 0, t2128 = 0;
-    for (int i = 0; i < a.nprob; ++i) {
-      t256 += (long)((a.p[i].M + 255) / 256) * ((a.p[i].N + 255) / 256);
-      t2128 += (long)((a.p[i].M + 255) / 256) * ((a.p[i].N + 127) / 128);
+    // Cost model fitted on MI355X (M=3968 FLUX shapes): time = block-rounds on 256 CUs x (tile area x (K + fixed
+    // prologue/epilogue charge) / streaming efficiency of that tile).  Candidates: 128x128 simple loop (2 blocks
+    // per CU; small or skinny problems), 256x256 and 256x192 ping-pong (1 block per CU).  256x192 makes the tile
+    // count a multiple of 256 for M<=4096 and every FLUX N (3072/9216/12288/21504).
+    static const int cand[3] = {1, 3, 4};
+    static const int cand_pp[3] = {0, 1, 1};
+    static const double eff[3] = {0.55, 1.0, 0.785}, ovh[3] = {500.0, 650.0, 350.0};
+    double best = 1e300;
+    for (int ci = 0; ci < 3; ++ci) {
+      const int c = cand[ci];
+      long tiles = 0;
+      for (int i = 0; i < a.nprob; ++i)
+        tiles += (long)((a.p[i].M + cfg_bm[c] - 1) / cfg_bm[c]) * ((a.p[i].N + cfg_bn[c] - 1) / cfg_bn[c]);
+      const int per_cu = (c == 1) ? 2 : 1;
+      const long rounds = (tiles + 256L * per_cu - 1) / (256L * per_cu);
+      const double t = rounds * (per_cu * (double)cfg_bm[c] * cfg_bn[c] * ((double)a.p[0].K + ovh[ci]) / eff[ci]);
+      if (t < best) { best = t; tile_cfg = c; pp = cand_pp[ci]; }
     }
-    tile_cfg = 1;
-    (void)t256; (void)t2128;
   }
-  int bm, bn;
-  switch (tile_cfg) {
-    case 1: bm = 128; bn = 128; break;
-    case 2: bm = 256; bn = 128; break;
-    case 3: bm = 256; bn = 256; break;
-    default: snprintf(err, errlen, "gemm: bad tile_cfg %d", tile_cfg); return VC_ERR_ARG;
-  }
+  if (tile_cfg < 1 || tile_cfg > 4 || pp > 4 || (pp && tile_cfg < 3)) { snprintf(err, errlen, "gemm: bad tile_cfg %d", tile_cfg); return VC_ERR_ARG; }
+  const int bm = cfg_bm[tile_cfg], bn = cfg_bn[tile_cfg];
   int total = 0;
   for (int i = 0; i < a.nprob; ++i) {
     a.p[i].tiles_m = (a.p[i].M + bm - 1) / bm;
@@ -226,9 +353,18 @@ int vc_gemm_launch(VcGemmArgs a, int tile_cfg, hipStream_t s, char* err, int err
   }
   hipError_t e;
   switch (tile_cfg) {
-    case 1: e = launch_cfg<128, 128, 2, 2>(a, total, s); break;
-    case 2: e = launch_cfg<256, 128, 4, 2>(a, total, s); break;
-    default: e = launch_cfg<256, 256, 2, 4>(a, total, s); break;
+    case 1: e = launch_cfg<128, 128, 2, 2, 0>(a, total, s); break;
+    case 2: e = launch_cfg<256, 128, 4, 2, 0>(a, total, s); break;
+    case 3:
+      e = pp == 0 ? launch_cfg<256, 256, 2, 4, 0>(a, total, s) : pp == 1 ? launch_cfg<256, 256, 2, 4, 1>(a, total, s)
+        : pp == 2 ? launch_cfg<256, 256, 2, 4, 2>(a, total, s) : pp == 3 ? launch_cfg<256, 256, 2, 4, 3>(a, total, s)
+                  : launch_cfg<256, 256, 2, 4, 4>(a, total, s);
+      break;
+    default:
+      e = pp == 0 ? launch_cfg<256, 192, 4, 2, 0>(a, total, s) : pp == 1 ? launch_cfg<256, 192, 4, 2, 1>(a, total, s)
+        : pp == 2 ? launch_cfg<256, 192, 4, 2, 2>(a, total, s) : pp == 3 ? launch_cfg<256, 192, 4, 2, 3>(a, total, s)
+                  : launch_cfg<256, 192, 4, 2, 4>(a, total, s);
+      break;
   }
   if (e != hipSuccess) { snprintf(err, errlen, "gemm launch: %s", hipGetErrorString(e)); return VC_ERR_HIP; }
   return VC_OK;

@@ -27,7 +27,7 @@ class GemmProblem(C.Structure):
     _fields_ = [
         ("A", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p), ("C", C.c_void_p),
         ("res", C.c_void_p), ("gate", C.c_void_p),
-        ("lda", C.c_int64), ("ldc", C.c_int64), ("ldres", C.c_int64), ("gate_bstride", C.c_int64),
+        ("lda", C.c_int64), ("ldw", C.c_int64), ("ldc", C.c_int64), ("ldres", C.c_int64), ("gate_bstride", C.c_int64),
         ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("rows_per_batch", C.c_int32),
         ("tiles_m", C.c_int32), ("tiles_n", C.c_int32), ("tile_start", C.c_int32), ("_pad", C.c_int32),
     ]
@@ -36,7 +36,7 @@ class GemmProblem(C.Structure):
 class GemmArgs(C.Structure):
     _fields_ = [
         ("p", GemmProblem * 2), ("nprob", C.c_int32), ("epi", C.c_int32),
-        ("step_ptr", C.c_void_p), ("gate_step_stride", C.c_int64),
+        ("step_ptr", C.c_void_p), ("gate_step_stride", C.c_int64), ("debug_ts", C.c_void_p),
     ]
 
 
@@ -134,8 +134,6 @@ def make_problem(a, w, bias, out, res=None, gate=None, rows_per_batch=None, gate
         _bf16(t, n)
         if t.dim() != 2 or t.stride(1) != 1:
             raise VclozeHipError(f"gemm {n}: need a 2-D tensor with contiguous last dim")
-    if not w.is_contiguous():
-        raise VclozeHipError("gemm W must be contiguous [N,K]")
     M, K = a.shape
     N = w.shape[0]
     if w.shape[1] != K or tuple(out.shape) != (M, N):
@@ -143,7 +141,7 @@ def make_problem(a, w, bias, out, res=None, gate=None, rows_per_batch=None, gate
     p = GemmProblem()
     p.A, p.W, p.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
     p.bias = _p(bias)
-    p.lda, p.ldc = a.stride(0), out.stride(0)
+    p.lda, p.ldw, p.ldc = a.stride(0), w.stride(0), out.stride(0)
     p.M, p.N, p.K = M, N, K
     p.rows_per_batch = rows_per_batch or M
     if res is not None:
@@ -155,7 +153,7 @@ def make_problem(a, w, bias, out, res=None, gate=None, rows_per_batch=None, gate
     return p
 
 
-def gemm(problems, epi=EPI_BIAS, tile_cfg=0, step_ptr=None, gate_step_stride=0, stream=None) -> None:
+def gemm(problems, epi=EPI_BIAS, tile_cfg=0, step_ptr=None, gate_step_stride=0, stream=None, debug_ts=None) -> None:
     args = GemmArgs()
     if isinstance(problems, GemmProblem):
         problems = [problems]
@@ -165,6 +163,7 @@ def gemm(problems, epi=EPI_BIAS, tile_cfg=0, step_ptr=None, gate_step_stride=0, 
     args.epi = epi
     args.step_ptr = _p(step_ptr)
     args.gate_step_stride = gate_step_stride
+    args.debug_ts = _p(debug_ts)
     _check(lib().vc_gemm(C.byref(args), tile_cfg, stream if stream is not None else cur_stream()), "vc_gemm")
 
 

@@ -70,15 +70,9 @@ def build_model(dev, rank, world, lora_rank=256):
                 p.zero_()
             else:                             # matrices incl. LoRA A/B: N(0, 0.02) so the LoRA path is live
                 p.normal_(0.0, 0.02, generator=g)
-    bcast_s = 0.0
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.synchronize()
-        t0 = time.time()
-        for p in model.parameters():          # one-time RCCL broadcast of the frozen weights over xGMI
-            dist.broadcast(p.data, src=0)
-        torch.cuda.synchronize()
-        bcast_s = time.time() - t0
+    from visualcloze_amd import parallel as par
+    torch.cuda.synchronize()
+    bcast_s = par.broadcast_weights(model, src=0)   # one-time RCCL broadcast of the frozen weights over xGMI
     return model, bcast_s
 
 
@@ -265,10 +259,8 @@ def main():
     hip.require_gpu()                       # fails loudly: there is no CPU path to fall back to
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+    from visualcloze_amd import parallel as par
+    par.init_distributed("nccl", dev)
     wl = WORKLOADS[a.workload]
     model, bcast_s = build_model(dev, rank, world)
     eng = model.engine()
@@ -276,14 +268,10 @@ def main():
         eng.tile_cfg = a.tile_cfg
     if a.attn_variant is not None:
         eng.attn_variant = a.attn_variant
-    x, kw = make_inputs(dev, wl, seed=rank)            # per-rank seed: independent grids
+    x, kw = make_inputs(dev, wl, seed=par.sample_seed(0, rank))   # seed from the global sample index
     job = Job(model, x, kw, wl["steps"])
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
+    barrier = par.barrier
 
     with torch.cuda.stream(eng.stream):
         for _ in range(a.warmup):
@@ -292,13 +280,9 @@ def main():
         t0 = time.perf_counter()
         for _ in range(a.steps):
             job.step()
-        torch.cuda.synchronize()
+        barrier()                                   # synchronize + barrier + synchronize
         elapsed = time.perf_counter() - t0
-    if world > 1:
-        te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(te, op=torch.distributed.ReduceOp.MAX)
-        elapsed = te.item()
-        torch.distributed.barrier()
+    elapsed = par.max_over_ranks(elapsed, dev)
     final = job.ws.XS.float()
     assert torch.isfinite(final).all(), "non-finite latent"
 

@@ -97,7 +97,8 @@ int vc_add3(const void* a, const void* b, const void* c, void* y, int64_t n, int
 int vc_copy(void* dst, const void* src, int64_t bytes, void* stream);
 /* x||cond -> [rows, cx+cc] (transport.py:195) */
 int vc_concat_cols(const void* x, int32_t cx, const void* cond, int32_t cc, void* out, int64_t rows, void* stream);
-/* Euler update of the fixed-grid solver: x = bf16(x + bf16(dt * (-v))), dt = dts[*step_ptr] (f32). */
+/* Euler update of the fixed-grid solver: x = bf16(x + bf16(bf16(dt) * (-v))), dt = dts[*step_ptr] (f32 table;
+ * torch casts the 0-dim f32 dt to the bf16 common dtype before the multiply, transport/integrators.py:119). */
 int vc_euler_step(void* x, const void* v, const float* dts, const int32_t* step_ptr, int64_t n, void* stream);
 int vc_step_advance(int32_t* step_ptr, void* stream);
 

@@ -348,7 +348,8 @@ def sample_euler(model_fn, x: Tensor, cond: Optional[Tensor], t: Tensor, P: Prec
         v = model_fn(xin, tm)
         assert v.shape == x.shape, "Output shape from ODE solver must match input shape"
         dt = t[i + 1] - t[i]
-        x = P.r(x + P.r(dt * (-v)))
+        # bf16 mode: torch casts the 0-dim f32 dt to the common dtype (bf16) before multiplying a bf16 tensor
+        x = P.r(x + P.r(P.r(dt) * (-v)))
         states.append(x)
         evals.append(float(tm[0]))
     return states, evals

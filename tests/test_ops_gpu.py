@@ -171,7 +171,7 @@ def test_elementwise(hip):
     xs, v = rnd(999, seed=7), rnd(999, seed=8)
     dts = torch.tensor([0.1, 0.037, 0.2], device=DEV)
     step = torch.tensor([1], dtype=torch.int32, device=DEV)
-    ref = R.rb(xs.float() + R.rb(0.037 * (-v.float())))
+    ref = R.rb(xs.float() + R.rb(R.rb(torch.tensor(0.037)).item() * (-v.float())))
     hip.euler_step(xs, v, dts, step)
     check(xs, ref, 1e-6)
     hip.step_advance(step)

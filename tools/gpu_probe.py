@@ -175,7 +175,7 @@ def probe_elementwise():
     xs, v = rnd(999, seed=7), rnd(999, seed=8)
     dts = torch.tensor([0.1, 0.037, 0.2], device=dev)
     step = torch.tensor([1], dtype=torch.int32, device=dev)
-    ref = R.rb(xs.float() + R.rb(0.037 * (-v.float())))
+    ref = R.rb(xs.float() + R.rb(R.rb(torch.tensor(0.037)).item() * (-v.float())))
     x2 = xs.clone()
     hip.euler_step(x2, v, dts, step)
     report("euler", x2, ref)

@@ -48,7 +48,9 @@ __global__ void euler_kernel(bf16_t* __restrict__ x, const bf16_t* __restrict__ 
                              const int* __restrict__ step_ptr, long n) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const float dt = dts[step_ptr ? *step_ptr : 0];
+  // dt is a 0-dim f32 tensor in the reference; multiplying a bf16 tensor by it casts dt to the common dtype
+  // (bf16) first, so the effective step is bf16(dt) (verified against torch: 100 % bitwise agreement)
+  const float dt = rbf(dts[step_ptr ? *step_ptr : 0]);
   const float dy = rbf(dt * (-bf2f(v[i])));
   x[i] = f2bf(bf2f(x[i]) + dy);
 }

@@ -27,6 +27,7 @@ struct AttnArgs {
   const int32_t* kv_len;
   int64_t ld, bstride, ldo, out_bstride;
   int32_t B, L, Lpad, H, qblocks;
+  uint64_t* debug_ts;   // profiling builds only (-DVC_ATTN_TIMESTAMPS)
 };
 
 constexpr int KVB = 64;               // keys per tile
@@ -117,25 +118,49 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs a) 
   float m_run = -INFINITY, l_run = 0.f;
   const float c_scale = 0.08838834764831845f * 1.4426950408889634f;  // 128^-0.5 * log2(e)
 
+#ifdef VC_ATTN_TIMESTAMPS
+  uint64_t* ts = (a.debug_ts && blockIdx.x < 2 && lane == 0 && wave == 0) ? a.debug_ts + blockIdx.x * 4096 : nullptr;
+  int tsi = 0;
+  auto stamp = [&]() { if (ts && tsi < 4096) ts[tsi++] = __builtin_amdgcn_s_memtime(); };
+#else
+  auto stamp = [&]() {};
+#endif
   __syncthreads();
 
   for (int kt = 0; kt < nkt; ++kt) {
     const int cur = kt & 1;
+    stamp();
     if (kt + 1 < nkt) stage(cur ^ 1, kt + 1);
     const char* base = smem + cur * STAGE;
 
-    // S^T = K . Q^T
+    // S^T = K . Q^T.  Fragment reads run one 8-deep batch AHEAD of the MFMAs that consume them (rotating register
+    // set): a ds_read_b128 takes ~130+ cycles to return under load vs 32 cycles per MFMA, so reading just-in-time
+    // (what the compiler schedules on its own) leaves the matrix pipe waiting on LDS latency 3/4 of the time.
     f32x16 s[2];
+    bf16x8 fr8[8];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int t = 0; t < 8; ++t) fr8[t] = *(const bf16x8*)(base + (k_rd[0] ^ (t * 32)));
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[u][r] = 0.f;
+    for (int r = 0; r < 16; ++r) { s[0][r] = 0.f; s[1][r] = 0.f; }
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const bf16x8 kf = *(const bf16x8*)(base + (k_rd[u] ^ (t * 32)));
-        s[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[t], s[u], 0, 0, 0);
-      }
+    for (int t = 0; t < 8; ++t) {
+      s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr8[t], qf[t], s[0], 0, 0, 0);
+      fr8[t] = *(const bf16x8*)(base + (k_rd[1] ^ (t * 32)));
     }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr8[t], qf[t], s[1], 0, 0, 0);
+      // V fragments of d-tiles 0,1 (k-steps 0..3 each) land while the softmax VALU work runs
+      fr8[t] = *(const bf16x8*)(base + (v_rd[t >> 2] ^ ((t & 3) * 32)));
+    }
+    // pin the issue order (hipcc otherwise sinks every read next to its MFMA): 8 reads, then MFMA/read pairs
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    stamp();
     // mask keys beyond kv_len (only the last tile can hold any)
     if (kt * KVB + KVB > kvlen) {
 #pragma unroll
@@ -153,9 +178,20 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs a) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[u][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx * c_scale);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
+    // Deferred rescale: keep the running max (and skip the 64-multiply rescale of O) while no row of this wave grows
+    // its max by more than 2^8 - P then stays <= 256, which bf16 (relative precision) and the f32 sums absorb; the
+    // branch is wave-uniform.  m_run = -inf on the first tile forces the rescale path there.
+    const float m_cand = fmaxf(m_run, mx * c_scale);
+    float alpha = 1.0f;
+    if (!__all(m_cand - m_run <= 8.0f)) {
+      alpha = __builtin_amdgcn_exp2f(m_run - m_cand);
+      m_run = m_cand;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    }
+    const float m_new = m_run;
     float psum = 0.f;
     bf16x8 pf[4];
 #pragma unroll
@@ -167,19 +203,24 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs a) 
         pf[u * 2 + (r >> 3)][r & 7] = (__bf16)p;
       }
     l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
 
-    // O^T += Vt . P^T
+    stamp();
+    // O^T += Vt . P^T  (fr8 holds d-tiles 0,1; each slot is refilled with d-tiles 2,3 right after its MFMA)
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
+    for (int t = 0; t < 8; ++t) {
+      o[t >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr8[t], pf[t & 3], o[t >> 2], 0, 0, 0);
+      fr8[t] = *(const bf16x8*)(base + (v_rd[2 + (t >> 2)] ^ ((t & 3) * 32)));
+    }
 #pragma unroll
-      for (int sI = 0; sI < 4; ++sI) {
-        const bf16x8 vf = *(const bf16x8*)(base + (v_rd[dt] ^ (sI * 32)));
-        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[sI], o[dt], 0, 0, 0);
-      }
+    for (int t = 0; t < 8; ++t)
+      o[2 + (t >> 2)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr8[t], pf[t & 3], o[2 + (t >> 2)], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 1);
+    stamp();
     __syncthreads();
   }
 
@@ -203,6 +244,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs a) 
 
 }  // namespace
 
+static uint64_t* g_attn_debug_ts = nullptr;
+extern "C" void vc_debug_set_attn_ts(void* p) { g_attn_debug_ts = (uint64_t*)p; }   // tools/ only; not in the ABI header
+
 int vc_attention_launch(const void* qkv, int64_t ld, int64_t bstride, const void* vt, void* out, int64_t ldo,
                         int64_t out_bstride, const int32_t* kv_len, int32_t B, int32_t L, int32_t Lpad,
                         int32_t H, int32_t variant, hipStream_t s, char* err, int errlen) {
@@ -215,6 +259,7 @@ int vc_attention_launch(const void* qkv, int64_t ld, int64_t bstride, const void
   a.qkv = (const bf16_t*)qkv; a.vt = (const bf16_t*)vt; a.out = (bf16_t*)out; a.kv_len = kv_len;
   a.ld = ld; a.bstride = bstride; a.ldo = ldo; a.out_bstride = out_bstride;
   a.B = B; a.L = L; a.Lpad = Lpad; a.H = H;
+  a.debug_ts = g_attn_debug_ts;
   const int lds = 2 * STAGE;
   hipError_t e;
   if (variant == 1) {  // 4 waves x 32 queries

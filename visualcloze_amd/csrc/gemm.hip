@@ -125,16 +125,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const VcGemmArgs
     //   interval  4t       4t+1   4t+2   4t+3   4t+4        M(t,kk) = reads of tile t slice kk, C = its MFMAs
     //   group 0   M(t,0)   C(t,0) M(t,1) C(t,1) M(t+1,0)
     //   group 1   C(t-1,1) M(t,0) C(t,0) M(t,1) C(t,1)
-    // Tile t+1's LDS-DMA (A part = A_IT pieces, B part = B_IT pieces per thread) may be issued from interval 4t on
-    // (its buffer's last readers, group 1's M(t-1,1), retired their ds_reads with lgkmcnt(0) before the barrier
-    // ending interval 4t-1) and every wave waits for its own pieces (vmcnt(0)) before the barrier ending interval
-    // 4t+3, one full interval before the first read.  PP selects WHERE in that window the pieces are issued
-    // (the DMA issue cost, not its latency, is what a segment pays):
-    //   PP  group 0                      group 1
-    //   1   M0: A+B                      M0: A+B
-    //   2   M0: A, C0: B                 C1(prev tile): A, M0: B
-    //   3   C0: A, M1: B                 C1(prev tile): A, C0: B
-    //   4   M0: A, M1: B                 C1(prev tile): A, M0: B
+    // Tile t+1's LDS-DMA is issued at the top of M(t,0) (interval 4t for group 0, 4t+1 for group 1): its buffer's
+    // last readers, group 1's M(t-1,1), retired their ds_reads with lgkmcnt(0) before the barrier ending interval
+    // 4t-1.  Every wave waits for its own pieces (vmcnt(0)) before the barrier ending interval 4t+3, one full
+    // interval before the first read.  (Measured alternatives that did NOT help on MI355X, see DESIGN.md: spreading
+    // the DMA issue over other segments; whole-K-tile segments; a 4-deep ring of K=32 stages - its 64-B row
+    // pieces halve the bytes used per 128-B line and lost 20 %.)
     static_assert(WM * WN == 8, "ping-pong schedule needs 8 waves");
     const int grp = wave >> 2;
     auto bar = [&]() {
@@ -142,32 +138,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const VcGemmArgs
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
     };
-    auto stageA = [&](int buf, int k0) {
-      char* sa = smem + buf * STAGE_BYTES;
-#pragma unroll
-      for (int i = 0; i < A_IT; ++i) glds16(Ab + a_off[i] + k0, sa + (i * NT + wave * 64) * 16);
-    };
-    auto stageB = [&](int buf, int k0) {
-      char* sb = smem + buf * STAGE_BYTES + A_BYTES;
-#pragma unroll
-      for (int i = 0; i < B_IT; ++i) glds16(Wb + b_off[i] + k0, sb + (i * NT + wave * 64) * 16);
-    };
-    // what each (group, segment) issues: 0 none, 1 = A(t+1), 2 = B(t+1), 3 = A+B(t+1), 5 = A(t+2)
-    constexpr int G0_M0 = (PP == 1) ? 3 : (PP == 2 || PP == 4) ? 1 : 0;
-    constexpr int G0_C0 = (PP == 2) ? 2 : (PP == 3) ? 1 : 0;
-    constexpr int G0_M1 = (PP == 3 || PP == 4) ? 2 : 0;
-    constexpr int G1_M0 = (PP == 1) ? 3 : (PP == 2 || PP == 4) ? 2 : 0;
-    constexpr int G1_C0 = (PP == 3) ? 2 : 0;
-    constexpr int G1_C1 = (PP == 1) ? 0 : 5;
-    auto issue = [&](int what, int kt, int cur) {
-      if (what == 0) return;
-      if (what == 5) { if (kt + 2 < nk) stageA(cur, (kt + 2) * BK); return; }
-      if (kt + 1 >= nk) return;
-      if (what & 1) stageA(cur ^ 1, (kt + 1) * BK);
-      if (what & 2) stageB(cur ^ 1, (kt + 1) * BK);
-    };
-    // profiling hook: block 0, lane 0 of waves 0 and 4 stamp s_memtime at 6 points per segment pair
-#ifdef VC_GEMM_TIMESTAMPS
+#ifdef VC_GEMM_TIMESTAMPS   // profiling builds only (tools/gemm_ts.py): s_memtime stamps of block 0, waves 0 and 4
     uint64_t* ts = (args.debug_ts && blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4))
                        ? args.debug_ts + (wave >> 2) * 4096 : nullptr;
     int tsi = 0;
@@ -178,10 +149,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const VcGemmArgs
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     bar();
-    if (grp == 1) {
-      if (G1_C1 == 5 && nk > 1) stageA(1, BK);   // what C1 of "tile -1" would have issued
-      bar();
-    }
+    if (grp == 1) bar();
     for (int kt = 0; kt < nk; ++kt) {
       const int cur = kt & 1;
       const char* base = smem + cur * STAGE_BYTES;
@@ -189,8 +157,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const VcGemmArgs
       for (int kk = 0; kk < 2; ++kk) {
         // ---- memory segment
         stamp();
-        if (kk == 0) { if (grp == 0) issue(G0_M0, kt, cur); else issue(G1_M0, kt, cur); }
-        else if (grp == 0) issue(G0_M1, kt, cur);
+        if (kk == 0 && kt + 1 < nk) stage(cur ^ 1, (kt + 1) * BK);
         bf16x8 af[MI], bfr[NI];
 #pragma unroll
         for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(base + ((a_rd + i * 16 * 128) ^ (kk * 64)));
@@ -203,8 +170,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const VcGemmArgs
         bar();
         stamp();
         // ---- compute segment
-        if (kk == 0) { if (grp == 0) issue(G0_C0, kt, cur); else issue(G1_C0, kt, cur); }
-        else if (grp == 1) issue(G1_C1, kt, cur);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -318,7 +283,7 @@ int vc_gemm_launch(VcGemmArgs a, int tile_cfg, hipStream_t s, char* err, int err
     if (a.epi == VC_EPI_GATE_RES && (!p.res || !p.gate || p.rows_per_batch <= 0 || p.ldres % 8 || p.gate_bstride % 8 || a.gate_step_stride % 8)) {
       snprintf(err, errlen, "gemm: gate/residual epilogue needs res, gate, rows_per_batch"); return VC_ERR_ARG; }
   }
-  // + 16*PP selects a ping-pong main-loop schedule PP = 1..4 (8-wave tiles 256x256 / 256x192 only)
+  // +16 selects the ping-pong main loop (8-wave tiles 256x256 / 256x192); auto picks it for those tiles
   int pp = (tile_cfg >> 4) & 7;
   tile_cfg &= 15;
   static const int cfg_bm[5] = {0, 128, 256, 256, 256}, cfg_bn[5] = {0, 128, 128, 256, 192};
@@ -342,7 +307,7 @@ int vc_gemm_launch(VcGemmArgs a, int tile_cfg, hipStream_t s, char* err, int err
       if (t < best) { best = t; tile_cfg = c; pp = cand_pp[ci]; }
     }
   }
-  if (tile_cfg < 1 || tile_cfg > 4 || pp > 4 || (pp && tile_cfg < 3)) { snprintf(err, errlen, "gemm: bad tile_cfg %d", tile_cfg); return VC_ERR_ARG; }
+  if (tile_cfg < 1 || tile_cfg > 4 || pp > 1 || (pp && tile_cfg < 3)) { snprintf(err, errlen, "gemm: bad tile_cfg %d", tile_cfg); return VC_ERR_ARG; }
   const int bm = cfg_bm[tile_cfg], bn = cfg_bn[tile_cfg];
   int total = 0;
   for (int i = 0; i < a.nprob; ++i) {
@@ -355,16 +320,8 @@ int vc_gemm_launch(VcGemmArgs a, int tile_cfg, hipStream_t s, char* err, int err
   switch (tile_cfg) {
     case 1: e = launch_cfg<128, 128, 2, 2, 0>(a, total, s); break;
     case 2: e = launch_cfg<256, 128, 4, 2, 0>(a, total, s); break;
-    case 3:
-      e = pp == 0 ? launch_cfg<256, 256, 2, 4, 0>(a, total, s) : pp == 1 ? launch_cfg<256, 256, 2, 4, 1>(a, total, s)
-        : pp == 2 ? launch_cfg<256, 256, 2, 4, 2>(a, total, s) : pp == 3 ? launch_cfg<256, 256, 2, 4, 3>(a, total, s)
-                  : launch_cfg<256, 256, 2, 4, 4>(a, total, s);
-      break;
-    default:
-      e = pp == 0 ? launch_cfg<256, 192, 4, 2, 0>(a, total, s) : pp == 1 ? launch_cfg<256, 192, 4, 2, 1>(a, total, s)
-        : pp == 2 ? launch_cfg<256, 192, 4, 2, 2>(a, total, s) : pp == 3 ? launch_cfg<256, 192, 4, 2, 3>(a, total, s)
-                  : launch_cfg<256, 192, 4, 2, 4>(a, total, s);
-      break;
+    case 3: e = pp ? launch_cfg<256, 256, 2, 4, 1>(a, total, s) : launch_cfg<256, 256, 2, 4, 0>(a, total, s); break;
+    default: e = pp ? launch_cfg<256, 192, 4, 2, 1>(a, total, s) : launch_cfg<256, 192, 4, 2, 0>(a, total, s); break;
   }
   if (e != hipSuccess) { snprintf(err, errlen, "gemm launch: %s", hipGetErrorString(e)); return VC_ERR_HIP; }
   return VC_OK;

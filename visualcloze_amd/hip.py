@@ -13,7 +13,7 @@ from typing import Optional
 import torch  # noqa: F401  (must be imported first so the process shares torch's HIP runtime)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvcloze_hip.so")
+LIB_PATH = os.environ.get("VC_HIP_LIB") or os.path.join(_HERE, "lib", "libvcloze_hip.so")   # VC_HIP_LIB: profiling build
 CSRC = os.path.join(_HERE, "csrc")
 
 EPI_BIAS, EPI_GELU, EPI_GATE_RES, EPI_SILU = 0, 1, 2, 3

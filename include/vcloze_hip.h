@@ -102,6 +102,15 @@ int vc_concat_cols(const void* x, int32_t cx, const void* cond, int32_t cc, void
 int vc_euler_step(void* x, const void* v, const float* dts, const int32_t* step_ptr, int64_t n, void* stream);
 int vc_step_advance(int32_t* step_ptr, void* stream);
 
+/* ---- latent-grid packer / unpacker (the steps either side of the loop) ----
+ * pack:   latent [C,h,w] bf16 -> tokens[(h/2)(w/2)][col0 .. col0+4C) of rows with stride ld
+ *         ("c (h ph) (w pw) -> (h w) (c ph pw)", models/sampling.py:61, visualcloze.py:208-209,385-386)
+ * mask:   pixel mask [H,W] bf16 -> [(H/16)(W/16)][col0 .. col0+256)  (8x8 unshuffle + 2x2 pack, visualcloze.py:381-382)
+ * unpack: the inverse of pack (visualcloze.py:237,428) */
+int vc_pack_latent(const void* latent, void* tokens, int32_t C, int32_t h, int32_t w, int64_t ld, int32_t col0, void* stream);
+int vc_pack_mask(const void* mask, void* tokens, int32_t H, int32_t W, int64_t ld, int32_t col0, void* stream);
+int vc_unpack_latent(const void* tokens, int64_t ld, int32_t col0, void* latent, int32_t C, int32_t h, int32_t w, void* stream);
+
 /* ---- hipGraph helpers: capture the launches issued on `stream` between begin/end ---- */
 int vc_stream_create(void** stream);
 int vc_stream_destroy(void* stream);

@@ -368,3 +368,40 @@ def grid_img_ids(rows_hw: List[tuple]) -> Tensor:
         ids[..., 2] = ids[..., 2] + torch.arange(w // 2)[None, :]
         out.append(ids.reshape(-1, 3))
     return torch.cat(out, dim=0)
+
+
+def pack_latent(lat: Tensor) -> Tensor:
+    """"c (h ph) (w pw) -> (h w) (c ph pw)", ph = pw = 2 (models/sampling.py:61): [C,h,w] -> [(h/2)(w/2), 4C]."""
+    C, h, w = lat.shape
+    return lat.reshape(C, h // 2, 2, w // 2, 2).permute(1, 3, 0, 2, 4).reshape((h // 2) * (w // 2), C * 4)
+
+
+def unpack_latent(tok: Tensor, h: int, w: int) -> Tensor:
+    """"(h w) (c ph pw) -> c (h ph) (w pw)" (visualcloze.py:237,428): [(h/2)(w/2), 4C] -> [C,h,w]."""
+    C = tok.shape[-1] // 4
+    return tok.reshape(h // 2, w // 2, C, 2, 2).permute(2, 0, 3, 1, 4).reshape(C, h, w)
+
+
+def pack_mask(mask: Tensor) -> Tensor:
+    """visualcloze.py:381-382: pixel mask [H,W] -> 8x8 pixel-unshuffle -> 2x2 pack -> [(H/16)(W/16), 256]."""
+    H, W = mask.shape
+    m8 = mask.reshape(H // 8, 8, W // 8, 8).permute(1, 3, 0, 2).reshape(64, H // 8, W // 8)
+    return pack_latent(m8)
+
+
+def prepare_grid(samples: List[List[Tensor]]):
+    """Tensor part of prepare_modified (models/sampling.py:37-100): per sample a list of row latents [1,16,h,w];
+    returns img [B,Nmax,64], img_ids [B,Nmax,3], img_mask [B,Nmax] (int32), right-padded to the batch max."""
+    toks, ids = [], []
+    for rows in samples:
+        toks.append(torch.cat([pack_latent(r.squeeze(0)) for r in rows], dim=0))
+        ids.append(grid_img_ids([tuple(r.shape[-2:]) for r in rows]))
+    n = max(t.shape[0] for t in toks)
+    B = len(samples)
+    img = torch.zeros(B, n, toks[0].shape[1], dtype=toks[0].dtype)
+    img_ids = torch.zeros(B, n, 3)
+    mask = torch.zeros(B, n, dtype=torch.int32)
+    for b in range(B):
+        k = toks[b].shape[0]
+        img[b, :k], img_ids[b, :k], mask[b, :k] = toks[b], ids[b], 1
+    return img, img_ids, mask

@@ -26,8 +26,12 @@ sys.path.insert(0, REPO)
 
 
 def install_shims():
+    import importlib.machinery
     fa = types.ModuleType("flash_attn")
     bp = types.ModuleType("flash_attn.bert_padding")
+    fa.__spec__ = importlib.machinery.ModuleSpec("flash_attn", None)      # transformers probes find_spec()
+    bp.__spec__ = importlib.machinery.ModuleSpec("flash_attn.bert_padding", None)
+    fa.__version__ = "0.0.0"
 
     def flash_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p=0.0,
                                softmax_scale=None, causal=False, **kw):
@@ -204,6 +208,36 @@ def main():
                     txt=inp["txt"].bfloat16(), txt_ids=inp["txt_ids"], txt_mask=inp["txt_mask"], y=inp["y"].bfloat16(),
                     img_ids=inp["img_ids"], img_mask=inp["img_mask"], guidance=inp["guidance"].bfloat16())
         out["flux_b1_ref_bf16"] = yb.float().numpy()
+
+    # ---------------- latent-grid packer: the tensor part of prepare_modified (models/sampling.py:37-118) -------------
+    # models.sampling imports cv2 / models.util (imwatermark) through image_embedders: stub those two modules.
+    import importlib.machinery
+    cv2 = types.ModuleType("cv2")
+    cv2.__spec__ = importlib.machinery.ModuleSpec("cv2", None)
+    sys.modules["cv2"] = cv2
+    mu = types.ModuleType("models.util")
+    mu.print_load_warning = lambda *a, **k: None
+    sys.modules["models.util"] = mu
+    from models.sampling import prepare_modified  # noqa: E402
+    from einops import rearrange  # noqa: E402
+    rows_a = [ptensor((1, 16, 4, 12), 61, q=5), ptensor((1, 16, 6, 8), 62, q=5)]     # two rows, different sizes
+    rows_b = [ptensor((1, 16, 4, 12), 63, q=5), ptensor((1, 16, 2, 8), 64, q=5)]     # shorter second sample -> padded
+    emb = [dict(txt=ptensor((16, 128), 65, q=6), vec=ptensor((64,), 66, q=6))] * 2
+    pk = prepare_modified(t5=None, clip=None, img=[rows_a, rows_b], prompt=["a", "b"], proportion_empty_prompts=0.0,
+                          text_emb=emb)
+    for i, r in enumerate(rows_a + rows_b):
+        out[f"pack_row{i}"] = r.numpy()
+    for k in ("img", "img_ids", "img_mask", "txt_ids", "txt_mask"):
+        out["pack_" + k] = pk[k].float().numpy()
+    # fill-mask packing of the pipeline (einops patterns of visualcloze.py:381-382): pixel mask -> [N, 256]
+    pm = (ptensor((1, 1, 32, 96), 67, q=0, kmax=1).abs() > 0.5).float()
+    m8 = rearrange(pm, "b c (h ph) (w pw) -> b (c ph pw) h w", ph=8, pw=8)
+    out["maskpack_in"] = pm.numpy()
+    out["maskpack_out"] = rearrange(m8, "b c (h ph) (w pw) -> b (h w) (c ph pw)", ph=2, pw=2).numpy()
+    # row-wise unpack of the result (visualcloze.py:425-429)
+    tok = ptensor((1, 24, 64), 68, q=5)
+    out["unpack_in"] = tok.numpy()
+    out["unpack_out"] = rearrange(tok, "b (h w) (c ph pw) -> b c (h ph) (w pw)", ph=2, pw=2, h=2, w=12).numpy()
 
     path = os.path.join(HERE, "tiny_golden.npz")
     np.savez_compressed(path, **out)

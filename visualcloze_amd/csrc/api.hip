@@ -73,6 +73,16 @@ int vc_euler_step(void* x, const void* v, const float* dts, const int32_t* step_
 }
 int vc_step_advance(int32_t* step_ptr, void* stream) { return vc_step_advance_launch(step_ptr, S(stream), ERRBUF); }
 
+int vc_pack_latent(const void* latent, void* tokens, int32_t C, int32_t h, int32_t w, int64_t ld, int32_t col0, void* stream) {
+  return vc_pack_latent_launch(latent, tokens, C, h, w, ld, col0, S(stream), ERRBUF);
+}
+int vc_pack_mask(const void* mask, void* tokens, int32_t H, int32_t W, int64_t ld, int32_t col0, void* stream) {
+  return vc_pack_mask_launch(mask, tokens, H, W, ld, col0, S(stream), ERRBUF);
+}
+int vc_unpack_latent(const void* tokens, int64_t ld, int32_t col0, void* latent, int32_t C, int32_t h, int32_t w, void* stream) {
+  return vc_unpack_latent_launch(tokens, ld, col0, latent, C, h, w, S(stream), ERRBUF);
+}
+
 /* ---- streams / graphs / events ---- */
 int vc_stream_create(void** stream) {
   if (!stream) { snprintf(g_err, sizeof(g_err), "stream_create: null"); return VC_ERR_ARG; }

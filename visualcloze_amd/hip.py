@@ -58,6 +58,9 @@ SYMBOLS = {
     "vc_concat_cols": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i64, _vp]),
     "vc_euler_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
     "vc_step_advance": (C.c_int, [_vp, _vp]),
+    "vc_pack_latent": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _i32, _vp]),
+    "vc_pack_mask": (C.c_int, [_vp, _vp, _i32, _i32, _i64, _i32, _vp]),
+    "vc_unpack_latent": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _i32, _i32, _vp]),
     "vc_stream_create": (C.c_int, [C.POINTER(_vp)]),
     "vc_stream_destroy": (C.c_int, [_vp]),
     "vc_stream_sync": (C.c_int, [_vp]),
@@ -247,6 +250,35 @@ def euler_step(x, v, dts, step_ptr=None, stream=None):
 
 def step_advance(step_ptr, stream=None):
     _check(lib().vc_step_advance(step_ptr.data_ptr(), stream if stream is not None else cur_stream()), "vc_step_advance")
+
+
+def pack_latent(latent, tokens, col0=0, stream=None):
+    """latent [C,h,w] bf16 (contiguous) -> tokens[:, col0:col0+4C] (rows of stride tokens.stride(0))."""
+    _bf16(latent, "latent"); _bf16(tokens, "tokens")
+    Cc, h, w = latent.shape[-3:]
+    if not latent.is_contiguous() or tokens.shape[0] != (h // 2) * (w // 2):
+        raise VclozeHipError("pack_latent: contiguous [C,h,w] latent and (h/2)(w/2) token rows expected")
+    _check(lib().vc_pack_latent(latent.data_ptr(), tokens.data_ptr(), Cc, h, w, tokens.stride(0), col0,
+                                stream if stream is not None else cur_stream()), "vc_pack_latent")
+
+
+def pack_mask(mask, tokens, col0=0, stream=None):
+    """pixel mask [H,W] bf16 -> tokens[:, col0:col0+256]."""
+    _bf16(mask, "mask"); _bf16(tokens, "tokens")
+    H, W = mask.shape[-2:]
+    if not mask.is_contiguous() or tokens.shape[0] != (H // 16) * (W // 16):
+        raise VclozeHipError("pack_mask: contiguous [H,W] mask and (H/16)(W/16) token rows expected")
+    _check(lib().vc_pack_mask(mask.data_ptr(), tokens.data_ptr(), H, W, tokens.stride(0), col0,
+                              stream if stream is not None else cur_stream()), "vc_pack_mask")
+
+
+def unpack_latent(tokens, latent, col0=0, stream=None):
+    _bf16(latent, "latent"); _bf16(tokens, "tokens")
+    Cc, h, w = latent.shape[-3:]
+    if not latent.is_contiguous() or tokens.shape[0] != (h // 2) * (w // 2):
+        raise VclozeHipError("unpack_latent: contiguous [C,h,w] latent and (h/2)(w/2) token rows expected")
+    _check(lib().vc_unpack_latent(tokens.data_ptr(), tokens.stride(0), col0, latent.data_ptr(), Cc, h, w,
+                                  stream if stream is not None else cur_stream()), "vc_unpack_latent")
 
 
 class Graph:

@@ -101,6 +101,8 @@ int vc_concat_cols(const void* x, int32_t cx, const void* cond, int32_t cc, void
  * torch casts the 0-dim f32 dt to the bf16 common dtype before the multiply, transport/integrators.py:119). */
 int vc_euler_step(void* x, const void* v, const float* dts, const int32_t* step_ptr, int64_t n, void* stream);
 int vc_step_advance(int32_t* step_ptr, void* stream);
+/* SDEdit start state x0 = noise*(1-s) + latent*s with the reference's bf16 roundings (visualcloze.py:221) */
+int vc_sdedit_mix(const void* noise, const void* latent, float strength, void* out, int64_t n, void* stream);
 
 /* ---- latent-grid packer / unpacker (the steps either side of the loop) ----
  * pack:   latent [C,h,w] bf16 -> tokens[(h/2)(w/2)][col0 .. col0+4C) of rows with stride ld

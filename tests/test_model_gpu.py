@@ -151,3 +151,49 @@ def test_fused_equals_eager_stepping(model):
     fused = fn(inp["x"].to("cuda", torch.bfloat16), m.forward, kw)
     eager = fn(inp["x"].to("cuda", torch.bfloat16), lambda x, **k: m.forward(x, **k), kw)
     assert rel_l2(fused[-1], eager[-1]) < 1e-2
+
+
+def test_latent_pipeline_grid_and_sdedit_vs_oracle(model):
+    """denoise_grid + sdedit_upsample against the oracle doing the same steps in bf16."""
+    import oracle.flux_oracle as O
+    from tests.procedural import TINY, ptensor
+    from visualcloze_amd import pipeline
+    m, sd = model
+    G = O.FluxGeometry(**TINY)
+    P = O.Prec("bf16", "merged")
+    rows_hw = [(4, 12), (4, 12)]
+    noise = [ptensor((1, 16, h, w), 80 + i, q=6) for i, (h, w) in enumerate(rows_hw)]
+    clat = [ptensor((1, 16, h, w), 90 + i, q=6) for i, (h, w) in enumerate(rows_hw)]
+    masks = [torch.zeros(1, 1, 32, 96), torch.cat((torch.zeros(1, 1, 32, 64), torch.ones(1, 1, 32, 32)), -1)]
+    txt, vec = ptensor((1, 16, TINY["context_in_dim"]), 99, q=6), ptensor((1, TINY["vec_in_dim"]), 98, q=6)
+    c = lambda t: t.to("cuda", torch.bfloat16)  # noqa: E731
+    got = pipeline.denoise_grid(m, [c(t) for t in noise], [c(t) for t in clat], [c(t) for t in masks], c(txt), c(vec),
+                                cfg=30.0, steps=4)
+    torch.cuda.synchronize()
+    # oracle: same packing, same grid, bf16 rounding points, guidance in bf16 (as the pipeline creates it)
+    img, ids, msk = O.prepare_grid([noise])
+    cond = torch.cat([torch.cat([O.pack_latent(l[0]) for l in clat]), torch.cat([O.pack_mask(mm[0, 0]) for mm in masks])], -1)[None]
+
+    def model_fn(xin, tm):
+        return O.flux_forward(sd, G, xin, ids, txt, torch.zeros(1, 16, 3), tm, vec, torch.ones(1, 16, dtype=torch.int32), msk,
+                              torch.full((1,), 30.0), P=P)
+    states, _ = O.sample_euler(model_fn, img, cond, O.time_grid(4, img.shape[1], True, 1), P)
+    want = [O.unpack_latent(states[-1][0, :24], 4, 12), O.unpack_latent(states[-1][0, 24:], 4, 12)]
+    for g_, w_ in zip(got, want):
+        assert g_.shape == (1, 16, 4, 12)
+        assert rel_l2(g_[0], w_) < 3e-2          # 3 evaluations, bf16 noise
+    # SDEdit
+    up = pipeline.sdedit_upsample(m, c(noise[0]), c(clat[0]), c(torch.zeros(1, 16, 4, 12)), c(txt), c(vec), cfg=30.0,
+                                  steps=4, strength=0.4)
+    torch.cuda.synchronize()
+    n_tok, l_tok = O.pack_latent(noise[0][0]), O.pack_latent(clat[0][0])
+    x0 = P.r(P.r(n_tok * (1 - 0.4)) + P.r(l_tok * 0.4))[None]
+    cond2 = torch.cat([O.pack_latent(torch.zeros(16, 4, 12)), torch.ones(12, 256)], -1)[None]
+    ids2 = O.grid_img_ids([(4, 12)])[None]
+
+    def model_fn2(xin, tm):
+        return O.flux_forward(sd, G, xin, ids2, txt, torch.zeros(1, 16, 3), tm, vec, torch.ones(1, 16, dtype=torch.int32),
+                              torch.ones(1, 12, dtype=torch.int32), torch.full((1,), 30.0), P=P)
+    st2, ev = O.sample_euler(model_fn2, x0, cond2, O.time_grid(4, 12, False, 1.0, strength=0.4), P)
+    assert len(ev) == 3 and abs(ev[0] - 0.6) < 1e-6
+    assert rel_l2(up[0], O.unpack_latent(st2[-1][0], 4, 12)) < 3e-2

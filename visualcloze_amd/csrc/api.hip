@@ -73,6 +73,9 @@ int vc_euler_step(void* x, const void* v, const float* dts, const int32_t* step_
 }
 int vc_step_advance(int32_t* step_ptr, void* stream) { return vc_step_advance_launch(step_ptr, S(stream), ERRBUF); }
 
+int vc_sdedit_mix(const void* noise, const void* latent, float strength, void* out, int64_t n, void* stream) {
+  return vc_sdedit_mix_launch(noise, latent, strength, out, n, S(stream), ERRBUF);
+}
 int vc_pack_latent(const void* latent, void* tokens, int32_t C, int32_t h, int32_t w, int64_t ld, int32_t col0, void* stream) {
   return vc_pack_latent_launch(latent, tokens, C, h, w, ld, col0, S(stream), ERRBUF);
 }

@@ -55,6 +55,14 @@ __global__ void euler_kernel(bf16_t* __restrict__ x, const bf16_t* __restrict__ 
   x[i] = f2bf(bf2f(x[i]) + dy);
 }
 
+// SDEdit start state (visualcloze.py:221): x0 = bf16(bf16(noise*(1-s)) + bf16(latent*s)), s a python float
+__global__ void sdedit_mix_kernel(const bf16_t* __restrict__ noise, const bf16_t* __restrict__ latent, float s,
+                                  bf16_t* __restrict__ out, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = f2bf(rbf(bf2f(noise[i]) * (1.0f - s)) + rbf(bf2f(latent[i]) * s));
+}
+
 __global__ void step_advance_kernel(int* step_ptr) { if (threadIdx.x == 0 && blockIdx.x == 0) *step_ptr += 1; }
 
 }  // namespace
@@ -96,4 +104,9 @@ int vc_step_advance_launch(int32_t* step_ptr, hipStream_t s, char* err, int errl
   if (!step_ptr) { snprintf(err, errlen, "step_advance: null"); return VC_ERR_ARG; }
   hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, s, step_ptr);
   VC_CHECK_LAUNCH("step_advance");
+}
+int vc_sdedit_mix_launch(const void* noise, const void* latent, float strength, void* out, int64_t n, hipStream_t s, char* err, int errlen) {
+  if (!noise || !latent || !out || n <= 0) { snprintf(err, errlen, "sdedit_mix: bad args"); return VC_ERR_ARG; }
+  hipLaunchKernelGGL(sdedit_mix_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16_t*)noise, (const bf16_t*)latent, strength, (bf16_t*)out, (long)n);
+  VC_CHECK_LAUNCH("sdedit_mix");
 }

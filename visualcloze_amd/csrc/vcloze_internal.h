@@ -23,3 +23,4 @@ int vc_step_advance_launch(int32_t* step_ptr, hipStream_t s, char* err, int errl
 int vc_pack_latent_launch(const void* in, void* out, int C, int h, int w, int64_t ld, int col0, hipStream_t s, char* err, int errlen);
 int vc_pack_mask_launch(const void* in, void* out, int H, int W, int64_t ld, int col0, hipStream_t s, char* err, int errlen);
 int vc_unpack_latent_launch(const void* in, int64_t ld, int col0, void* out, int C, int h, int w, hipStream_t s, char* err, int errlen);
+int vc_sdedit_mix_launch(const void* noise, const void* latent, float strength, void* out, int64_t n, hipStream_t s, char* err, int errlen);

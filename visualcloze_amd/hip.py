@@ -58,6 +58,7 @@ SYMBOLS = {
     "vc_concat_cols": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i64, _vp]),
     "vc_euler_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
     "vc_step_advance": (C.c_int, [_vp, _vp]),
+    "vc_sdedit_mix": (C.c_int, [_vp, _vp, C.c_float, _vp, _i64, _vp]),
     "vc_pack_latent": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _i32, _vp]),
     "vc_pack_mask": (C.c_int, [_vp, _vp, _i32, _i32, _i64, _i32, _vp]),
     "vc_unpack_latent": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _i32, _i32, _vp]),
@@ -250,6 +251,14 @@ def euler_step(x, v, dts, step_ptr=None, stream=None):
 
 def step_advance(step_ptr, stream=None):
     _check(lib().vc_step_advance(step_ptr.data_ptr(), stream if stream is not None else cur_stream()), "vc_step_advance")
+
+
+def sdedit_mix(noise, latent, strength, out=None, stream=None):
+    _bf16(noise, "noise"); _bf16(latent, "latent")
+    out = torch.empty_like(noise) if out is None else out
+    _check(lib().vc_sdedit_mix(noise.data_ptr(), latent.data_ptr(), float(strength), out.data_ptr(), noise.numel(),
+                               stream if stream is not None else cur_stream()), "vc_sdedit_mix")
+    return out
 
 
 def pack_latent(latent, tokens, col0=0, stream=None):

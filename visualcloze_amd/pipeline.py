@@ -1,0 +1,58 @@
+"""Latent-space part of `VisualClozeModel.process_images` / `.upsampling` (visualcloze.py:147-245, 363-434) on the
+MI355X path: everything between the VAE / text encoders and the VAE decoder.  VAE and T5/CLIP stay with the caller
+(out of scope), so inputs are row latents, pixel fill masks and text embeddings.
+
+    rows = denoise_grid(model, noise_rows, cond_latent_rows, mask_rows, txt, vec, cfg=30, steps=30)
+    up   = sdedit_upsample(model, noise, latent, blank_latent, txt, vec, cfg=30, steps=10, strength=0.4)
+"""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+import torch
+
+from . import hip, packing
+from .transport import Sampler, create_transport
+
+
+def _kwargs(inp_ids, inp_mask, txt, vec, cond, cfg, dev):
+    B, T = txt.shape[0], txt.shape[1]
+    return dict(txt=txt, txt_ids=torch.zeros(B, T, 3, device=dev), txt_mask=torch.ones(B, T, dtype=torch.int32, device=dev),
+                y=vec, img_ids=inp_ids, img_mask=inp_mask, cond=cond,
+                guidance=torch.full((B,), cfg, device=dev, dtype=torch.bfloat16))   # visualcloze.py:413
+
+
+@torch.no_grad()
+def denoise_grid(model, noise_rows: List[torch.Tensor], cond_latent_rows: List[torch.Tensor],
+                 mask_rows: List[torch.Tensor], txt: torch.Tensor, vec: torch.Tensor, cfg: float = 30.0,
+                 steps: int = 30, solver: str = "euler", time_shifting_factor=1) -> List[torch.Tensor]:
+    """One grid: per-row noise [1,16,h,w], VAE latents of the grid rows (already shifted/scaled), per-row PIXEL
+    fill masks [1,1,8h,8w]; txt [1,T,4096], vec [1,768].  Returns the denoised row latents [1,16,h,w]."""
+    dev = noise_rows[0].device
+    img, img_ids, img_mask = packing.prepare_grid([noise_rows])                       # visualcloze.py:403
+    cond = packing.pack_cond(cond_latent_rows, mask_rows)                              # :381-389
+    fn = Sampler(create_transport("Linear", "velocity", do_shift=True)).sample_ode(
+        sampling_method=solver, num_steps=steps, atol=1e-6, rtol=1e-3, reverse=False, do_shift=True,
+        time_shifting_factor=time_shifting_factor)                                     # :284-292
+    samples = fn(img, model.forward, _kwargs(img_ids, img_mask, txt, vec, cond, cfg, dev))[-1][:1]   # :415-420
+    return packing.unpack_rows(samples, [tuple(r.shape[-2:]) for r in noise_rows])     # :425-429
+
+
+@torch.no_grad()
+def sdedit_upsample(model, noise: torch.Tensor, latent: torch.Tensor, blank_latent: torch.Tensor, txt: torch.Tensor,
+                    vec: torch.Tensor, cfg: float = 30.0, steps: int = 10, strength: float = 0.4,
+                    solver: str = "euler") -> torch.Tensor:
+    """SDEdit refinement of one image (visualcloze.py:184-237): start from noise*(1-s) + latent*s, everything masked,
+    un-shifted grid from t0 = strength.  noise/latent/blank_latent: [1,16,h,w]; returns [1,16,h,w]."""
+    dev = latent.device
+    h, w = latent.shape[-2:]
+    img, img_ids, img_mask = packing.prepare_grid([[noise]])
+    lat_tok, _, _ = packing.prepare_grid([[latent]])
+    x0 = hip.sdedit_mix(img, lat_tok, strength)                                        # :221
+    ones = torch.ones(1, 1, 8 * h, 8 * w, dtype=torch.bfloat16, device=dev)            # mask = 1 everywhere, :198
+    cond = packing.pack_cond([blank_latent], [ones])                                   # :214
+    fn = Sampler(create_transport("Linear", "velocity", do_shift=True)).sample_ode(
+        sampling_method=solver, num_steps=steps, atol=1e-6, rtol=1e-3, reverse=False, do_shift=False,
+        time_shifting_factor=1.0, strength=strength)                                   # :184-193
+    sample = fn(x0, model.forward, _kwargs(img_ids, img_mask, txt, vec, cond, cfg, dev))[-1][:1]
+    return packing.unpack_rows(sample, [(h, w)])[0]

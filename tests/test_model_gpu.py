@@ -178,7 +178,7 @@ def test_latent_pipeline_grid_and_sdedit_vs_oracle(model):
         return O.flux_forward(sd, G, xin, ids, txt, torch.zeros(1, 16, 3), tm, vec, torch.ones(1, 16, dtype=torch.int32), msk,
                               torch.full((1,), 30.0), P=P)
     states, _ = O.sample_euler(model_fn, img, cond, O.time_grid(4, img.shape[1], True, 1), P)
-    want = [O.unpack_latent(states[-1][0, :24], 4, 12), O.unpack_latent(states[-1][0, 24:], 4, 12)]
+    want = [O.unpack_latent(states[-1][0, :12], 4, 12), O.unpack_latent(states[-1][0, 12:], 4, 12)]
     for g_, w_ in zip(got, want):
         assert g_.shape == (1, 16, 4, 12)
         assert rel_l2(g_[0], w_) < 3e-2          # 3 evaluations, bf16 noise

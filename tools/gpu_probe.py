@@ -216,7 +216,7 @@ def main():
         probe_gemm(37, 64, 256, 2, cfg, lda_pad=64)
         probe_gemm(513, 264, 384, 1, cfg)
         probe_gemm_grouped(cfg)
-    if "--gemm-only" in sys.argv:
+    if "--gemm-only" in sys.argv or "--attn-only" in sys.argv:
         return perf()
     probe_ln(10, 256); probe_ln(1000, 3072); probe_ln(7, 4096)
     probe_elementwise()
@@ -232,7 +232,7 @@ def main():
 
 def perf():
     if "--perf" in sys.argv:
-        for cfg in (0, 20, 19):
+        for cfg in (() if "--attn-only" in sys.argv else (0, 20, 19)):
             for pa, pw in ((0, 0),):
                 probe_gemm(3968, 9216, 3072, 0, cfg, time_it=True, lda_pad=pa, ldw_pad=pw)
             probe_gemm(3968, 3072, 3072, 2, cfg, time_it=True)

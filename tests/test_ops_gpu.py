@@ -31,7 +31,7 @@ def hip():
     return h
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 19, 20])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 19, 20, 21])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
 @pytest.mark.parametrize("shape", [(128, 128, 64), (200, 192, 128), (37, 64, 256), (513, 264, 384), (1, 512, 256)])
 def test_gemm(hip, cfg, epi, shape):
@@ -57,7 +57,7 @@ def test_gemm_transpose_detecting(hip):
     assert torch.equal(out.float(), w.float().t())
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
 def test_gemm_grouped_and_inplace_residual(hip, cfg):
     M1, M2, N, K = 300, 136, 384, 256
     a1, a2 = rnd(M1, K, seed=1), rnd(M2, K, seed=2)

@@ -209,7 +209,7 @@ def probe_graph():
 def main():
     print("device:", torch.cuda.get_device_name(0), "lib:", hip.LIB_PATH)
     hip.require_gpu()
-    for cfg in (1, 2, 3, 4, 19, 20):
+    for cfg in (1, 2, 3, 4, 5, 19, 20, 21):
         for epi in (0, 1, 2, 3):
             probe_gemm(128, 128, 64, epi, cfg)
         probe_gemm(200, 192, 128, 0, cfg)
@@ -232,7 +232,7 @@ def main():
 
 def perf():
     if "--perf" in sys.argv:
-        for cfg in (() if "--attn-only" in sys.argv else (0, 20, 19)):
+        for cfg in (() if "--attn-only" in sys.argv else (0, 20, 5, 19)):
             for pa, pw in ((0, 0),):
                 probe_gemm(3968, 9216, 3072, 0, cfg, time_it=True, lda_pad=pa, ldw_pad=pw)
             probe_gemm(3968, 3072, 3072, 2, cfg, time_it=True)

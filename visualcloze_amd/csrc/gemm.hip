@@ -28,8 +28,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const VcGemmArgs
   constexpr int MI = TM / 16, NI = TN / 16;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
   constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
-  constexpr int A_IT = BM * 8 / NT, B_IT = BN * 8 / NT;
-  static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "staging split");
+  constexpr int A_CH = BM * 8, B_CH = BN * 8;                       // 16-B chunks per operand tile
+  constexpr int A_IT = (A_CH + NT - 1) / NT, B_IT = (B_CH + NT - 1) / NT;
+  static_assert(A_CH % 64 == 0 && B_CH % 64 == 0, "a wave-instruction (64 chunks) must not straddle the tile end");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
@@ -76,9 +77,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const VcGemmArgs
     char* sa = smem + buf * STAGE_BYTES;
     char* sb = sa + A_BYTES;
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) glds16(Ab + a_off[i] + k0, sa + (i * NT + wave * 64) * 16);
+    for (int i = 0; i < A_IT; ++i)
+      if (A_CH % NT == 0 || i * NT + wave * 64 < A_CH) glds16(Ab + a_off[i] + k0, sa + (i * NT + wave * 64) * 16);
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i) glds16(Wb + b_off[i] + k0, sb + (i * NT + wave * 64) * 16);
+    for (int i = 0; i < B_IT; ++i)   // 256x288: the last sweep covers half a tile's worth -> waves 0-3 only (wave-uniform)
+      if (B_CH % NT == 0 || i * NT + wave * 64 < B_CH) glds16(Wb + b_off[i] + k0, sb + (i * NT + wave * 64) * 16);
   };
 
   // ---- fragment read offsets ----
@@ -269,7 +272,7 @@ hipError_t launch_cfg(const VcGemmArgs& a, int total_tiles, hipStream_t s) {
 
 }  // namespace
 
-// tile_cfg: 0 = auto, 1 = 128x128 (4 waves), 2 = 256x128, 3 = 256x256, 4 = 256x192 (8 waves each)
+// tile_cfg: 0 = auto, 1 = 128x128 (4 waves), 2 = 256x128, 3 = 256x256, 4 = 256x192, 5 = 256x288 (8 waves each)
 int vc_gemm_launch(VcGemmArgs a, int tile_cfg, hipStream_t s, char* err, int errlen) {
   if (a.nprob < 1 || a.nprob > 2) { snprintf(err, errlen, "gemm: nprob must be 1 or 2"); return VC_ERR_ARG; }
   for (int i = 0; i < a.nprob; ++i) {
@@ -286,17 +289,18 @@ int vc_gemm_launch(VcGemmArgs a, int tile_cfg, hipStream_t s, char* err, int err
   // +16 selects the ping-pong main loop (8-wave tiles 256x256 / 256x192); auto picks it for those tiles
   int pp = (tile_cfg >> 4) & 7;
   tile_cfg &= 15;
-  static const int cfg_bm[5] = {0, 128, 256, 256, 256}, cfg_bn[5] = {0, 128, 128, 256, 192};
+  static const int cfg_bm[6] = {0, 128, 256, 256, 256, 256}, cfg_bn[6] = {0, 128, 128, 256, 192, 288};
   if (tile_cfg == 0) {
     // Cost model fitted on MI355X (M=3968 FLUX shapes): time = block-rounds on 256 CUs x (tile area x (K + fixed
     // prologue/epilogue charge) / streaming efficiency of that tile).  Candidates: 128x128 simple loop (2 blocks
-    // per CU; small or skinny problems), 256x256 and 256x192 ping-pong (1 block per CU).  256x192 makes the tile
-    // count a multiple of 256 for M<=4096 and every FLUX N (3072/9216/12288/21504).
-    static const int cand[3] = {1, 3, 4};
-    static const int cand_pp[3] = {0, 1, 1};
-    static const double eff[3] = {0.55, 1.0, 0.785}, ovh[3] = {500.0, 650.0, 350.0};
+    // per CU; small or skinny problems), 256x256 / 256x192 ping-pong and 256x288 (1 block per CU).  For M <= 4096:
+    // 256x192 gives N=3072 exactly one round (256 tiles), 256x288 gives N=9216 exactly two (512), 256x256 gives
+    // N=12288 exactly three (768).
+    static const int cand[4] = {1, 3, 4, 5};
+    static const int cand_pp[4] = {0, 1, 1, 0};     // 256x288 runs the simple loop: its ping-pong form spills VGPRs
+    static const double eff[4] = {0.55, 1.0, 0.785, 0.88}, ovh[4] = {500.0, 650.0, 350.0, 490.0};
     double best = 1e300;
-    for (int ci = 0; ci < 3; ++ci) {
+    for (int ci = 0; ci < 4; ++ci) {
       const int c = cand[ci];
       long tiles = 0;
       for (int i = 0; i < a.nprob; ++i)
@@ -307,7 +311,7 @@ int vc_gemm_launch(VcGemmArgs a, int tile_cfg, hipStream_t s, char* err, int err
       if (t < best) { best = t; tile_cfg = c; pp = cand_pp[ci]; }
     }
   }
-  if (tile_cfg < 1 || tile_cfg > 4 || pp > 1 || (pp && tile_cfg < 3)) { snprintf(err, errlen, "gemm: bad tile_cfg %d", tile_cfg); return VC_ERR_ARG; }
+  if (tile_cfg < 1 || tile_cfg > 5 || pp > 1 || (pp && tile_cfg < 3)) { snprintf(err, errlen, "gemm: bad tile_cfg %d", tile_cfg); return VC_ERR_ARG; }
   const int bm = cfg_bm[tile_cfg], bn = cfg_bn[tile_cfg];
   int total = 0;
   for (int i = 0; i < a.nprob; ++i) {
@@ -321,7 +325,8 @@ int vc_gemm_launch(VcGemmArgs a, int tile_cfg, hipStream_t s, char* err, int err
     case 1: e = launch_cfg<128, 128, 2, 2, 0>(a, total, s); break;
     case 2: e = launch_cfg<256, 128, 4, 2, 0>(a, total, s); break;
     case 3: e = pp ? launch_cfg<256, 256, 2, 4, 1>(a, total, s) : launch_cfg<256, 256, 2, 4, 0>(a, total, s); break;
-    default: e = pp ? launch_cfg<256, 192, 4, 2, 1>(a, total, s) : launch_cfg<256, 192, 4, 2, 0>(a, total, s); break;
+    case 4: e = pp ? launch_cfg<256, 192, 4, 2, 1>(a, total, s) : launch_cfg<256, 192, 4, 2, 0>(a, total, s); break;
+    default: e = pp ? launch_cfg<256, 288, 4, 2, 1>(a, total, s) : launch_cfg<256, 288, 4, 2, 0>(a, total, s); break;
   }
   if (e != hipSuccess) { snprintf(err, errlen, "gemm launch: %s", hipGetErrorString(e)); return VC_ERR_HIP; }
   return VC_OK;

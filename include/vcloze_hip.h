@@ -42,15 +42,21 @@ typedef struct VcGemmProblem {
   const void* res;  /* GATE_RES: residual [M,N] bf16 (may alias C), row stride ldres */
   const void* gate; /* GATE_RES: gate vector(s) bf16; row b of batch uses gate + b*gate_bstride */
   int64_t lda, ldw, ldc, ldres, gate_bstride;
+  /* batch-strided rows (samples of a per-GPU batch interleave text and image rows): with a_rpb > 0 row m of A lives at
+   * (m / a_rpb) * a_bstride + (m % a_rpb) * lda; likewise C and res with c_rpb / c_bstride (res must share C's layout).
+   * 0 = plain rows at m * ld. */
+  int64_t a_bstride, c_bstride;
   int32_t M, N, K;
   int32_t rows_per_batch; /* GATE_RES: batch index of row m is m / rows_per_batch */
+  int32_t a_rpb, c_rpb;
   int32_t tiles_m, tiles_n, tile_start; /* filled by the launcher */
   int32_t _pad;
 } VcGemmProblem;
 
+#define VC_GEMM_MAX_PROBLEMS 4
 typedef struct VcGemmArgs {
-  VcGemmProblem p[2];
-  int32_t nprob; /* 1 or 2 problems in one grid (img+txt streams) */
+  VcGemmProblem p[VC_GEMM_MAX_PROBLEMS];
+  int32_t nprob; /* 1..4 problems in one grid (img+txt streams of up to two samples) */
   int32_t epi;
   const int32_t* step_ptr;  /* optional device step counter: gate += *step_ptr * gate_step_stride */
   int64_t gate_step_stride;

@@ -24,8 +24,8 @@ def test_abi_exports_every_declared_symbol():
 
 def test_struct_layout_matches_header():
     from visualcloze_amd import hip
-    assert ctypes.sizeof(hip.GemmProblem) == 6 * 8 + 5 * 8 + 8 * 4
-    assert ctypes.sizeof(hip.GemmArgs) == 2 * ctypes.sizeof(hip.GemmProblem) + 8 + 8 + 8 + 8
+    assert ctypes.sizeof(hip.GemmProblem) == 6 * 8 + 7 * 8 + 10 * 4
+    assert ctypes.sizeof(hip.GemmArgs) == 4 * ctypes.sizeof(hip.GemmProblem) + 8 + 8 + 8 + 8
 
 
 def test_no_gpu_fails_loudly():

@@ -74,6 +74,45 @@ def test_gemm_grouped_and_inplace_residual(hip, cfg):
     check(x, ref)
 
 
+def test_gemm_four_problems_batch_strided_rows(hip):
+    """Per-GPU batch of 2: img/txt streams of both samples in one grid; QKV-style output rows land batch-strided in a
+    joint [B*L, N] buffer and proj-style A rows are read batch-strided out of it (engine.py double blocks)."""
+    B, Nn, T, D, NO = 2, 136, 40, 128, 192
+    L = Nn + T
+    xi, xt = rnd(B * Nn, D, seed=1), rnd(B * T, D, seed=2)
+    wi, wt = rnd(NO, D, scale=D ** -0.5, seed=3), rnd(NO, D, scale=D ** -0.5, seed=4)
+    bi, bt = rnd(NO, seed=5), rnd(NO, seed=6)
+    joint = torch.full((B * L, NO), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ld = joint.stride(0)
+    pi = hip.make_problem(xi, wi, bi, joint[T:], M=B * Nn, c_rpb=Nn, c_bstride=L * ld)
+    pt = hip.make_problem(xt, wt, bt, joint[:T], M=B * T, c_rpb=T, c_bstride=L * ld)
+    hip.gemm([pi, pt], epi=0)
+    torch.cuda.synchronize()
+    ri, rt = R.gemm_ref(xi, wi, bi, 0), R.gemm_ref(xt, wt, bt, 0)
+    ref = torch.cat([torch.cat([rt[b * T:(b + 1) * T], ri[b * Nn:(b + 1) * Nn]]) for b in range(B)])
+    check(joint, ref)
+    # read the joint rows back batch-strided as A operands, 4 problems (2 samples x 2 streams), gated residual
+    w2 = rnd(D, NO, scale=NO ** -0.5, seed=7)
+    b2, gates = rnd(D, seed=8), rnd(B, D, seed=9)
+    oi, ot = rnd(B * Nn, D, seed=10), rnd(B * T, D, seed=11)
+    oi0, ot0 = oi.clone(), ot.clone()
+    ps = [hip.make_problem(joint[T:], w2, b2, oi, res=oi, gate=gates, rows_per_batch=Nn, gate_bstride=D, M=B * Nn, a_rpb=Nn, a_bstride=L * ld),
+          hip.make_problem(joint[:T], w2, b2, ot, res=ot, gate=gates, rows_per_batch=T, gate_bstride=D, M=B * T, a_rpb=T, a_bstride=L * ld)]
+    # the same two problems again as separate per-sample problems -> 4 in one launch must give the same result
+    oi2, ot2 = oi0.clone(), ot0.clone()
+    ps4 = []
+    for b in range(B):
+        ps4.append(hip.make_problem(joint[b * L + T:(b + 1) * L], w2, b2, oi2[b * Nn:(b + 1) * Nn], res=oi2[b * Nn:(b + 1) * Nn], gate=gates[b]))
+        ps4.append(hip.make_problem(joint[b * L:b * L + T], w2, b2, ot2[b * T:(b + 1) * T], res=ot2[b * T:(b + 1) * T], gate=gates[b]))
+    hip.gemm(ps, epi=hip.EPI_GATE_RES)
+    hip.gemm(ps4, epi=hip.EPI_GATE_RES)
+    torch.cuda.synchronize()
+    for b in range(B):
+        check(oi[b * Nn:(b + 1) * Nn], R.gemm_ref(ref[b * L + T:(b + 1) * L].to(torch.bfloat16), w2, b2, 2, oi0[b * Nn:(b + 1) * Nn], gates[b]))
+        check(ot[b * T:(b + 1) * T], R.gemm_ref(ref[b * L:b * L + T].to(torch.bfloat16), w2, b2, 2, ot0[b * T:(b + 1) * T], gates[b]))
+    assert torch.equal(oi, oi2) and torch.equal(ot, ot2)
+
+
 def test_gemm_rejects_bad_arguments(hip):
     a, w = rnd(8, 100), rnd(16, 100)
     with pytest.raises(hip.VclozeHipError):          # K not a multiple of 64

@@ -20,8 +20,7 @@ def main():
     ws = eng.workspace(T, N, 1)
     bf = lambda t: t.to(dev, torch.bfloat16).contiguous()  # noqa: E731
     t = torch.tensor([0.7])
-    eng.prepare_sample(ws, bf(inp["txt"][0]), bf(inp["y"][0]), inp["guidance"], False, inp["img_ids"][0],
-                       inp["txt_ids"][0], t, T + N)
+    eng.prepare_sample(ws, bf(inp["txt"]), bf(inp["y"]), inp["guidance"], False, inp["img_ids"], inp["txt_ids"], t, [T + N])
     ws.XIN.copy_(bf(torch.cat((inp["x"], inp["cond"]), -1)[0]))
     taps = {}
     eng.eval_once(ws, None, euler=False, concat=False, taps=taps)

@@ -40,8 +40,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const VcGemmArgs
 
   // ---- which tile ----
   int id = xcd_remap(blockIdx.x, gridDim.x);
-  const int pi = (args.nprob > 1 && id >= args.p[1].tile_start) ? 1 : 0;
-  const VcGemmProblem P = pi ? args.p[1] : args.p[0];
+  int pi = 0;
+#pragma unroll
+  for (int q = 1; q < VC_GEMM_MAX_PROBLEMS; ++q)
+    if (q < args.nprob && id >= args.p[q].tile_start) pi = q;
+  const VcGemmProblem P = pi == 3 ? args.p[3] : pi == 2 ? args.p[2] : pi == 1 ? args.p[1] : args.p[0];
   id -= P.tile_start;
   constexpr int GROUP_M = 8;
   const int in_group = GROUP_M * P.tiles_n;
@@ -63,7 +66,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const VcGemmArgs
     const int c = i * NT + tid;
     const int row = c >> 3, slot = (c & 7) ^ (row & 7);
     const int grow = min(m0 + row, M - 1);
-    a_off[i] = (uint32_t)grow * (uint32_t)P.lda + slot * 8;
+    a_off[i] = (P.a_rpb > 0 ? (uint32_t)(grow / P.a_rpb) * (uint32_t)P.a_bstride + (uint32_t)(grow % P.a_rpb) * (uint32_t)P.lda
+                            : (uint32_t)grow * (uint32_t)P.lda) + slot * 8;
   }
 #pragma unroll
   for (int i = 0; i < B_IT; ++i) {
@@ -225,6 +229,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const VcGemmArgs
     const int row = c / CPR, cc = c % CPR;
     const int m = m0 + row, n = n0 + cc * 8;
     if (m >= M || n >= N) continue;
+    const long crow = P.c_rpb > 0 ? (long)(m / P.c_rpb) * P.c_bstride + (long)(m % P.c_rpb) * P.ldc : (long)m * P.ldc;
     const u32x4 tw = *(const u32x4*)(smem + row * EP_LD + cc * 16);
     float v[8];
 #pragma unroll
@@ -238,12 +243,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const VcGemmArgs
       for (int e = 0; e < 4; ++e) o[e] = pack2bf(silu_f(v[2 * e]), silu_f(v[2 * e + 1]));
     } else if (EPI == VC_EPI_GATE_RES) {
       const u32x4 gg = *(const u32x4*)(gate + gate_step + (long)(m / P.rows_per_batch) * P.gate_bstride + n);
-      const u32x4 rr = *(const u32x4*)(res + (long)m * P.ldres + n);
+      const u32x4 rr = *(const u32x4*)(res + (P.c_rpb > 0 ? crow : (long)m * P.ldres) + n);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         o[e] = pack2bf(lo_bf(rr[e]) + rbf(lo_bf(gg[e]) * v[2 * e]), hi_bf(rr[e]) + rbf(hi_bf(gg[e]) * v[2 * e + 1]));
     }
-    *(u32x4*)(C + (long)m * P.ldc + n) = o;
+    *(u32x4*)(C + crow + n) = o;
   }
 }
 
@@ -274,14 +279,17 @@ hipError_t launch_cfg(const VcGemmArgs& a, int total_tiles, hipStream_t s) {
 
 // tile_cfg: 0 = auto, 1 = 128x128 (4 waves), 2 = 256x128, 3 = 256x256, 4 = 256x192, 5 = 256x288 (8 waves each)
 int vc_gemm_launch(VcGemmArgs a, int tile_cfg, hipStream_t s, char* err, int errlen) {
-  if (a.nprob < 1 || a.nprob > 2) { snprintf(err, errlen, "gemm: nprob must be 1 or 2"); return VC_ERR_ARG; }
+  if (a.nprob < 1 || a.nprob > VC_GEMM_MAX_PROBLEMS) { snprintf(err, errlen, "gemm: nprob must be 1..%d", VC_GEMM_MAX_PROBLEMS); return VC_ERR_ARG; }
   for (int i = 0; i < a.nprob; ++i) {
     const VcGemmProblem& p = a.p[i];
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) { snprintf(err, errlen, "gemm: empty problem %d (M=%d N=%d K=%d)", i, p.M, p.N, p.K); return VC_ERR_ARG; }
     if (p.K % BK) { snprintf(err, errlen, "gemm: K=%d must be a multiple of %d", p.K, BK); return VC_ERR_ARG; }
     if (p.N % 8 || p.ldc % 8 || p.lda % 8) { snprintf(err, errlen, "gemm: need N, ldc, lda multiples of 8 (N=%d ldc=%ld lda=%ld)", p.N, (long)p.ldc, (long)p.lda); return VC_ERR_ARG; }
     if (!p.A || !p.W || !p.C) { snprintf(err, errlen, "gemm: null operand"); return VC_ERR_ARG; }
-    if ((uint64_t)p.M * (uint64_t)p.lda >= (1ull << 32) || (uint64_t)p.N * (uint64_t)p.ldw >= (1ull << 32) || p.ldw < p.K || p.ldw % 8) {
+    if (p.a_rpb < 0 || p.c_rpb < 0 || p.a_bstride % 8 || p.c_bstride % 8 || (p.c_rpb > 0 && p.res && p.ldres != p.ldc)) {
+      snprintf(err, errlen, "gemm: bad batch-strided row description"); return VC_ERR_ARG; }
+    if ((p.a_rpb > 0 ? (uint64_t)((p.M + p.a_rpb - 1) / p.a_rpb) * (uint64_t)p.a_bstride : 0) >= (1ull << 32) ||
+        (uint64_t)(p.a_rpb > 0 ? p.a_rpb : p.M) * (uint64_t)p.lda >= (1ull << 32) || (uint64_t)p.N * (uint64_t)p.ldw >= (1ull << 32) || p.ldw < p.K || p.ldw % 8) {
       snprintf(err, errlen, "gemm: operand exceeds 32-bit element offsets"); return VC_ERR_ARG; }
     if (a.epi == VC_EPI_GATE_RES && (!p.res || !p.gate || p.rows_per_batch <= 0 || p.ldres % 8 || p.gate_bstride % 8 || a.gate_step_stride % 8)) {
       snprintf(err, errlen, "gemm: gate/residual epilogue needs res, gate, rows_per_batch"); return VC_ERR_ARG; }

@@ -28,14 +28,16 @@ class GemmProblem(C.Structure):
         ("A", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p), ("C", C.c_void_p),
         ("res", C.c_void_p), ("gate", C.c_void_p),
         ("lda", C.c_int64), ("ldw", C.c_int64), ("ldc", C.c_int64), ("ldres", C.c_int64), ("gate_bstride", C.c_int64),
+        ("a_bstride", C.c_int64), ("c_bstride", C.c_int64),
         ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("rows_per_batch", C.c_int32),
+        ("a_rpb", C.c_int32), ("c_rpb", C.c_int32),
         ("tiles_m", C.c_int32), ("tiles_n", C.c_int32), ("tile_start", C.c_int32), ("_pad", C.c_int32),
     ]
 
 
 class GemmArgs(C.Structure):
     _fields_ = [
-        ("p", GemmProblem * 2), ("nprob", C.c_int32), ("epi", C.c_int32),
+        ("p", GemmProblem * 4), ("nprob", C.c_int32), ("epi", C.c_int32),
         ("step_ptr", C.c_void_p), ("gate_step_stride", C.c_int64), ("debug_ts", C.c_void_p),
     ]
 
@@ -133,14 +135,21 @@ def _bf16(t: torch.Tensor, name: str) -> None:
 # ------------------------------------------------------------------------------------------------
 # op wrappers (2-D row-major views; the last dim must be contiguous)
 # ------------------------------------------------------------------------------------------------
-def make_problem(a, w, bias, out, res=None, gate=None, rows_per_batch=None, gate_bstride=0) -> GemmProblem:
+def make_problem(a, w, bias, out, res=None, gate=None, rows_per_batch=None, gate_bstride=0, M=None,
+                 a_rpb=0, a_bstride=0, c_rpb=0, c_bstride=0) -> GemmProblem:
+    """`M` + (a_rpb, a_bstride) / (c_rpb, c_bstride) describe batch-strided rows: `a` / `out` are then views of the
+    FIRST batch element's rows (row m of the problem lives at (m // rpb) * bstride + (m % rpb) * ld)."""
     for n, t in (("A", a), ("W", w), ("C", out)):
         _bf16(t, n)
         if t.dim() != 2 or t.stride(1) != 1:
             raise VclozeHipError(f"gemm {n}: need a 2-D tensor with contiguous last dim")
-    M, K = a.shape
+    K = a.shape[1]
     N = w.shape[0]
-    if w.shape[1] != K or tuple(out.shape) != (M, N):
+    if M is None:
+        M = a.shape[0]
+        if tuple(out.shape) != (M, N):
+            raise VclozeHipError(f"gemm shape mismatch A{tuple(a.shape)} W{tuple(w.shape)} C{tuple(out.shape)}")
+    if w.shape[1] != K or out.shape[1] != N:
         raise VclozeHipError(f"gemm shape mismatch A{tuple(a.shape)} W{tuple(w.shape)} C{tuple(out.shape)}")
     p = GemmProblem()
     p.A, p.W, p.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
@@ -148,6 +157,7 @@ def make_problem(a, w, bias, out, res=None, gate=None, rows_per_batch=None, gate
     p.lda, p.ldw, p.ldc = a.stride(0), w.stride(0), out.stride(0)
     p.M, p.N, p.K = M, N, K
     p.rows_per_batch = rows_per_batch or M
+    p.a_rpb, p.a_bstride, p.c_rpb, p.c_bstride = a_rpb, a_bstride, c_rpb, c_bstride
     if res is not None:
         _bf16(res, "res")
         p.res, p.ldres = res.data_ptr(), res.stride(0)
@@ -178,35 +188,38 @@ def linear(a, w, bias=None, out=None, epi=EPI_BIAS, res=None, gate=None, tile_cf
     return out
 
 
-def ln_modulate(x, shift, scale, out=None, step_ptr=None, mod_step_stride=0, stream=None):
+def ln_modulate(x, shift, scale, out=None, step_ptr=None, mod_step_stride=0, stream=None, rows_per_batch=None,
+                mod_bstride=0):
     _bf16(x, "x")
     rows, D = x.shape
     if out is None:
         out = torch.empty(rows, D, dtype=torch.bfloat16, device=x.device)
     _check(lib().vc_ln_modulate(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), shift.data_ptr(),
-                                scale.data_ptr(), 0, rows, D, rows, _p(step_ptr), mod_step_stride,
+                                scale.data_ptr(), mod_bstride, rows, D, rows_per_batch or rows, _p(step_ptr), mod_step_stride,
                                 stream if stream is not None else cur_stream()), "vc_ln_modulate")
     return out
 
 
-def qknorm_rope_vt(qkv, q_scale, k_scale, rope, vt, L, H, stream=None, q_scale2=None, k_scale2=None, split=0):
+def qknorm_rope_vt(qkv, q_scale, k_scale, rope, vt, L, H, stream=None, q_scale2=None, k_scale2=None, split=0, B=1):
     """qkv: [L, >=3*H*128] rows (q|k|v at column 0, H*128, 2*H*128); rope: [L,64,2] f32; vt: [H,128,Lpad].
     rows < split use (q_scale, k_scale), the rest (q_scale2, k_scale2) when given."""
     _bf16(qkv, "qkv")
     if rope.dtype != torch.float32 or not rope.is_contiguous():
-        raise VclozeHipError("rope table must be contiguous f32 [L,64,2]")
+        raise VclozeHipError("rope table must be contiguous f32 [B?,L,64,2]")
     Lpad = vt.shape[-1]
-    _check(lib().vc_qknorm_rope_vt(qkv.data_ptr(), qkv.stride(0), 0, q_scale.data_ptr(), k_scale.data_ptr(),
-                                   _p(q_scale2), _p(k_scale2), split, rope.data_ptr(), 0, vt.data_ptr(), 1, L, Lpad, H,
+    # B > 1: qkv rows are sample-major ([B*L, ld]), rope [B,L,64,2], vt [B,H,128,Lpad]
+    _check(lib().vc_qknorm_rope_vt(qkv.data_ptr(), qkv.stride(0), L * qkv.stride(0), q_scale.data_ptr(), k_scale.data_ptr(),
+                                   _p(q_scale2), _p(k_scale2), split, rope.data_ptr(), L * 128 if rope.dim() == 4 else 0,
+                                   vt.data_ptr(), B, L, Lpad, H,
                                    stream if stream is not None else cur_stream()), "vc_qknorm_rope_vt")
 
 
-def attention(qkv, vt, out, L, H, kv_len=None, variant=0, stream=None):
-    """out: [L, >=H*128] rows (B L (H D)); kv_len: optional int32 device tensor [1]."""
+def attention(qkv, vt, out, L, H, kv_len=None, variant=0, stream=None, B=1):
+    """out: [B*L, >=H*128] rows (B L (H D)), sample-major like qkv; kv_len: optional int32 device tensor [B]."""
     _bf16(qkv, "qkv"); _bf16(vt, "vt"); _bf16(out, "out")
     Lpad = vt.shape[-1]
-    _check(lib().vc_attention(qkv.data_ptr(), qkv.stride(0), 0, vt.data_ptr(), out.data_ptr(), out.stride(0), 0,
-                              _p(kv_len), 1, L, Lpad, H, variant,
+    _check(lib().vc_attention(qkv.data_ptr(), qkv.stride(0), L * qkv.stride(0), vt.data_ptr(), out.data_ptr(),
+                              out.stride(0), L * out.stride(0), _p(kv_len), B, L, Lpad, H, variant,
                               stream if stream is not None else cur_stream()), "vc_attention")
 
 

@@ -269,15 +269,17 @@ class Flux(nn.Module):
         dev = eng.dev
         out = torch.empty(B, N, self.out_channels, dtype=torch.bfloat16, device=dev)
         bf = lambda t: t.to(dev, torch.bfloat16).contiguous()  # noqa: E731
-        for b in range(B):
-            ws = eng.workspace(T, N, 1)
-            g_b = None if guidance is None else guidance[b:b + 1]
-            eng.prepare_sample(ws, bf(txt[b]), bf(y[b]), g_b, guidance is not None and guidance.dtype == torch.bfloat16,
-                               img_ids[b], txt_ids[b], timesteps[b:b + 1].float(),
-                               self._kv_len(txt_mask, img_mask, b, T, N))
-            ws.XIN.copy_(bf(img[b]))
+        gbf16 = guidance is not None and guidance.dtype == torch.bfloat16
+        for b0 in range(0, B, eng.MAX_BATCH):          # samples of a chunk run as ONE stacked launch sequence
+            bs = min(eng.MAX_BATCH, B - b0)
+            sl = slice(b0, b0 + bs)
+            ws = eng.workspace(T, N, 1, bs)
+            eng.prepare_sample(ws, bf(txt[sl]), bf(y[sl]), None if guidance is None else guidance[sl], gbf16, img_ids[sl],
+                               txt_ids[sl], timesteps[sl].float().reshape(1, bs),
+                               [self._kv_len(txt_mask, img_mask, b, T, N) for b in range(b0, b0 + bs)])
+            ws.XIN.copy_(bf(img[sl]).reshape(bs * N, -1))
             eng.eval_once(ws, None, euler=False, concat=False)
-            out[b].copy_(ws.V)
+            out[sl].copy_(ws.V.reshape(bs, N, -1))
         return out.to(img.dtype) if img.dtype.is_floating_point else out
 
 

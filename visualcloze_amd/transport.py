@@ -125,31 +125,33 @@ def _sample_fused(flux, x, kw, t, return_trajectory):
     bf = lambda a: a.to(dev, torch.bfloat16).contiguous()  # noqa: E731
     out = torch.empty(B, N, C, dtype=torch.bfloat16, device=dev)
     traj = []
+    gbf16 = guidance is not None and guidance.dtype == torch.bfloat16
     st = eng.stream
     st.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(st):
         s = st.cuda_stream
-        for b in range(B):
-            ws = eng.workspace(T, N, S)
-            kv_len = flux._kv_len(kw.get("txt_mask"), kw.get("img_mask"), b, T, N)
-            eng.prepare_sample(ws, bf(txt[b]), bf(y[b]), None if guidance is None else guidance[b:b + 1],
-                               guidance is not None and guidance.dtype == torch.bfloat16, kw["img_ids"][b],
-                               kw["txt_ids"][b], eval_t, kv_len, s=s)
+        for b0 in range(0, B, eng.MAX_BATCH):        # a chunk of samples advances together, one graph replay per step
+            bs = min(eng.MAX_BATCH, B - b0)
+            sl = slice(b0, b0 + bs)
+            ws = eng.workspace(T, N, S, bs)
+            kv_len = [flux._kv_len(kw.get("txt_mask"), kw.get("img_mask"), b, T, N) for b in range(b0, b0 + bs)]
+            eng.prepare_sample(ws, bf(txt[sl]), bf(y[sl]), None if guidance is None else guidance[sl], gbf16,
+                               kw["img_ids"][sl], kw["txt_ids"][sl], eval_t, kv_len, s=s)
             ws.DTS.copy_(dts, non_blocking=True)
             ws.STEP.zero_()
-            ws.XS.copy_(bf(x[b]))
-            ws.COND.copy_(bf(cond[b]))
+            ws.XS.copy_(bf(x[sl]).reshape(bs * N, C))
+            ws.COND.copy_(bf(cond[sl]).reshape(bs * N, -1))
             graph = eng.step_graph(ws, s)
             states = []
             for _ in range(S):
                 graph.launch(s)          # one Flux evaluation + Euler update + step counter increment
                 if return_trajectory:
-                    states.append(ws.XS.clone())
+                    states.append(ws.XS.reshape(bs, N, C).clone())
             if return_trajectory:
-                traj.append(torch.stack(states))
-            out[b].copy_(ws.XS)
+                traj.append(torch.stack(states))                  # [S, bs, N, C]
+            out[sl].copy_(ws.XS.reshape(bs, N, C))
     torch.cuda.current_stream().wait_stream(st)
     if return_trajectory:
-        full = torch.cat((x.to(dev, torch.bfloat16)[None], torch.stack(traj, dim=1)), dim=0)
+        full = torch.cat((x.to(dev, torch.bfloat16)[None], torch.cat(traj, dim=1)), dim=0)
         return full.to(x.dtype)
     return out[None].to(x.dtype)

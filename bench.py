@@ -156,33 +156,35 @@ def roofline_gemm(job, iters=3):
     21.2 TFLOP per evaluation at cfg 2) — launch by launch on the engine stream with HIP events."""
     from visualcloze_amd import hip
     eng, ws = job.eng, job.ws
-    D, T, N, L = eng.D, ws.T, ws.N, ws.L
-    X, CAT = ws.X, ws.CAT
-    Xt, Xi, ATT, HID = X[:T], X[T:], CAT[:, :D], CAT[:, D:]
-    mss = eng.W.n_mod
+    D, T, N, L, B = eng.D, ws.T, ws.N, ws.L, ws.B
+    nm = eng.W.n_mod
+    mss = B * nm
+    XI, XT, X, CAT, HID = ws.XI, ws.XT, ws.X, ws.CAT, ws.HID
+    ATT = CAT[:, :D]
+    HID_I, HID_T = HID[:B * N], HID[B * N:]
+    att_i = dict(M=B * N, a_rpb=N, a_bstride=L * CAT.stride(0))
+    att_t = dict(M=B * T, a_rpb=T, a_bstride=L * CAT.stride(0))
     launches, flops = [], 0.0
+
+    def P(name, a_, o_, gate, rpb, **kw):
+        return eng._prob(name, a_, o_, res=o_, gate=gate, rows_per_batch=rpb, gate_bstride=nm, **kw)
     for i in range(eng.g.depth):
         pf = f"double_blocks.{i}"
         im, tm = pf + ".img_mod.lin", pf + ".txt_mod.lin"
-        launches.append(((pf + ".img_attn.proj", pf + ".txt_attn.proj"), (ATT[T:], ATT[:T]), (Xi, Xt),
-                         (eng._mod(ws, im, 2), eng._mod(ws, tm, 2))))
-        launches.append(((pf + ".img_mlp.2", pf + ".txt_mlp.2"), (HID[T:], HID[:T]), (Xi, Xt),
-                         (eng._mod(ws, im, 5), eng._mod(ws, tm, 5))))
-        flops += 2.0 * L * D * D + 2.0 * L * D * eng.mlp
+        launches.append([P(pf + ".img_attn.proj", ATT[T:], XI, eng._mod(ws, im, 2), N, **att_i),
+                         P(pf + ".txt_attn.proj", ATT[:T], XT, eng._mod(ws, tm, 2), T, **att_t)])
+        launches.append([P(pf + ".img_mlp.2", HID_I, XI, eng._mod(ws, im, 5), N),
+                         P(pf + ".txt_mlp.2", HID_T, XT, eng._mod(ws, tm, 5), T)])
+        flops += B * (2.0 * L * D * D + 2.0 * L * D * eng.mlp)
     for i in range(eng.g.depth_single_blocks):
         pf = f"single_blocks.{i}"
-        launches.append(((pf + ".linear2",), (CAT,), (X,), (eng._mod(ws, pf + ".modulation.lin", 2),)))
-        flops += 2.0 * L * D * (D + eng.mlp)
+        launches.append([P(pf + ".linear2", CAT, X, eng._mod(ws, pf + ".modulation.lin", 2), L)])
+        flops += B * 2.0 * L * D * (D + eng.mlp)
     s = job.s
 
     def run():
-        for names, As, outs, gates in launches:
-            if len(names) == 2:
-                eng._lin2(names, As, outs, epi=hip.EPI_GATE_RES, ress=outs, gates=gates, step_ptr=ws.STEP,
-                          gate_step_stride=mss, s=s)
-            else:
-                eng._lin(names[0], As[0], outs[0], epi=hip.EPI_GATE_RES, res=outs[0], gate=gates[0], step_ptr=ws.STEP,
-                         gate_step_stride=mss, s=s)
+        for ps in launches:
+            eng._gemm(ps, epi=hip.EPI_GATE_RES, step_ptr=ws.STEP, gate_step_stride=mss, s=s)
     ws.STEP.zero_()
     with torch.cuda.stream(job.eng.stream):
         run()
@@ -205,14 +207,14 @@ def roofline_attention(job, iters=3):
     eng, ws = job.eng, job.ws
     s = job.s
     with torch.cuda.stream(eng.stream):
-        hip.attention(ws.QKV, ws.VT, ws.CAT[:, :eng.D], ws.L, eng.H, variant=eng.attn_variant, stream=s)
+        hip.attention(ws.QKV, ws.VT, ws.CAT[:, :eng.D], ws.L, eng.H, variant=eng.attn_variant, stream=s, B=ws.B)
         e0, e1 = hip.Event(), hip.Event()
         e0.record(s)
         for _ in range(iters * 10):
-            hip.attention(ws.QKV, ws.VT, ws.CAT[:, :eng.D], ws.L, eng.H, variant=eng.attn_variant, stream=s)
+            hip.attention(ws.QKV, ws.VT, ws.CAT[:, :eng.D], ws.L, eng.H, variant=eng.attn_variant, stream=s, B=ws.B)
         e1.record(s)
         ms = e0.elapsed_ms(e1) / (iters * 10)
-    fl = 4.0 * ws.L * ws.L * eng.D
+    fl = 4.0 * ws.L * ws.L * eng.D * ws.B
     return dict(kernel="attn_fwd_kernel", avg_launch_us=round(ms * 1e3, 2), achieved=round(fl / ms / 1e9, 1),
                 unit="TFLOP/s", frac=round(fl / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4))
 

@@ -1,17 +1,20 @@
-"""Tiny end-to-end check of the HIP path against the CPU oracle (used by __graft_entry__.smoke())."""
+"""Test helpers: the tiny procedural-weight model on the GPU and the smoke check of the HIP path against the CPU
+oracle (used by tests/ and __graft_entry__.smoke(); lives outside the product package because it imports oracle/)."""
 import os
 import sys
 
 import torch
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
 
 
 def tiny_model(dev="cuda:0", dtype=torch.bfloat16):
     if REPO not in sys.path:
         sys.path.insert(0, REPO)
     from tests.procedural import TINY, TINY_RANK, procedural_param
-    from .model import FluxLoraWrapper, FluxParams
+    from visualcloze_amd.model import FluxLoraWrapper, FluxParams
     m = FluxLoraWrapper(lora_rank=TINY_RANK, lora_scale=1.0, params=FluxParams(**TINY))
     sd = {k: procedural_param(k, v.shape) for k, v in m.state_dict().items()}
     m.load_state_dict(sd, strict=True)
@@ -24,7 +27,7 @@ def rel_l2(a, b):
 
 
 def smoke() -> None:
-    from . import hip
+    from visualcloze_amd import hip
     hip.require_gpu()
     if REPO not in sys.path:
         sys.path.insert(0, REPO)

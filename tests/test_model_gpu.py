@@ -23,7 +23,7 @@ def rel_l2(a, b):
 
 @pytest.fixture(scope="module")
 def model():
-    from visualcloze_amd.selftest import tiny_model
+    from tests.helpers import tiny_model
     return tiny_model()
 
 

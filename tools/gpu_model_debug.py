@@ -8,7 +8,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import oracle.flux_oracle as O  # noqa: E402
 from tests.procedural import TINY, tiny_inputs  # noqa: E402
-from visualcloze_amd.selftest import rel_l2, tiny_model  # noqa: E402
+from tests.helpers import rel_l2, tiny_model  # noqa: E402
 
 
 def main():

@@ -22,14 +22,16 @@ namespace {
 constexpr int BK = 64;
 
 template <int BM, int BN, int WM, int WN, int EPI, int PP>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const VcGemmArgs args) {
-  constexpr int NT = WM * WN * 64;
+__global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_kernel(const VcGemmArgs args) {
+  constexpr int NCW = WM * WN;                       // compute waves
+  constexpr int NT = (NCW + (PP == 2 ? 4 : 0)) * 64;  // PP == 2 adds 4 loader waves (one per SIMD)
+  constexpr int NS = PP == 2 ? 256 : NT;              // threads that stage operand tiles
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int MI = TM / 16, NI = TN / 16;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
   constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
   constexpr int A_CH = BM * 8, B_CH = BN * 8;                       // 16-B chunks per operand tile
-  constexpr int A_IT = (A_CH + NT - 1) / NT, B_IT = (B_CH + NT - 1) / NT;
+  constexpr int A_IT = (A_CH + NS - 1) / NS, B_IT = (B_CH + NS - 1) / NS;
   static_assert(A_CH % 64 == 0 && B_CH % 64 == 0, "a wave-instruction (64 chunks) must not straddle the tile end");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -46,7 +48,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const VcGemmArgs
     if (q < args.nprob && id >= args.p[q].tile_start) pi = q;
   const VcGemmProblem P = pi == 3 ? args.p[3] : pi == 2 ? args.p[2] : pi == 1 ? args.p[1] : args.p[0];
   id -= P.tile_start;
-  constexpr int GROUP_M = 8;
+#ifndef VC_GROUP_M
+#define VC_GROUP_M 8
+#endif
+  constexpr int GROUP_M = VC_GROUP_M;
   const int in_group = GROUP_M * P.tiles_n;
   const int group = id / in_group;
   const int first_m = group * GROUP_M;
@@ -60,10 +65,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const VcGemmArgs
   const bf16_t* __restrict__ Wb = (const bf16_t*)P.W;
 
   // ---- staging source offsets (elements), one per 16-B chunk this thread copies ----
+  const int stid = PP == 2 ? (tid - NCW * 64) & 255 : tid;   // staging thread / wave index (PP == 2: loader waves)
+  const int swave = PP == 2 ? (wave - NCW) & 3 : wave;
   uint32_t a_off[A_IT], b_off[B_IT];
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
-    const int c = i * NT + tid;
+    const int c = i * NS + stid;
     const int row = c >> 3, slot = (c & 7) ^ (row & 7);
     const int grow = min(m0 + row, M - 1);
     a_off[i] = (P.a_rpb > 0 ? (uint32_t)(grow / P.a_rpb) * (uint32_t)P.a_bstride + (uint32_t)(grow % P.a_rpb) * (uint32_t)P.lda
@@ -71,22 +78,29 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const VcGemmArgs
   }
 #pragma unroll
   for (int i = 0; i < B_IT; ++i) {
-    const int c = i * NT + tid;
+    const int c = i * NS + stid;
     const int row = c >> 3, slot = (c & 7) ^ (row & 7);
     const int grow = min(n0 + row, N - 1);
     b_off[i] = (uint32_t)grow * (uint32_t)P.ldw + slot * 8;
   }
 
   auto stage = [&](int buf, int k0) {
+#ifdef VC_GEMM_NO_DMA     // analysis builds only: core side of the loop alone (operands of K-tile 0 reused)
+    if (k0 > 0) return;
+#endif
     char* sa = smem + buf * STAGE_BYTES;
     char* sb = sa + A_BYTES;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i)
-      if (A_CH % NT == 0 || i * NT + wave * 64 < A_CH) glds16(Ab + a_off[i] + k0, sa + (i * NT + wave * 64) * 16);
+      if (A_CH % NS == 0 || i * NS + swave * 64 < A_CH) glds16(Ab + a_off[i] + k0, sa + (i * NS + swave * 64) * 16);
 #pragma unroll
     for (int i = 0; i < B_IT; ++i)   // 256x288: the last sweep covers half a tile's worth -> waves 0-3 only (wave-uniform)
-      if (B_CH % NT == 0 || i * NT + wave * 64 < B_CH) glds16(Wb + b_off[i] + k0, sb + (i * NT + wave * 64) * 16);
+      if (B_CH % NS == 0 || i * NS + swave * 64 < B_CH) glds16(Wb + b_off[i] + k0, sb + (i * NS + swave * 64) * 16);
   };
+  // PP == 2 (loader waves): A lives in a 2-deep ring, W in a 3-deep ring (2*A_BYTES + 3*B_BYTES = 136 KB for 256x192)
+  constexpr int W_RING0 = 2 * A_BYTES;
+  auto stage_a_piece = [&](int slot, int k0, int i) { glds16(Ab + a_off[i] + k0, smem + slot * A_BYTES + (i * NS + swave * 64) * 16); };
+  auto stage_w_piece = [&](int slot, int k0, int i) { glds16(Wb + b_off[i] + k0, smem + W_RING0 + slot * B_BYTES + (i * NS + swave * 64) * 16); };
 
   // ---- fragment read offsets ----
   const int fr = lane & 15, fq = lane >> 4;
@@ -123,6 +137,131 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const VcGemmArgs
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
       }
       __syncthreads();
+    }
+  } else if constexpr (PP == 2) {
+    // ---- ping-pong schedule with LOADER WAVES: the 8 compute waves alternate MEMORY (ds_read only) and COMPUTE
+    // segments exactly as in the PP == 1 schedule below, but every LDS-DMA is issued by 4 extra waves (one per SIMD,
+    // 3 waves per SIMD in all, <= 168 VGPRs).  An LDS-DMA wave-instruction holds its wave's issue slot for ~60-180
+    // cycles; inside a compute wave's MEMORY segment that made the segment ~2x the partner's COMPUTE segment
+    // (tools/gemm_l2hot.py: loop without DMA 1.7 PFLOP/s, loop without MFMA 1.6, both together 1.1-1.2).  The loaders
+    // take part in every workgroup barrier (s_barrier counts all live waves), so their per-interval work is bounded:
+    // during K-tile t they issue A(t+1) then W(t+2) over intervals 4t, 4t+1, 4t+2 (both slots' last readers, group 1's
+    // M(t-1,1), retired before the barrier ending 4t-1) and wait with vmcnt(#W pieces) before the barrier ending
+    // 4t+3: A(t+1) and W(t+1) have landed, W(t+2) - streamed from HBM, the long-latency operand - keeps flying.
+    static_assert(NCW == 8 && A_CH % NS == 0 && B_CH % NS == 0, "loader-wave schedule: 8 compute waves, whole sweeps");
+    auto bar = [&]() {
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    constexpr int NPIECE = A_IT + B_IT;                 // wave-instructions per loader wave per K-tile
+#ifndef VC_LW_TOUCH
+#define VC_LW_TOUCH 0
+#endif
+#ifndef VC_LW_WD
+#define VC_LW_WD 2
+#endif
+#ifndef VC_LW_ORDER
+#define VC_LW_ORDER 0
+#endif
+#ifndef VC_LW_P0
+#define VC_LW_P0 ((NPIECE + 2) / 3)
+#endif
+#ifndef VC_LW_P1
+#define VC_LW_P1 ((NPIECE - P0 + 1) / 2)
+#endif
+    constexpr int WD = VC_LW_WD;                        // W is issued WD tiles ahead into a ring of WD+1 slots
+    constexpr int P0 = VC_LW_P0, P1 = VC_LW_P1;         // pieces issued in intervals 4t / 4t+1 (the rest in 4t+2)
+    constexpr int TOUCH = VC_LW_TOUCH, NTOUCH = TOUCH > 0 ? 1 : 0;
+    if (wave >= NCW) {
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) stage_a_piece(0, 0, i);
+#pragma unroll
+      for (int d = 0; d < WD; ++d)
+        if (d < nk) {
+#pragma unroll
+          for (int i = 0; i < B_IT; ++i) stage_w_piece(d, d * BK, i);
+        }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      bar();
+      int wsd = WD;                                     // W slot of tile kt+WD
+      // optional L2 touch: one lane per 128-B line of A(t+TOUCH)
+      const int trow = min(m0 + stid, M - 1);
+      const uint32_t t_off = P.a_rpb > 0 ? (uint32_t)(trow / P.a_rpb) * (uint32_t)P.a_bstride + (uint32_t)(trow % P.a_rpb) * (uint32_t)P.lda
+                                         : (uint32_t)trow * (uint32_t)P.lda;
+      for (int kt = 0; kt < nk; ++kt) {
+        const int as1 = (kt & 1) ^ 1, k1 = (kt + 1) * BK, kd = (kt + WD) * BK;
+        const bool more1 = kt + 1 < nk, mored = kt + WD < nk;
+        auto piece = [&](int j) {
+#ifdef VC_GEMM_NO_DMA
+          return;
+#endif
+          const int ja = VC_LW_ORDER == 0 ? j : j - B_IT, jw = VC_LW_ORDER == 0 ? j - A_IT : j;
+#pragma unroll
+          for (int i = 0; i < A_IT; ++i)
+            if (ja == i && more1) stage_a_piece(as1, k1, i);
+#pragma unroll
+          for (int i = 0; i < B_IT; ++i)
+            if (jw == i && mored) stage_w_piece(wsd, kd, i);
+        };
+#pragma unroll
+        for (int j = 0; j < P0; ++j) piece(j);
+        bar();
+#pragma unroll
+        for (int j = P0; j < P0 + P1; ++j) piece(j);
+        bar();
+#pragma unroll
+        for (int j = P0 + P1; j < NPIECE; ++j) piece(j);
+        if (TOUCH > 0 && mored) {
+          // 4-B LDS-DMA into a scratch row: a load with no VGPR destination to keep alive
+          __builtin_amdgcn_global_load_lds((gptr_t)(Ab + t_off + min(kt + TOUCH, nk - 1) * BK),
+                                           (lptr_t)(smem + 2 * A_BYTES + (WD + 1) * B_BYTES + swave * 256), 4, 0, 0);
+        }
+        bar();
+        // A(t+1) and W(t+1) must have landed; with A issued first and WD == 2, W(t+2) (the last pieces) keeps flying
+        if (VC_LW_ORDER == 0 && WD >= 2 && mored) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B_IT + NTOUCH) : "memory");
+        else if (NTOUCH && mored) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NTOUCH) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        bar();
+        wsd = wsd == WD ? 0 : wsd + 1;
+      }
+      bar();
+    } else {
+      const int grp = wave >> 2;
+      bar();
+      if (grp == 1) bar();
+      int ws = 0;                                       // W slot of tile kt
+      for (int kt = 0; kt < nk; ++kt) {
+        const char* base_a = smem + (kt & 1) * A_BYTES;
+        const char* base_b = smem + W_RING0 - A_BYTES + ws * B_BYTES;   // b_rd already carries +A_BYTES
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          bf16x8 af[MI], bfr[NI];
+#pragma unroll
+          for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(base_a + ((a_rd + i * 16 * 128) ^ (kk * 64)));
+#pragma unroll
+          for (int j = 0; j < NI; ++j) bfr[j] = *(const bf16x8*)(base_b + ((b_rd + j * 16 * 128) ^ (kk * 64)));
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          bar();
+          __builtin_amdgcn_s_setprio(1);
+#ifdef VC_GEMM_NO_MFMA
+#pragma unroll
+          for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(af[i]));
+#pragma unroll
+          for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(bfr[j]));
+#else
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+#endif
+          __builtin_amdgcn_s_setprio(0);
+          bar();
+        }
+        ws = ws == WD ? 0 : ws + 1;
+      }
+      if (grp == 0) bar();
     }
   } else {
     // ---- ping-pong schedule (8 waves = 2 per SIMD): the two waves of a SIMD alternate between a MEMORY segment
@@ -178,11 +317,18 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const VcGemmArgs
         stamp();
         // ---- compute segment
         __builtin_amdgcn_s_setprio(1);
+#ifdef VC_GEMM_NO_MFMA   // analysis builds only (tools/gemm_l2hot.py): memory side of the loop alone
+#pragma unroll
+        for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(af[i]));
+#pragma unroll
+        for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(bfr[j]));
+#else
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < NI; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+#endif
         __builtin_amdgcn_s_setprio(0);
         stamp();
         if (kk == 1 && grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -200,6 +346,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const VcGemmArgs
   const bf16_t* __restrict__ bias = (const bf16_t*)P.bias;
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
+    if (PP == 2 && wave >= NCW) break;   // loader waves hold no accumulators
     const int row = wm * TM + i * 16 + fr;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
@@ -254,8 +401,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const VcGemmArgs
 
 template <int BM, int BN, int WM, int WN, int PP>
 hipError_t launch_cfg(const VcGemmArgs& a, int total_tiles, hipStream_t s) {
-  constexpr int NT = WM * WN * 64;
-  constexpr int LDS_STAGES = 2 * (BM + BN) * BK * 2, LDS_EPI = BM * (BN * 2 + 16);
+  constexpr int NT = (WM * WN + (PP == 2 ? 4 : 0)) * 64;
+  constexpr int LDS_STAGES = (PP == 2 ? 2 * BM + 3 * BN : 2 * (BM + BN)) * BK * 2 + (PP == 2 ? 1024 : 0), LDS_EPI = BM * (BN * 2 + 16);
   constexpr int LDS = LDS_STAGES > LDS_EPI ? LDS_STAGES : LDS_EPI;
   void (*fn)(const VcGemmArgs) = nullptr;
   switch (a.epi) {
@@ -289,26 +436,26 @@ int vc_gemm_launch(VcGemmArgs a, int tile_cfg, hipStream_t s, char* err, int err
     if (p.a_rpb < 0 || p.c_rpb < 0 || p.a_bstride % 8 || p.c_bstride % 8 || (p.c_rpb > 0 && p.res && p.ldres != p.ldc)) {
       snprintf(err, errlen, "gemm: bad batch-strided row description"); return VC_ERR_ARG; }
     if ((p.a_rpb > 0 ? (uint64_t)((p.M + p.a_rpb - 1) / p.a_rpb) * (uint64_t)p.a_bstride : 0) >= (1ull << 32) ||
-        (uint64_t)(p.a_rpb > 0 ? p.a_rpb : p.M) * (uint64_t)p.lda >= (1ull << 32) || (uint64_t)p.N * (uint64_t)p.ldw >= (1ull << 32) || p.ldw < p.K || p.ldw % 8) {
+        (uint64_t)(p.a_rpb > 0 ? p.a_rpb : p.M) * (uint64_t)p.lda >= (1ull << 32) || (uint64_t)p.N * (uint64_t)p.ldw >= (1ull << 32) || (p.ldw != 0 && p.ldw < p.K) || p.ldw % 8) {
       snprintf(err, errlen, "gemm: operand exceeds 32-bit element offsets"); return VC_ERR_ARG; }
     if (a.epi == VC_EPI_GATE_RES && (!p.res || !p.gate || p.rows_per_batch <= 0 || p.ldres % 8 || p.gate_bstride % 8 || a.gate_step_stride % 8)) {
       snprintf(err, errlen, "gemm: gate/residual epilogue needs res, gate, rows_per_batch"); return VC_ERR_ARG; }
   }
-  // +16 selects the ping-pong main loop (8-wave tiles 256x256 / 256x192); auto picks it for those tiles
+  // +16 selects the ping-pong main loop (8-wave tiles 256x256 / 256x192), +32 its loader-wave form (256x192 only)
   int pp = (tile_cfg >> 4) & 7;
   tile_cfg &= 15;
   static const int cfg_bm[6] = {0, 128, 256, 256, 256, 256}, cfg_bn[6] = {0, 128, 128, 256, 192, 288};
   if (tile_cfg == 0) {
     // Cost model fitted on MI355X (M=3968 FLUX shapes): time = block-rounds on 256 CUs x (tile area x (K + fixed
-    // prologue/epilogue charge) / streaming efficiency of that tile).  Candidates: 128x128 simple loop (2 blocks
-    // per CU; small or skinny problems), 256x256 / 256x192 ping-pong and 256x288 (1 block per CU).  For M <= 4096:
-    // 256x192 gives N=3072 exactly one round (256 tiles), 256x288 gives N=9216 exactly two (512), 256x256 gives
-    // N=12288 exactly three (768).
-    static const int cand[4] = {1, 3, 4, 5};
-    static const int cand_pp[4] = {0, 1, 1, 0};     // 256x288 runs the simple loop: its ping-pong form spills VGPRs
-    static const double eff[4] = {0.55, 1.0, 0.785, 0.88}, ovh[4] = {500.0, 650.0, 350.0, 490.0};
+    // prologue/epilogue charge) / streaming efficiency of that tile).  Candidates: 128x128 simple loop (2 blocks per
+    // CU; small or skinny problems) and 256x192 with loader waves (1 block per CU), which beat the 256x256 / 256x192
+    // ping-pong and the 256x288 tiles on every FLUX shape in an interleaved A/B (tools/gemm_ab.py); those stay
+    // selectable by number.  For M <= 4096, 256x192 gives N=3072 / 9216 / 12288 exactly 1 / 3 / 4 rounds.
+    static const int cand[2] = {1, 4};
+    static const int cand_pp[2] = {0, 2};
+    static const double eff[2] = {0.55, 0.94}, ovh[2] = {500.0, 350.0};
     double best = 1e300;
-    for (int ci = 0; ci < 4; ++ci) {
+    for (int ci = 0; ci < 2; ++ci) {
       const int c = cand[ci];
       long tiles = 0;
       for (int i = 0; i < a.nprob; ++i)
@@ -319,7 +466,7 @@ int vc_gemm_launch(VcGemmArgs a, int tile_cfg, hipStream_t s, char* err, int err
       if (t < best) { best = t; tile_cfg = c; pp = cand_pp[ci]; }
     }
   }
-  if (tile_cfg < 1 || tile_cfg > 5 || pp > 1 || (pp && tile_cfg < 3)) { snprintf(err, errlen, "gemm: bad tile_cfg %d", tile_cfg); return VC_ERR_ARG; }
+  if (tile_cfg < 1 || tile_cfg > 5 || pp > 2 || (pp && tile_cfg < 3) || (pp == 2 && tile_cfg != 4)) { snprintf(err, errlen, "gemm: bad tile_cfg %d", tile_cfg); return VC_ERR_ARG; }
   const int bm = cfg_bm[tile_cfg], bn = cfg_bn[tile_cfg];
   int total = 0;
   for (int i = 0; i < a.nprob; ++i) {
@@ -333,7 +480,7 @@ int vc_gemm_launch(VcGemmArgs a, int tile_cfg, hipStream_t s, char* err, int err
     case 1: e = launch_cfg<128, 128, 2, 2, 0>(a, total, s); break;
     case 2: e = launch_cfg<256, 128, 4, 2, 0>(a, total, s); break;
     case 3: e = pp ? launch_cfg<256, 256, 2, 4, 1>(a, total, s) : launch_cfg<256, 256, 2, 4, 0>(a, total, s); break;
-    case 4: e = pp ? launch_cfg<256, 192, 4, 2, 1>(a, total, s) : launch_cfg<256, 192, 4, 2, 0>(a, total, s); break;
+    case 4: e = pp == 2 ? launch_cfg<256, 192, 4, 2, 2>(a, total, s) : pp ? launch_cfg<256, 192, 4, 2, 1>(a, total, s) : launch_cfg<256, 192, 4, 2, 0>(a, total, s); break;
     default: e = pp ? launch_cfg<256, 288, 4, 2, 1>(a, total, s) : launch_cfg<256, 288, 4, 2, 0>(a, total, s); break;
   }
   if (e != hipSuccess) { snprintf(err, errlen, "gemm launch: %s", hipGetErrorString(e)); return VC_ERR_HIP; }

@@ -87,7 +87,10 @@ int vc_qknorm_rope_vt(void* qkv, int64_t ld, int64_t bstride, const void* q_scal
 /* Joint text+image attention, non-causal, D=128, softmax scale 128^-0.5 (math.py:63-99 /
  * flash_attn_varlen_func).  q,k from the qkv rows above; vt from vc_qknorm_rope_vt.
  * kv_len[b] (host-visible semantics: keys >= kv_len masked, query rows >= kv_len written as 0,
- * = pad_input of math.py:96); NULL = all L.  out: [B, L, H*128] bf16, row stride ldo. */
+ * = pad_input of math.py:96); NULL = all L.  out: [B, L, H*128] bf16, row stride ldo.
+ * variant: 0 = 8 waves x 32 queries per workgroup, 1 = 4 waves x 32 queries (two workgroups per CU); +2 = the same
+ * kernel on a persistent grid (one workgroup per resident slot, work items assigned statically) - 3 is the default
+ * of the host engine.  All variants produce bit-identical results. */
 int vc_attention(const void* qkv, int64_t ld, int64_t bstride, const void* vt, void* out, int64_t ldo,
                  int64_t out_bstride, const int32_t* kv_len, int32_t B, int32_t L, int32_t Lpad, int32_t H,
                  int32_t variant, void* stream);

@@ -90,7 +90,7 @@ def test_attention_properties_full_size():
     out = torch.empty(L, D, dtype=torch.bfloat16, device=DEV)
     # V = 1  =>  every output element is a convex combination of ones
     vt = torch.ones(H, 128, L, dtype=torch.bfloat16, device=DEV)
-    for variant in (0, 1):
+    for variant in (0, 1, 2, 3):
         hip.attention(qkv, vt, out, L, H, variant=variant)
         torch.cuda.synchronize()
         assert (out.float() - 1.0).abs().max().item() < 1e-2
@@ -167,7 +167,7 @@ def test_race_screen_repeated_launches_are_bit_identical():
                 assert torch.equal(outs[0], outs[1]), f"cfg {cfg}: launch {it} differs"
     qkv = torch.randn(L, 3 * D, generator=g).to(torch.bfloat16).to(DEV)
     vt = qkv[:, 2 * D:].reshape(L, H, 128).permute(1, 2, 0).contiguous()
-    for variant in (0, 1):
+    for variant in (0, 1, 2, 3):
         o0 = torch.empty(L, D, dtype=torch.bfloat16, device=DEV)
         o1 = torch.empty(L, D, dtype=torch.bfloat16, device=DEV)
         hip.attention(qkv, vt, o0, L, H, variant=variant)

@@ -1,0 +1,48 @@
+"""A/B timing of attention variants (library builds x kernel variant) interleaved in one process.
+    python tools/attn_ab.py main:1 main:0 nodma:1 ..."""
+import sys, os, ctypes as C, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from visualcloze_amd import hip
+dev = "cuda:0"
+hip.lib()
+LIBDIR = os.path.dirname(hip.LIB_PATH)
+libs = {}
+def getlib(name):
+    if name not in libs:
+        l = C.CDLL(hip.LIB_PATH if name == "main" else os.path.join(LIBDIR, f"libvcloze_hip_{name}.so"))
+        l.vc_attention.restype = C.c_int
+        libs[name] = l
+    return libs[name]
+def rnd(*s, scale=1.0):
+    return (torch.randn(*s, device=dev) * scale).to(torch.bfloat16)
+variants = [(v.split(":")[0], int(v.split(":")[1])) for v in sys.argv[1:]]
+for L in (3968, 6656):
+    H = 24
+    Lpad = (L + 63) // 64 * 64
+    qkv = rnd(L, 3 * H * 128)
+    vt = rnd(H, 128, Lpad)
+    o = torch.empty(L, H * 128, dtype=torch.bfloat16, device=dev)
+    stream = hip.cur_stream()
+    def run(l, var):
+        # int vc_attention(qkv, ld, bstride, vt, out, ldo, out_bstride, kv_len, B, L, Lpad, H, variant, stream)
+        rc = l.vc_attention(C.c_void_p(qkv.data_ptr()), C.c_int64(qkv.stride(0)), C.c_int64(0), C.c_void_p(vt.data_ptr()), C.c_void_p(o.data_ptr()),
+                            C.c_int64(o.stride(0)), C.c_int64(0), C.c_void_p(0), C.c_int32(1), C.c_int32(L), C.c_int32(Lpad), C.c_int32(H), C.c_int32(var), C.c_void_p(stream))
+        assert rc == 0, rc
+    run(getlib("main"), 1); ref = o.clone()
+    for v in variants:
+        o.zero_(); run(getlib(v[0]), v[1]); torch.cuda.synchronize()
+        if not torch.equal(o, ref):
+            d = (o.float() - ref.float()).abs().max().item()
+            print(f"  MISMATCH {v}: max abs diff vs main:1 = {d:.4g}, nan={bool(torch.isnan(o.float()).any())}")
+    tot = {v: 0.0 for v in variants}
+    R, n = 6, 10
+    for r in range(R + 1):
+        for v in variants:
+            l = getlib(v[0])
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n): run(l, v[1])
+            e1.record(); torch.cuda.synchronize()
+            if r > 0: tot[v] += e0.elapsed_time(e1) * 1e3 / n
+    fl = 4.0 * L * L * H * 128
+    print(f"L={L}: " + " | ".join(f"{v[0]}:{v[1]} {tot[v]/R:6.1f} us {fl/(tot[v]/R)/1e6:5.0f} TF" for v in variants), flush=True)

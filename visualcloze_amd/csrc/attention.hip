@@ -15,6 +15,7 @@
 // registers of a lane line up with 8 CONTIGUOUS keys per 16-key step -> P feeds PV with no cross-lane moves.
 // LDS images are lane-linear (DMA) with XOR slot swizzles applied on the source address and on the
 // ds_read_b128 address (K: slot ^= row&15 on 256-B rows; Vt: slot ^= (row>>1)&7 on 128-B rows).
+#include <algorithm>
 #include "common.h"
 #include "vcloze_internal.h"
 
@@ -26,7 +27,7 @@ struct AttnArgs {
   bf16_t* out;
   const int32_t* kv_len;
   int64_t ld, bstride, ldo, out_bstride;
-  int32_t B, L, Lpad, H, qblocks;
+  int32_t B, L, Lpad, H, qblocks, items;
   uint64_t* debug_ts;   // profiling builds only (-DVC_ATTN_TIMESTAMPS)
 };
 
@@ -48,7 +49,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs a) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lq = lane & 31, hh = lane >> 5;
 
-  int id = xcd_remap(blockIdx.x, gridDim.x);
+  // Persistent launch: gridDim.x = CUs x resident blocks; block p takes work items p, p + gridDim.x, ...  With 744
+  // items on 512 slots (L=3968) the hardware dispatcher refills BOTH slots of the CUs that finish first (4 items on
+  // some CUs, 2 on others); the static assignment gives every CU 3 (slot 0 runs a second item while slot 1 idles).
+  for (int item = blockIdx.x; item < a.items; item += gridDim.x) {
+  int id = xcd_remap(item, a.items);
   const int qb = id % a.qblocks;
   const int bh = id / a.qblocks;
   const int h = bh % a.H, b = bh / a.H;
@@ -130,7 +135,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs a) 
   for (int kt = 0; kt < nkt; ++kt) {
     const int cur = kt & 1;
     stamp();
+#ifndef VC_ATTN_NO_DMA      // analysis builds only (wrong results): the loop without its LDS-DMA
     if (kt + 1 < nkt) stage(cur ^ 1, kt + 1);
+#endif
     const char* base = smem + cur * STAGE;
 
     // S^T = K . Q^T.  Fragment reads run one 8-deep batch AHEAD of the MFMAs that consume them (rotating register
@@ -198,7 +205,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs a) 
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
+#ifdef VC_ATTN_NO_EXP        // analysis builds only (wrong results): the loop without its transcendentals
+        const float p = s[u][r] * c_scale - m_new;
+#else
         const float p = __builtin_amdgcn_exp2f(s[u][r] * c_scale - m_new);
+#endif
         psum += p;
         pf[u * 2 + (r >> 3)][r & 7] = (__bf16)p;
       }
@@ -240,6 +251,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs a) 
         *(u32x2*)(orow + dt * 32 + g * 8 + hh * 4) = w;
       }
   }
+  }  // work items
 }
 
 }  // namespace
@@ -262,16 +274,25 @@ int vc_attention_launch(const void* qkv, int64_t ld, int64_t bstride, const void
   a.debug_ts = g_attn_debug_ts;
   const int lds = 2 * STAGE;
   hipError_t e;
+  const bool persist = (variant & 2) != 0;   // +2: persistent grid with static item assignment (variants 2, 3)
+  variant &= 1;
+  static int n_cu = 0;
+  if (persist && n_cu == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+  }
   if (variant == 1) {  // 4 waves x 32 queries
     a.qblocks = (L + 127) / 128;
     static bool done = false;
     if (!done) { e = hipFuncSetAttribute((const void*)attn_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) goto fail; done = true; }
-    hipLaunchKernelGGL(attn_fwd_kernel<4>, dim3(a.qblocks * H * B), dim3(256), lds, s, a);
+    a.items = a.qblocks * H * B;
+    hipLaunchKernelGGL(attn_fwd_kernel<4>, dim3(std::min(a.items, persist ? 2 * n_cu : a.items)), dim3(256), lds, s, a);
   } else {  // 8 waves x 32 queries
     a.qblocks = (L + 255) / 256;
     static bool done8 = false;
     if (!done8) { e = hipFuncSetAttribute((const void*)attn_fwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) goto fail; done8 = true; }
-    hipLaunchKernelGGL(attn_fwd_kernel<8>, dim3(a.qblocks * H * B), dim3(512), lds, s, a);
+    a.items = a.qblocks * H * B;
+    hipLaunchKernelGGL(attn_fwd_kernel<8>, dim3(std::min(a.items, persist ? n_cu : a.items)), dim3(512), lds, s, a);
   }
   e = hipGetLastError();
   if (e == hipSuccess) return VC_OK;

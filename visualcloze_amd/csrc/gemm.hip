@@ -174,6 +174,9 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
     constexpr int P0 = VC_LW_P0, P1 = VC_LW_P1;         // pieces issued in intervals 4t / 4t+1 (the rest in 4t+2)
     constexpr int TOUCH = VC_LW_TOUCH, NTOUCH = TOUCH > 0 ? 1 : 0;
     if (wave >= NCW) {
+#ifdef VC_LW_LPRIO
+      __builtin_amdgcn_s_setprio(VC_LW_LPRIO);
+#endif
 #pragma unroll
       for (int i = 0; i < A_IT; ++i) stage_a_piece(0, 0, i);
 #pragma unroll
@@ -219,6 +222,9 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
         }
         bar();
         // A(t+1) and W(t+1) must have landed; with A issued first and WD == 2, W(t+2) (the last pieces) keeps flying
+#ifdef VC_LW_NOWAIT   // analysis only (wrong results): how much of the loop time is the loaders' vmcnt wait?
+        if (kt + 4 < nk) {} else
+#endif
         if (VC_LW_ORDER == 0 && WD >= 2 && mored) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B_IT + NTOUCH) : "memory");
         else if (NTOUCH && mored) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NTOUCH) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

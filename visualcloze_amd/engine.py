@@ -91,7 +91,7 @@ class FluxEngine:
         self.H = geom.num_heads
         self.mlp = int(geom.hidden_size * geom.mlp_ratio)
         self._ws: Dict[tuple, Workspace] = {}
-        self.attn_variant = 1
+        self.attn_variant = 3      # 4 waves x 32 queries, persistent grid (hip.attention variants: +2 = persistent)
         self.tile_cfg = 0
         self.stream = torch.cuda.Stream(device=dev)   # capture needs a non-default stream
 

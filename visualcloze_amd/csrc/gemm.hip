@@ -39,6 +39,13 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
+#ifdef VC_GEMM_TIMESTAMPS   // profiling builds only (tools/gemm_phases.py): entry / loop start / loop end / pass 1 / exit per block
+  uint64_t* pts = (args.debug_ts && tid == 0) ? args.debug_ts + 8192 + (size_t)blockIdx.x * 8 : nullptr;
+  if (pts) pts[0] = __builtin_amdgcn_s_memtime();
+#define VC_PHASE_STAMP(i) do { if (pts) pts[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define VC_PHASE_STAMP(i) do {} while (0)
+#endif
 
   // ---- which tile ----
   int id = xcd_remap(blockIdx.x, gridDim.x);
@@ -97,8 +104,10 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
     for (int i = 0; i < B_IT; ++i)   // 256x288: the last sweep covers half a tile's worth -> waves 0-3 only (wave-uniform)
       if (B_CH % NS == 0 || i * NS + swave * 64 < B_CH) glds16(Wb + b_off[i] + k0, sb + (i * NS + swave * 64) * 16);
   };
-  // PP == 2 (loader waves): A lives in a 2-deep ring, W in a 3-deep ring (2*A_BYTES + 3*B_BYTES = 136 KB for 256x192)
+  // PP == 2 (loader waves): A lives in a 2-deep ring, W in a 3-deep ring (2*A_BYTES + 3*B_BYTES = 136 KB for 256x192),
+  // followed by 1 KB of scratch (L2-touch experiments) and the tile's bias slice
   constexpr int W_RING0 = 2 * A_BYTES;
+  constexpr int LW_BIAS_OFF = 2 * A_BYTES + 3 * B_BYTES + 1024;
   auto stage_a_piece = [&](int slot, int k0, int i) { glds16(Ab + a_off[i] + k0, smem + slot * A_BYTES + (i * NS + swave * 64) * 16); };
   auto stage_w_piece = [&](int slot, int k0, int i) { glds16(Wb + b_off[i] + k0, smem + W_RING0 + slot * B_BYTES + (i * NS + swave * 64) * 16); };
 
@@ -171,12 +180,21 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
 #define VC_LW_P1 ((NPIECE - P0 + 1) / 2)
 #endif
     constexpr int WD = VC_LW_WD;                        // W is issued WD tiles ahead into a ring of WD+1 slots
+    static_assert(WD <= 2, "LDS layout reserves 3 W slots");
     constexpr int P0 = VC_LW_P0, P1 = VC_LW_P1;         // pieces issued in intervals 4t / 4t+1 (the rest in 4t+2)
     constexpr int TOUCH = VC_LW_TOUCH, NTOUCH = TOUCH > 0 ? 1 : 0;
     if (wave >= NCW) {
 #ifdef VC_LW_LPRIO
       __builtin_amdgcn_s_setprio(VC_LW_LPRIO);
 #endif
+      // the tile's bias slice goes to LDS now (zeros where there is none): epilogue pass 1 then needs no global load
+      // between the last MFMA and its first LDS write (24 dependent 8-B loads cost ~3 us per block there)
+      if (stid < BN / 4) {
+        const int col = stid * 4;
+        u32x2 bb = {0u, 0u};
+        if (P.bias && n0 + col < N) bb = *(const u32x2*)((const bf16_t*)P.bias + n0 + col);
+        *(u32x2*)(smem + LW_BIAS_OFF + col * 2) = bb;
+      }
 #pragma unroll
       for (int i = 0; i < A_IT; ++i) stage_a_piece(0, 0, i);
 #pragma unroll
@@ -185,7 +203,7 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
 #pragma unroll
           for (int i = 0; i < B_IT; ++i) stage_w_piece(d, d * BK, i);
         }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       bar();
       int wsd = WD;                                     // W slot of tile kt+WD
       // optional L2 touch: one lane per 128-B line of A(t+TOUCH)
@@ -235,6 +253,7 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
     } else {
       const int grp = wave >> 2;
       bar();
+      VC_PHASE_STAMP(1);
       if (grp == 1) bar();
       int ws = 0;                                       // W slot of tile kt
       for (int kt = 0; kt < nk; ++kt) {
@@ -345,6 +364,7 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
     if (grp == 0) bar();
   }
 
+  VC_PHASE_STAMP(2);
   // ---- epilogue, pass 1: lane holds C[m = ..+fr][n = ..+fq*4 .. +3]; t = bf16(acc + bias) -> LDS tile ----
   // (the K loop ended on a barrier, so the staging buffers are free).  Rows are padded by 16 B: the 16 rows a
   // ds_write_b64 lane group touches then land on distinct bank pairs (2-way at worst).
@@ -358,7 +378,10 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
     for (int j = 0; j < NI; ++j) {
       const int col = wn * TN + j * 16 + fq * 4;
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      if (bias && n0 + col < N) {
+      if (PP == 2) {
+        const u32x2 bb = *(const u32x2*)(smem + LW_BIAS_OFF + col * 2);
+        v[0] += lo_bf(bb[0]); v[1] += hi_bf(bb[0]); v[2] += lo_bf(bb[1]); v[3] += hi_bf(bb[1]);
+      } else if (bias && n0 + col < N) {
         const u32x2 bb = *(const u32x2*)(bias + n0 + col);
         v[0] += lo_bf(bb[0]); v[1] += hi_bf(bb[0]); v[2] += lo_bf(bb[1]); v[3] += hi_bf(bb[1]);
       }
@@ -369,6 +392,7 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
     }
   }
   __syncthreads();
+  VC_PHASE_STAMP(3);
 
   // ---- pass 2: row-major, 16 B per lane, whole rows per wave-instruction -> coalesced HBM traffic ----
   bf16_t* __restrict__ C = (bf16_t*)P.C;
@@ -377,7 +401,10 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
   long gate_step = 0;
   if (EPI == VC_EPI_GATE_RES && args.step_ptr) gate_step = (long)(*args.step_ptr) * args.gate_step_stride;
   constexpr int CPR = BN / 8;  // 16-B chunks per tile row
-#pragma unroll 4
+#ifndef VC_EPI_UNROLL
+#define VC_EPI_UNROLL 4
+#endif
+#pragma unroll VC_EPI_UNROLL
   for (int c = tid; c < BM * CPR; c += NT) {
     const int row = c / CPR, cc = c % CPR;
     const int m = m0 + row, n = n0 + cc * 8;
@@ -403,12 +430,13 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
     }
     *(u32x4*)(C + crow + n) = o;
   }
+  VC_PHASE_STAMP(4);
 }
 
 template <int BM, int BN, int WM, int WN, int PP>
 hipError_t launch_cfg(const VcGemmArgs& a, int total_tiles, hipStream_t s) {
   constexpr int NT = (WM * WN + (PP == 2 ? 4 : 0)) * 64;
-  constexpr int LDS_STAGES = (PP == 2 ? 2 * BM + 3 * BN : 2 * (BM + BN)) * BK * 2 + (PP == 2 ? 1024 : 0), LDS_EPI = BM * (BN * 2 + 16);
+  constexpr int LDS_STAGES = (PP == 2 ? 2 * BM + 3 * BN : 2 * (BM + BN)) * BK * 2 + (PP == 2 ? 1024 + BN * 2 : 0), LDS_EPI = BM * (BN * 2 + 16);
   constexpr int LDS = LDS_STAGES > LDS_EPI ? LDS_STAGES : LDS_EPI;
   void (*fn)(const VcGemmArgs) = nullptr;
   switch (a.epi) {

@@ -55,10 +55,7 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
     if (q < args.nprob && id >= args.p[q].tile_start) pi = q;
   const VcGemmProblem P = pi == 3 ? args.p[3] : pi == 2 ? args.p[2] : pi == 1 ? args.p[1] : args.p[0];
   id -= P.tile_start;
-#ifndef VC_GROUP_M
-#define VC_GROUP_M 8
-#endif
-  constexpr int GROUP_M = VC_GROUP_M;
+  constexpr int GROUP_M = 8;
   const int in_group = GROUP_M * P.tiles_n;
   const int group = id / in_group;
   const int first_m = group * GROUP_M;
@@ -105,9 +102,9 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
       if (B_CH % NS == 0 || i * NS + swave * 64 < B_CH) glds16(Wb + b_off[i] + k0, sb + (i * NS + swave * 64) * 16);
   };
   // PP == 2 (loader waves): A lives in a 2-deep ring, W in a 3-deep ring (2*A_BYTES + 3*B_BYTES = 136 KB for 256x192),
-  // followed by 1 KB of scratch (L2-touch experiments) and the tile's bias slice
+  // followed by the tile's bias slice
   constexpr int W_RING0 = 2 * A_BYTES;
-  constexpr int LW_BIAS_OFF = 2 * A_BYTES + 3 * B_BYTES + 1024;
+  constexpr int LW_BIAS_OFF = 2 * A_BYTES + 3 * B_BYTES;
   auto stage_a_piece = [&](int slot, int k0, int i) { glds16(Ab + a_off[i] + k0, smem + slot * A_BYTES + (i * NS + swave * 64) * 16); };
   auto stage_w_piece = [&](int slot, int k0, int i) { glds16(Wb + b_off[i] + k0, smem + W_RING0 + slot * B_BYTES + (i * NS + swave * 64) * 16); };
 
@@ -164,29 +161,9 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
       __builtin_amdgcn_sched_barrier(0);
     };
     constexpr int NPIECE = A_IT + B_IT;                 // wave-instructions per loader wave per K-tile
-#ifndef VC_LW_TOUCH
-#define VC_LW_TOUCH 0
-#endif
-#ifndef VC_LW_WD
-#define VC_LW_WD 2
-#endif
-#ifndef VC_LW_ORDER
-#define VC_LW_ORDER 0
-#endif
-#ifndef VC_LW_P0
-#define VC_LW_P0 ((NPIECE + 2) / 3)
-#endif
-#ifndef VC_LW_P1
-#define VC_LW_P1 ((NPIECE - P0 + 1) / 2)
-#endif
-    constexpr int WD = VC_LW_WD;                        // W is issued WD tiles ahead into a ring of WD+1 slots
-    static_assert(WD <= 2, "LDS layout reserves 3 W slots");
-    constexpr int P0 = VC_LW_P0, P1 = VC_LW_P1;         // pieces issued in intervals 4t / 4t+1 (the rest in 4t+2)
-    constexpr int TOUCH = VC_LW_TOUCH, NTOUCH = TOUCH > 0 ? 1 : 0;
+    constexpr int P0 = (NPIECE + 2) / 3, P1 = (NPIECE - P0 + 1) / 2;   // pieces issued in intervals 4t / 4t+1 (rest: 4t+2)
+    constexpr int WD = 2;                               // W is issued WD tiles ahead into a ring of WD+1 slots
     if (wave >= NCW) {
-#ifdef VC_LW_LPRIO
-      __builtin_amdgcn_s_setprio(VC_LW_LPRIO);
-#endif
       // the tile's bias slice goes to LDS now (zeros where there is none): epilogue pass 1 then needs no global load
       // between the last MFMA and its first LDS write (24 dependent 8-B loads cost ~3 us per block there)
       if (stid < BN / 4) {
@@ -206,24 +183,20 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       bar();
       int wsd = WD;                                     // W slot of tile kt+WD
-      // optional L2 touch: one lane per 128-B line of A(t+TOUCH)
-      const int trow = min(m0 + stid, M - 1);
-      const uint32_t t_off = P.a_rpb > 0 ? (uint32_t)(trow / P.a_rpb) * (uint32_t)P.a_bstride + (uint32_t)(trow % P.a_rpb) * (uint32_t)P.lda
-                                         : (uint32_t)trow * (uint32_t)P.lda;
       for (int kt = 0; kt < nk; ++kt) {
         const int as1 = (kt & 1) ^ 1, k1 = (kt + 1) * BK, kd = (kt + WD) * BK;
         const bool more1 = kt + 1 < nk, mored = kt + WD < nk;
+        // piece j of round t: j < A_IT -> A(t+1) piece j, else W(t+2) piece j - A_IT
         auto piece = [&](int j) {
-#ifdef VC_GEMM_NO_DMA
+#ifdef VC_GEMM_NO_DMA     // analysis builds only: core side of the loop alone
           return;
 #endif
-          const int ja = VC_LW_ORDER == 0 ? j : j - B_IT, jw = VC_LW_ORDER == 0 ? j - A_IT : j;
 #pragma unroll
           for (int i = 0; i < A_IT; ++i)
-            if (ja == i && more1) stage_a_piece(as1, k1, i);
+            if (j == i && more1) stage_a_piece(as1, k1, i);
 #pragma unroll
           for (int i = 0; i < B_IT; ++i)
-            if (jw == i && mored) stage_w_piece(wsd, kd, i);
+            if (j == A_IT + i && mored) stage_w_piece(wsd, kd, i);
         };
 #pragma unroll
         for (int j = 0; j < P0; ++j) piece(j);
@@ -233,18 +206,9 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
         bar();
 #pragma unroll
         for (int j = P0 + P1; j < NPIECE; ++j) piece(j);
-        if (TOUCH > 0 && mored) {
-          // 4-B LDS-DMA into a scratch row: a load with no VGPR destination to keep alive
-          __builtin_amdgcn_global_load_lds((gptr_t)(Ab + t_off + min(kt + TOUCH, nk - 1) * BK),
-                                           (lptr_t)(smem + 2 * A_BYTES + (WD + 1) * B_BYTES + swave * 256), 4, 0, 0);
-        }
         bar();
-        // A(t+1) and W(t+1) must have landed; with A issued first and WD == 2, W(t+2) (the last pieces) keeps flying
-#ifdef VC_LW_NOWAIT   // analysis only (wrong results): how much of the loop time is the loaders' vmcnt wait?
-        if (kt + 4 < nk) {} else
-#endif
-        if (VC_LW_ORDER == 0 && WD >= 2 && mored) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B_IT + NTOUCH) : "memory");
-        else if (NTOUCH && mored) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NTOUCH) : "memory");
+        // A(t+1) and W(t+1) must have landed; W(t+2) - the last B_IT pieces issued - keeps flying
+        if (mored) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B_IT) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         bar();
         wsd = wsd == WD ? 0 : wsd + 1;
@@ -401,10 +365,7 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
   long gate_step = 0;
   if (EPI == VC_EPI_GATE_RES && args.step_ptr) gate_step = (long)(*args.step_ptr) * args.gate_step_stride;
   constexpr int CPR = BN / 8;  // 16-B chunks per tile row
-#ifndef VC_EPI_UNROLL
-#define VC_EPI_UNROLL 4
-#endif
-#pragma unroll VC_EPI_UNROLL
+#pragma unroll 4
   for (int c = tid; c < BM * CPR; c += NT) {
     const int row = c / CPR, cc = c % CPR;
     const int m = m0 + row, n = n0 + cc * 8;
@@ -436,7 +397,7 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
 template <int BM, int BN, int WM, int WN, int PP>
 hipError_t launch_cfg(const VcGemmArgs& a, int total_tiles, hipStream_t s) {
   constexpr int NT = (WM * WN + (PP == 2 ? 4 : 0)) * 64;
-  constexpr int LDS_STAGES = (PP == 2 ? 2 * BM + 3 * BN : 2 * (BM + BN)) * BK * 2 + (PP == 2 ? 1024 + BN * 2 : 0), LDS_EPI = BM * (BN * 2 + 16);
+  constexpr int LDS_STAGES = (PP == 2 ? 2 * BM + 3 * BN : 2 * (BM + BN)) * BK * 2 + (PP == 2 ? BN * 2 : 0), LDS_EPI = BM * (BN * 2 + 16);
   constexpr int LDS = LDS_STAGES > LDS_EPI ? LDS_STAGES : LDS_EPI;
   void (*fn)(const VcGemmArgs) = nullptr;
   switch (a.epi) {

@@ -26,5 +26,19 @@ for (M, N, K, epi) in [(3968, 3072, 3072, 2), (3968, 9216, 3072, 0), (3968, 1228
     for name, i, j in [("entry (rel. first block)", None, 0), ("prologue  entry->loop", 0, 1), ("main loop", 1, 2), ("epilogue pass 1", 2, 3), ("epilogue pass 2", 3, 4)]:
         v = rel[:, j] if i is None else (t[:, j] - t[:, i])
         print(f"   {name:26s} mean {float(v.mean()):9.0f}  min {float(v.min()):9.0f}  max {float(v.max()):9.0f}")
-    first = rel[:256]
-    print(f"   first round exits at mean {float(first[:, 4].mean()):.0f}; second-round entries (if any) mean {float(rel[256:512, 0].mean()) if nblk > 256 else float('nan'):.0f}")
+    # same-CU succession: HW_ID (cu_id bits 8-11, sh 12, se 13-15 on gfx9) + XCC_ID identify the CU; s_memtime is per XCD
+    ids = ts[8192:].view(nblk, 8)[:, 5].cpu()
+    key = [(int(x) >> 32, (int(x) & 0xffffffff) >> 8 & 0xff) for x in ids]
+    bycu = {}
+    for b in range(nblk):
+        bycu.setdefault(key[b], []).append((float(t[b, 0]), float(t[b, 4]), b))
+    gaps = []
+    for k, lst in bycu.items():
+        lst.sort()
+        for i in range(1, len(lst)):
+            gaps.append(lst[i][0] - lst[i - 1][1])
+    if gaps:
+        g = torch.tensor(gaps)
+        print(f"   {len(bycu)} distinct CUs; exit -> next block's entry on the same CU: mean {float(g.mean()):.0f} median {float(g.median()):.0f} min {float(g.min()):.0f} max {float(g.max()):.0f} cycles ({len(gaps)} successions)")
+    else:
+        print(f"   {len(bycu)} distinct CUs, one block each")

@@ -38,6 +38,21 @@ VC_DEV float gelu_tanh(float x) {
   const float e = __builtin_amdgcn_exp2f(-2.0f * 1.4426950408889634f * u);
   return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
+// two at a time: the polynomial part maps onto v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 (one issue slot per PAIR), only
+// the exp and the rcp stay per element.  arg = -2*log2(e)*u = x * (kA + kB*x^2).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+VC_DEV f32x2 gelu_tanh2(f32x2 x) {
+  const float kA = -2.0f * 1.4426950408889634f * 0.7978845608028654f, kB = kA * 0.044715f;
+  const f32x2 a = (x * x * kB + kA) * x;
+  f32x2 d;
+  d[0] = __builtin_amdgcn_exp2f(a[0]);
+  d[1] = __builtin_amdgcn_exp2f(a[1]);
+  d = d + 1.0f;
+  f32x2 r;
+  r[0] = __builtin_amdgcn_rcpf(d[0]);
+  r[1] = __builtin_amdgcn_rcpf(d[1]);
+  return x * r;
+}
 VC_DEV float silu_f(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }

@@ -41,7 +41,10 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
   const int wm = wave / WN, wn = wave % WN;
 #ifdef VC_GEMM_TIMESTAMPS   // profiling builds only (tools/gemm_phases.py): entry / loop start / loop end / pass 1 / exit per block
   uint64_t* pts = (args.debug_ts && tid == 0) ? args.debug_ts + 8192 + (size_t)blockIdx.x * 8 : nullptr;
-  if (pts) pts[0] = __builtin_amdgcn_s_memtime();
+  if (pts) {
+    pts[0] = __builtin_amdgcn_s_memtime();
+    pts[5] = ((uint64_t)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) | (uint32_t)__builtin_amdgcn_s_getreg(4 | (31 << 11));   // XCC_ID, HW_ID
+  }
 #define VC_PHASE_STAMP(i) do { if (pts) pts[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define VC_PHASE_STAMP(i) do {} while (0)
@@ -378,7 +381,10 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
     u32x4 o = tw;
     if (EPI == VC_EPI_GELU) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = pack2bf(gelu_tanh(v[2 * e]), gelu_tanh(v[2 * e + 1]));
+      for (int e = 0; e < 4; ++e) {
+        const f32x2 g = gelu_tanh2(f32x2{v[2 * e], v[2 * e + 1]});
+        o[e] = pack2bf(g[0], g[1]);
+      }
     } else if (EPI == VC_EPI_SILU) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = pack2bf(silu_f(v[2 * e]), silu_f(v[2 * e + 1]));

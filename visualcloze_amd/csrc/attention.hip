@@ -42,6 +42,7 @@ template <int NW>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs a) {
   constexpr int NT = NW * 64;
   constexpr int K_IT = (K_TILE / 16) / NT, V_IT = (V_TILE / 16) / NT;
+  constexpr int DMA_EVERY = 16 / (K_IT + V_IT);
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
@@ -79,6 +80,20 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs a) 
     const int d = c >> 3;
     v_off[i] = (uint32_t)d * (uint32_t)a.Lpad + ((((c & 7) ^ ((d >> 1) & 7))) << 3);
   }
+  // one LDS-DMA wave-instruction of tile kt: i < K_IT -> K piece i, else V piece i - K_IT
+  auto stage_piece = [&](int buf, int kt, int i) {
+    char* sk = smem + buf * STAGE;
+    char* sv = sk + K_TILE;
+#pragma unroll
+    for (int j = 0; j < K_IT; ++j)
+      if (i == j) {
+        const int key = min(kt * KVB + (int)k_row[j], L - 1);
+        glds16(kbase + (long)key * a.ld + k_col[j], sk + (j * NT + wave * 64) * 16);
+      }
+#pragma unroll
+    for (int j = 0; j < V_IT; ++j)
+      if (i == K_IT + j) glds16(vbase + v_off[j] + kt * KVB, sv + (j * NT + wave * 64) * 16);
+  };
   auto stage = [&](int buf, int kt) {
     char* sk = smem + buf * STAGE;
     char* sv = sk + K_TILE;
@@ -135,9 +150,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs a) 
   for (int kt = 0; kt < nkt; ++kt) {
     const int cur = kt & 1;
     stamp();
-#ifndef VC_ATTN_NO_DMA      // analysis builds only (wrong results): the loop without its LDS-DMA
-    if (kt + 1 < nkt) stage(cur ^ 1, kt + 1);
-#endif
+    // Tile kt+1's LDS-DMA pieces (8 per wave with 4 waves, 4 with 8) go out one behind every DMA_EVERY-th QK^T MFMA: an
+    // LDS-DMA wave-instruction holds the issue slot for ~75 cycles, and issued back to back at the top of the tile
+    // (600 cycles without an MFMA from this wave) they cost 5 % of the kernel.  The last tile re-stages itself into the idle buffer so the body stays free
+    // of branches (sched_group_barrier pins issue order only inside one basic block).
+    const int ktn = min(kt + 1, nkt - 1);
     const char* base = smem + cur * STAGE;
 
     // S^T = K . Q^T.  Fragment reads run one 8-deep batch AHEAD of the MFMAs that consume them (rotating register
@@ -153,12 +170,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs a) 
     for (int t = 0; t < 8; ++t) {
       s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr8[t], qf[t], s[0], 0, 0, 0);
       fr8[t] = *(const bf16x8*)(base + (k_rd[1] ^ (t * 32)));
+#ifndef VC_ATTN_NO_DMA      // analysis builds only (wrong results): the loop without its LDS-DMA
+      if (t % DMA_EVERY == 0) stage_piece(cur ^ 1, ktn, t / DMA_EVERY);
+#endif
     }
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr8[t], qf[t], s[1], 0, 0, 0);
       // V fragments of d-tiles 0,1 (k-steps 0..3 each) land while the softmax VALU work runs
       fr8[t] = *(const bf16x8*)(base + (v_rd[t >> 2] ^ ((t & 3) * 32)));
+#ifndef VC_ATTN_NO_DMA
+      if ((t + 8) % DMA_EVERY == 0) stage_piece(cur ^ 1, ktn, (t + 8) / DMA_EVERY);
+#endif
     }
     // pin the issue order (hipcc otherwise sinks every read next to its MFMA): 8 reads, then MFMA/read pairs
     __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
@@ -166,6 +189,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs a) 
     for (int t = 0; t < 16; ++t) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#ifndef VC_ATTN_NO_DMA
+      if (t % DMA_EVERY == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+#endif
     }
     stamp();
     // mask keys beyond kv_len (only the last tile can hold any)

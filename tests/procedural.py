@@ -75,3 +75,25 @@ def tiny_inputs(B: int = 1, rows_hw=((4, 12), (4, 12)), T: int = 16, seed: int =
         txt_mask=torch.ones(B, T, dtype=torch.int32), img_mask=torch.ones(B, N, dtype=torch.int32),
         guidance=torch.full((B,), 30.0),
     )
+
+
+# ---- VAE decoder: tiny geometry with every channel count a multiple of 64 ----
+TINY_AE = dict(resolution=16, in_channels=3, ch=64, out_ch=3, ch_mult=[1, 2], num_res_blocks=1, z_channels=4,
+               scale_factor=0.3611, shift_factor=0.1159)
+
+
+def procedural_ae_param(key: str, shape) -> torch.Tensor:
+    """Weight for an AutoEncoder state-dict entry (conv [O,I,k,k] / GroupNorm affine), exactly representable in bf16."""
+    seed = key_seed("ae:" + key)
+    shape = tuple(shape)
+    if ".norm" in key and key.endswith(".weight"):       # GroupNorm gamma ~ 1
+        return ptensor(shape, seed, q=8, kmax=64, offset=1.0)
+    if key.endswith(".bias"):
+        return ptensor(shape, seed, q=8, kmax=32)
+    fan_in = int(np.prod(shape[1:]))
+    q = int(round(math.log2(73.0 * math.sqrt(fan_in))))
+    return ptensor(shape, seed, q=q, kmax=127)
+
+
+def tiny_ae_latent(h: int, w: int, seed: int = 5) -> torch.Tensor:
+    return ptensor((1, TINY_AE["z_channels"], h, w), seed, q=5, kmax=96)      # |z| <= 3

@@ -76,6 +76,25 @@ int vc_step_advance(int32_t* step_ptr, void* stream) { return vc_step_advance_la
 int vc_sdedit_mix(const void* noise, const void* latent, float strength, void* out, int64_t n, void* stream) {
   return vc_sdedit_mix_launch(noise, latent, strength, out, n, S(stream), ERRBUF);
 }
+int vc_im2col3x3(const void* src, void* dst, int32_t H, int32_t W, int32_t C, int32_t up, void* stream) {
+  return vc_im2col3x3_launch(src, dst, H, W, C, up, S(stream), ERRBUF);
+}
+int vc_groupnorm(const void* x, const void* gamma, const void* beta, void* y, void* scratch, int64_t scratch_bytes,
+                 int64_t HW, int32_t C, int32_t G, float eps, int32_t swish, void* stream) {
+  return vc_groupnorm_launch(x, gamma, beta, y, scratch, scratch_bytes, HW, C, G, eps, swish, S(stream), ERRBUF);
+}
+int vc_softmax_rows(void* x, int64_t ld, int32_t rows, int32_t cols, float scale, void* stream) {
+  return vc_softmax_rows_launch(x, ld, rows, cols, scale, S(stream), ERRBUF);
+}
+int vc_transpose(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int32_t rows, int32_t cols, void* stream) {
+  return vc_transpose_launch(src, ld_src, dst, ld_dst, rows, cols, S(stream), ERRBUF);
+}
+int vc_nchw_to_nhwc(const void* src, int32_t src_is_f32, void* dst, int32_t C, int32_t Cp, int64_t HW, float div, float add, void* stream) {
+  return vc_nchw_to_nhwc_launch(src, src_is_f32, dst, C, Cp, HW, div, add, S(stream), ERRBUF);
+}
+int vc_nhwc_to_nchw(const void* src, void* dst, int32_t dst_is_f32, int32_t C, int32_t Cp, int64_t HW, void* stream) {
+  return vc_nhwc_to_nchw_launch(src, dst, dst_is_f32, C, Cp, HW, S(stream), ERRBUF);
+}
 int vc_pack_latent(const void* latent, void* tokens, int32_t C, int32_t h, int32_t w, int64_t ld, int32_t col0, void* stream) {
   return vc_pack_latent_launch(latent, tokens, C, h, w, ld, col0, S(stream), ERRBUF);
 }

@@ -24,3 +24,10 @@ int vc_pack_latent_launch(const void* in, void* out, int C, int h, int w, int64_
 int vc_pack_mask_launch(const void* in, void* out, int H, int W, int64_t ld, int col0, hipStream_t s, char* err, int errlen);
 int vc_unpack_latent_launch(const void* in, int64_t ld, int col0, void* out, int C, int h, int w, hipStream_t s, char* err, int errlen);
 int vc_sdedit_mix_launch(const void* noise, const void* latent, float strength, void* out, int64_t n, hipStream_t s, char* err, int errlen);
+int vc_im2col3x3_launch(const void* src, void* dst, int H, int W, int C, int up, hipStream_t s, char* err, int errlen);
+int vc_groupnorm_launch(const void* x, const void* gamma, const void* beta, void* y, void* scratch, int64_t scratch_bytes,
+                        int64_t HW, int C, int G, float eps, int swish, hipStream_t s, char* err, int errlen);
+int vc_softmax_rows_launch(void* x, int64_t ld, int rows, int cols, float scale, hipStream_t s, char* err, int errlen);
+int vc_transpose_launch(const void* src, int64_t lds_, void* dst, int64_t ldd, int R, int Cc, hipStream_t s, char* err, int errlen);
+int vc_nchw_to_nhwc_launch(const void* src, int src_f32, void* dst, int C, int Cp, int64_t HW, float div, float add, hipStream_t s, char* err, int errlen);
+int vc_nhwc_to_nchw_launch(const void* src, void* dst, int dst_f32, int C, int Cp, int64_t HW, hipStream_t s, char* err, int errlen);

@@ -64,6 +64,12 @@ SYMBOLS = {
     "vc_pack_latent": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _i32, _vp]),
     "vc_pack_mask": (C.c_int, [_vp, _vp, _i32, _i32, _i64, _i32, _vp]),
     "vc_unpack_latent": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _i32, _i32, _vp]),
+    "vc_im2col3x3": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "vc_groupnorm": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, C.c_float, _i32, _vp]),
+    "vc_softmax_rows": (C.c_int, [_vp, _i64, _i32, _i32, C.c_float, _vp]),
+    "vc_transpose": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _vp]),
+    "vc_nchw_to_nhwc": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i64, C.c_float, C.c_float, _vp]),
+    "vc_nhwc_to_nchw": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _vp]),
     "vc_stream_create": (C.c_int, [C.POINTER(_vp)]),
     "vc_stream_destroy": (C.c_int, [_vp]),
     "vc_stream_sync": (C.c_int, [_vp]),
@@ -301,6 +307,69 @@ def unpack_latent(tokens, latent, col0=0, stream=None):
         raise VclozeHipError("unpack_latent: contiguous [C,h,w] latent and (h/2)(w/2) token rows expected")
     _check(lib().vc_unpack_latent(tokens.data_ptr(), tokens.stride(0), col0, latent.data_ptr(), Cc, h, w,
                                   stream if stream is not None else cur_stream()), "vc_unpack_latent")
+
+
+# ---- VAE decoder glue (activations NHWC bf16 [H*W, C]) ----
+def im2col3x3(src, dst, H, W, up=False, stream=None):
+    _bf16(src, "src"); _bf16(dst, "dst")
+    Cc = src.shape[1]
+    hs, ws = (H >> 1, W >> 1) if up else (H, W)
+    if src.shape[0] != hs * ws or tuple(dst.shape) != (H * W, 9 * Cc) or not (src.is_contiguous() and dst.is_contiguous()):
+        raise VclozeHipError("im2col3x3: src [Hs*Ws, C] and dst [H*W, 9C] contiguous expected")
+    _check(lib().vc_im2col3x3(src.data_ptr(), dst.data_ptr(), H, W, Cc, int(bool(up)),
+                              stream if stream is not None else cur_stream()), "vc_im2col3x3")
+
+
+def groupnorm(x, gamma, beta, y, scratch, groups=32, eps=1e-6, swish=False, stream=None):
+    _bf16(x, "x"); _bf16(y, "y"); _bf16(gamma, "gamma"); _bf16(beta, "beta")
+    HW, Cc = x.shape
+    if not (x.is_contiguous() and y.is_contiguous()) or y.shape != x.shape or scratch.dtype != torch.float32:
+        raise VclozeHipError("groupnorm: contiguous [HW, C] x, y and an f32 scratch tensor expected")
+    _check(lib().vc_groupnorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), scratch.data_ptr(),
+                              scratch.numel() * 4, HW, Cc, groups, eps, int(bool(swish)),
+                              stream if stream is not None else cur_stream()), "vc_groupnorm")
+
+
+def groupnorm_scratch_floats(HW, groups=32):
+    return ((HW + 127) // 128 + 1) * 2 * groups
+
+
+def softmax_rows(x, scale, stream=None):
+    _bf16(x, "x")
+    if x.dim() != 2 or x.stride(1) != 1:
+        raise VclozeHipError("softmax_rows: 2-D tensor with contiguous rows expected")
+    _check(lib().vc_softmax_rows(x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], scale,
+                                 stream if stream is not None else cur_stream()), "vc_softmax_rows")
+
+
+def transpose(src, dst, stream=None):
+    _bf16(src, "src"); _bf16(dst, "dst")
+    if src.dim() != 2 or src.stride(1) != 1 or dst.stride(1) != 1 or tuple(dst.shape) != (src.shape[1], src.shape[0]):
+        raise VclozeHipError("transpose: [R, C] -> [C, R] with contiguous rows expected")
+    _check(lib().vc_transpose(src.data_ptr(), src.stride(0), dst.data_ptr(), dst.stride(0), src.shape[0], src.shape[1],
+                              stream if stream is not None else cur_stream()), "vc_transpose")
+
+
+def nchw_to_nhwc(src, dst, div=1.0, add=0.0, stream=None):
+    _bf16(dst, "dst")
+    if src.dtype not in (torch.float32, torch.bfloat16) or not (src.is_contiguous() and dst.is_contiguous()):
+        raise VclozeHipError("nchw_to_nhwc: contiguous f32/bf16 [C, H, W] source expected")
+    Cc, HW = src.shape[0], src[0].numel()
+    if dst.shape[0] != HW or dst.shape[1] < Cc:
+        raise VclozeHipError("nchw_to_nhwc: dst [H*W, Cp >= C] expected")
+    _check(lib().vc_nchw_to_nhwc(src.data_ptr(), int(src.dtype == torch.float32), dst.data_ptr(), Cc, dst.shape[1], HW,
+                                 div, add, stream if stream is not None else cur_stream()), "vc_nchw_to_nhwc")
+
+
+def nhwc_to_nchw(src, dst, stream=None):
+    _bf16(src, "src")
+    if dst.dtype not in (torch.float32, torch.bfloat16) or not (src.is_contiguous() and dst.is_contiguous()):
+        raise VclozeHipError("nhwc_to_nchw: contiguous f32/bf16 [C, H, W] destination expected")
+    Cc, HW = dst.shape[0], dst[0].numel()
+    if src.shape[0] != HW or src.shape[1] < Cc:
+        raise VclozeHipError("nhwc_to_nchw: src [H*W, Cp >= C] expected")
+    _check(lib().vc_nhwc_to_nchw(src.data_ptr(), dst.data_ptr(), int(dst.dtype == torch.float32), Cc, src.shape[1], HW,
+                                 stream if stream is not None else cur_stream()), "vc_nhwc_to_nchw")
 
 
 class Graph:

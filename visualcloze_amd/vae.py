@@ -1,0 +1,269 @@
+"""FLUX AutoEncoder **decoder** on MI355X (first slice).
+
+Mirrors the reference's vendored twin `models/modules/autoencoder.py` (classes `AttnBlock` :25-52, `ResnetBlock` :55-82,
+`Upsample` :98-106, `Decoder` :183-259, `AutoEncoder.decode` :306-308): same constructor arguments, same module tree and
+therefore the same `state_dict()` keys and shapes, so `ae.safetensors` decoder weights load unchanged.  Execution is
+NHWC bf16 on the HIP library: every 3x3 convolution is an im2col gather (`vc_im2col3x3`, which also folds the nearest
+2x upsampling) followed by the bf16 MFMA GEMM with fused bias / residual epilogue, GroupNorm+swish is `vc_groupnorm`,
+the mid-block attention (one head, head_dim = C) is two GEMMs around `vc_softmax_rows`.  There is no CPU or torch
+fallback: without the GPU library `decode` raises.
+
+The diffusers `AutoencoderKL` that `visualcloze.py:100` actually instantiates is not part of /root/reference; parity is
+pinned against the vendored twin above (tests/golden/make_vae_golden.py), not against diffusers.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import torch
+from torch import nn
+
+from . import hip
+
+
+@dataclass
+class AutoEncoderParams:            # autoencoder.py:8-18
+    resolution: int = 256
+    in_channels: int = 3
+    ch: int = 128
+    out_ch: int = 3
+    ch_mult: List[int] = field(default_factory=lambda: [1, 2, 4, 4])
+    num_res_blocks: int = 2
+    z_channels: int = 16
+    scale_factor: float = 0.3611
+    shift_factor: float = 0.1159
+
+
+FLUX_AE = dict(resolution=256, in_channels=3, ch=128, out_ch=3, ch_mult=[1, 2, 4, 4], num_res_blocks=2, z_channels=16,
+               scale_factor=0.3611, shift_factor=0.1159)      # models/util.py:86-96
+
+
+def _pad_to(n: int, m: int) -> int:
+    return (n + m - 1) // m * m
+
+
+class _Conv(nn.Module):
+    """Parameter holder with nn.Conv2d's state-dict layout ([O, I, k, k] weight, [O] bias)."""
+
+    def __init__(self, cin: int, cout: int, k: int):
+        super().__init__()
+        self.cin, self.cout, self.k = cin, cout, k
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
+        self.bias = nn.Parameter(torch.empty(cout))
+        self._prep = None
+
+    def prepared(self):
+        """GEMM operands: W [O_pad8, k*k*I_pad64] bf16 with K ordered (dy, dx, c) like vc_im2col3x3's columns."""
+        key = (self.weight._version, self.bias._version, self.weight.data_ptr(), self.weight.device)
+        if self._prep is None or self._prep[0] != key:
+            w = self.weight.detach().to(torch.bfloat16)
+            cin_p, cout_p = _pad_to(self.cin, 64), _pad_to(self.cout, 8)
+            wp = torch.zeros(cout_p, self.k * self.k, cin_p, dtype=torch.bfloat16, device=w.device)
+            wp[: self.cout, :, : self.cin] = w.permute(0, 2, 3, 1).reshape(self.cout, self.k * self.k, self.cin)
+            bp = torch.zeros(cout_p, dtype=torch.bfloat16, device=w.device)
+            bp[: self.cout] = self.bias.detach().to(torch.bfloat16)
+            self._prep = (key, wp.reshape(cout_p, -1).contiguous(), bp)
+        return self._prep[1], self._prep[2]
+
+
+class _GroupNorm(nn.Module):
+    def __init__(self, c: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(c))
+        self.bias = nn.Parameter(torch.empty(c))
+
+
+class AttnBlock(nn.Module):          # autoencoder.py:25-52
+    def __init__(self, in_channels: int):
+        super().__init__()
+        self.in_channels = in_channels
+        self.norm = _GroupNorm(in_channels)
+        self.q = _Conv(in_channels, in_channels, 1)
+        self.k = _Conv(in_channels, in_channels, 1)
+        self.v = _Conv(in_channels, in_channels, 1)
+        self.proj_out = _Conv(in_channels, in_channels, 1)
+
+
+class ResnetBlock(nn.Module):        # autoencoder.py:55-82
+    def __init__(self, in_channels: int, out_channels: Optional[int]):
+        super().__init__()
+        self.in_channels = in_channels
+        out_channels = in_channels if out_channels is None else out_channels
+        self.out_channels = out_channels
+        self.norm1 = _GroupNorm(in_channels)
+        self.conv1 = _Conv(in_channels, out_channels, 3)
+        self.norm2 = _GroupNorm(out_channels)
+        self.conv2 = _Conv(out_channels, out_channels, 3)
+        if self.in_channels != self.out_channels:
+            self.nin_shortcut = _Conv(in_channels, out_channels, 1)
+
+
+class Upsample(nn.Module):           # autoencoder.py:98-106
+    def __init__(self, in_channels: int):
+        super().__init__()
+        self.conv = _Conv(in_channels, in_channels, 3)
+
+
+class Decoder(nn.Module):            # autoencoder.py:183-259
+    def __init__(self, ch: int, out_ch: int, ch_mult: List[int], num_res_blocks: int, in_channels: int, resolution: int,
+                 z_channels: int):
+        super().__init__()
+        self.ch, self.out_ch, self.z_channels = ch, out_ch, z_channels
+        self.num_resolutions = len(ch_mult)
+        self.num_res_blocks = num_res_blocks
+        self.resolution, self.in_channels = resolution, in_channels
+        self.ffactor = 2 ** (self.num_resolutions - 1)
+        block_in = ch * ch_mult[self.num_resolutions - 1]
+        self.conv_in = _Conv(z_channels, block_in, 3)
+        self.mid = nn.Module()
+        self.mid.block_1 = ResnetBlock(block_in, block_in)
+        self.mid.attn_1 = AttnBlock(block_in)
+        self.mid.block_2 = ResnetBlock(block_in, block_in)
+        self.up = nn.ModuleList()
+        for i_level in reversed(range(self.num_resolutions)):
+            block = nn.ModuleList()
+            block_out = ch * ch_mult[i_level]
+            for _ in range(self.num_res_blocks + 1):
+                block.append(ResnetBlock(block_in, block_out))
+                block_in = block_out
+            up = nn.Module()
+            up.block = block
+            up.attn = nn.ModuleList()
+            if i_level != 0:
+                up.upsample = Upsample(block_in)
+            self.up.insert(0, up)
+        self.norm_out = _GroupNorm(block_in)
+        self.conv_out = _Conv(block_in, out_ch, 3)
+
+    # ------------------------------------------------------------------ execution (NHWC bf16 on the HIP library)
+    def _scratch(self, dev, name, shape, dtype=torch.bfloat16):
+        pool = self.__dict__.setdefault("_pool", {})
+        t = pool.get(name)
+        n = 1
+        for s in shape:
+            n *= s
+        if t is None or t.numel() < n or t.dtype != dtype or t.device != dev:
+            t = torch.empty(n, dtype=dtype, device=dev)
+            pool[name] = t
+        return t[:n].view(*shape)
+
+    def _conv3(self, conv: _Conv, x, H, W, out, up=False, res=None):
+        """out[H*W, O_pad] = conv3x3(x) (+ res); x is [Hs*Ws, I_pad64]."""
+        w, b = conv.prepared()
+        col = self._scratch(x.device, "col", (H * W, 9 * x.shape[1]))
+        hip.im2col3x3(x, col, H, W, up=up)
+        self._gemm(col, w, b, out, res)
+
+    def _conv1(self, conv: _Conv, x, out, res=None):
+        w, b = conv.prepared()
+        self._gemm(x, w, b, out, res)
+
+    def _gemm(self, a, w, b, out, res):
+        if res is None:
+            hip.gemm(hip.make_problem(a, w, b, out), epi=hip.EPI_BIAS)
+        else:   # x + h (autoencoder.py:82, :52): the gated-residual epilogue with a gate of ones
+            ones = self._scratch(a.device, "ones%d" % out.shape[1], (out.shape[1],))
+            ones.fill_(1.0)
+            hip.gemm(hip.make_problem(a, w, b, out, res=res, gate=ones, rows_per_batch=a.shape[0]), epi=hip.EPI_GATE_RES)
+
+    def _norm(self, gn: _GroupNorm, x, y, swish):
+        sc = self._scratch(x.device, "gn", (hip.groupnorm_scratch_floats(x.shape[0]),), torch.float32)
+        hip.groupnorm(x, gn.weight.detach().to(torch.bfloat16), gn.bias.detach().to(torch.bfloat16), y, sc, swish=swish)
+
+    def _resnet(self, blk: ResnetBlock, x, H, W, tag):
+        dev, HW = x.device, H * W
+        t = self._scratch(dev, "t0", (HW, blk.in_channels))
+        self._norm(blk.norm1, x, t, True)
+        h = self._scratch(dev, "t1", (HW, blk.out_channels))
+        self._conv3(blk.conv1, t, H, W, h)
+        t2 = self._scratch(dev, "t2", (HW, blk.out_channels))
+        self._norm(blk.norm2, h, t2, True)
+        if blk.in_channels != blk.out_channels:
+            sc = self._scratch(dev, "t3", (HW, blk.out_channels))
+            self._conv1(blk.nin_shortcut, x, sc)
+            x = sc
+        out = self._scratch(dev, "x" + tag, (HW, blk.out_channels))
+        self._conv3(blk.conv2, t2, H, W, out, res=x)
+        return out
+
+    def _attn(self, blk: AttnBlock, x, tag):
+        dev, (L, Cc) = x.device, x.shape
+        t = self._scratch(dev, "t0", (L, Cc))
+        self._norm(blk.norm, x, t, False)
+        q, k, v = (self._scratch(dev, n, (L, Cc)) for n in ("aq", "ak", "av"))
+        self._conv1(blk.q, t, q); self._conv1(blk.k, t, k); self._conv1(blk.v, t, v)
+        if L % 8:
+            raise hip.VclozeHipError(f"AttnBlock: h*w = {L} must be a multiple of 8")
+        Lp = _pad_to(L, 64)                                  # K of the P.V GEMM; the pad columns of P and V^T stay zero
+        s = self._scratch(dev, "as", (L, Lp))
+        if Lp != L:
+            s.zero_()
+        hip.gemm(hip.make_problem(q, k, None, s[:, :L]), epi=hip.EPI_BIAS)                  # S = Q K^T  [L, L]
+        hip.softmax_rows(s[:, :L], float(Cc) ** -0.5)
+        vt = self._scratch(dev, "avt", (Cc, Lp))
+        if Lp != L:
+            vt.zero_()
+        hip.transpose(v, vt[:, :L])
+        o = self._scratch(dev, "ao", (L, Cc))
+        hip.gemm(hip.make_problem(s, vt, None, o), epi=hip.EPI_BIAS)                        # O = P V
+        out = self._scratch(dev, "x" + tag, (L, Cc))
+        self._conv1(blk.proj_out, o, out, res=x)
+        return out
+
+    def forward(self, z: torch.Tensor) -> torch.Tensor:
+        """z: [B, z_channels, h, w] (f32 or bf16) -> image [B, out_ch, 8h, 8w] bf16 (the reference's Decoder.forward)."""
+        hip.require_gpu()
+        if z.dim() != 4 or z.shape[1] != self.z_channels:
+            raise ValueError(f"Decoder expects [B, {self.z_channels}, h, w], got {tuple(z.shape)}")
+        outs = []
+        for zi in z:
+            outs.append(self._decode_one(zi.contiguous(), 1.0, 0.0))
+        return torch.stack(outs)
+
+    def _decode_one(self, z, div, add):
+        dev = z.device
+        _, h, w = z.shape
+        H, W = h, w
+        x0 = self._scratch(dev, "zin", (H * W, _pad_to(self.z_channels, 64)))
+        hip.nchw_to_nhwc(z, x0, div, add)
+        cur = self._scratch(dev, "xa", (H * W, self.conv_in.cout))
+        self._conv3(self.conv_in, x0, H, W, cur)
+        flip = ["b", "a"]
+        k = 0
+        cur = self._resnet(self.mid.block_1, cur, H, W, flip[k & 1]); k += 1
+        cur = self._attn(self.mid.attn_1, cur, flip[k & 1]); k += 1
+        cur = self._resnet(self.mid.block_2, cur, H, W, flip[k & 1]); k += 1
+        for i_level in reversed(range(self.num_resolutions)):
+            for blk in self.up[i_level].block:
+                cur = self._resnet(blk, cur, H, W, flip[k & 1]); k += 1
+            if i_level != 0:
+                H, W = 2 * H, 2 * W
+                nxt = self._scratch(dev, "x" + flip[k & 1], (H * W, cur.shape[1])); k += 1
+                self._conv3(self.up[i_level].upsample.conv, cur, H, W, nxt, up=True)
+                cur = nxt
+        t = self._scratch(dev, "t0", (H * W, cur.shape[1]))
+        self._norm(self.norm_out, cur, t, True)
+        y = self._scratch(dev, "yout", (H * W, _pad_to(self.out_ch, 8)))
+        self._conv3(self.conv_out, t, H, W, y)
+        img = torch.empty(self.out_ch, H, W, dtype=torch.bfloat16, device=dev)
+        hip.nhwc_to_nchw(y, img)
+        return img
+
+
+class AutoEncoderDecoder(nn.Module):
+    """`AutoEncoder` restricted to its decode path (autoencoder.py:277-308); `decoder.*` keys as in ae.safetensors."""
+
+    def __init__(self, params: AutoEncoderParams):
+        super().__init__()
+        self.decoder = Decoder(resolution=params.resolution, in_channels=params.in_channels, ch=params.ch,
+                               out_ch=params.out_ch, ch_mult=params.ch_mult, num_res_blocks=params.num_res_blocks,
+                               z_channels=params.z_channels)
+        self.scale_factor = params.scale_factor
+        self.shift_factor = params.shift_factor
+
+    def decode(self, z: torch.Tensor) -> torch.Tensor:
+        hip.require_gpu()
+        if z.dim() != 4 or z.shape[1] != self.decoder.z_channels:
+            raise ValueError(f"decode expects [B, {self.decoder.z_channels}, h, w], got {tuple(z.shape)}")
+        return torch.stack([self.decoder._decode_one(zi.contiguous(), self.scale_factor, self.shift_factor) for zi in z])

@@ -125,8 +125,10 @@ int vc_unpack_latent(const void* tokens, int64_t ld, int32_t col0, void* latent,
 /* ---- VAE decoder glue (reference twin models/modules/autoencoder.py): activations are NHWC bf16
  * [H*W, C], C % 8 == 0; the 3x3 convolutions and 1x1 projections themselves are vc_gemm over these buffers. ----
  * im2col3x3:   src [Hs*Ws, C] -> dst [H*W, 9*C], column (dy*3+dx)*C + c of row (y,x) = src(y+dy-1, x+dx-1), zero outside
- *              (nn.Conv2d(k=3, padding=1), autoencoder.py:64,66,101,209,235); up = 1 reads src at (y>>1, x>>1), i.e.
- *              F.interpolate(scale_factor=2, mode="nearest") folded into the gather (Upsample.forward, :103-106).
+ *              (nn.Conv2d(k=3, padding=1), autoencoder.py:64,66,101,126,157,209,235); mode 1 reads src at (y>>1, x>>1),
+ *              i.e. F.interpolate(scale_factor=2, mode="nearest") folded into the gather (Upsample.forward, :103-106);
+ *              mode 2 reads src [2H*2W, C] at (2y+dy, 2x+dx), zero beyond the edge = pad (0,1,0,1) + stride-2 conv
+ *              (Downsample.forward, :91-95).
  * groupnorm:   nn.GroupNorm(G, C, eps, affine) over the whole [HW, C] map, f32 statistics (two-level, deterministic),
  *              y = bf16(.), then bf16(y*sigmoid(y)) if swish (autoencoder.py:21-22,30,63,65,234; :70-77,257-258).
  *              scratch: >= (ceil(HW/128) + 1) * 2 * G floats of device memory.
@@ -134,14 +136,18 @@ int vc_unpack_latent(const void* tokens, int64_t ld, int32_t col0, void* latent,
  *              (scaled_dot_product_attention of AttnBlock.attention, :47).
  * transpose:   dst[c, r] = src[r, c] (V^T operand of the P.V GEMM).
  * nchw_to_nhwc: dst[p, c] = bf16(src[c, p] / div + add), zero for C <= c < Cp  (decode: z / scale_factor + shift_factor,
- *              :306-307); src f32 or bf16.   nhwc_to_nchw: dst[c, p] = src[p, c] for c < C; dst f32 or bf16. */
-int vc_im2col3x3(const void* src, void* dst, int32_t H, int32_t W, int32_t C, int32_t up, void* stream);
+ *              :306-307); src f32 or bf16.   nhwc_to_nchw: dst[c, p] = src[p, c] for c < C; dst f32 or bf16.
+ * gaussian_sample: moments [HW, Cp] NHWC (mean channels [0,Z), logvar [Z,2Z)) -> out [Z, HW] bf16 =
+ *              scale * ((mean + exp(0.5*logvar) * noise) - shift); noise [Z, HW] bf16 or NULL for the mean
+ *              (DiagonalGaussian.forward :268-275, AutoEncoder.encode :301-304). */
+int vc_im2col3x3(const void* src, void* dst, int32_t H, int32_t W, int32_t C, int32_t mode, void* stream);
 int vc_groupnorm(const void* x, const void* gamma, const void* beta, void* y, void* scratch, int64_t scratch_bytes,
                  int64_t HW, int32_t C, int32_t G, float eps, int32_t swish, void* stream);
 int vc_softmax_rows(void* x, int64_t ld, int32_t rows, int32_t cols, float scale, void* stream);
 int vc_transpose(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int32_t rows, int32_t cols, void* stream);
 int vc_nchw_to_nhwc(const void* src, int32_t src_is_f32, void* dst, int32_t C, int32_t Cp, int64_t HW, float div, float add, void* stream);
 int vc_nhwc_to_nchw(const void* src, void* dst, int32_t dst_is_f32, int32_t C, int32_t Cp, int64_t HW, void* stream);
+int vc_gaussian_sample(const void* moments, int32_t Cp, const void* noise, void* out, int32_t Z, int64_t HW, float scale, float shift, void* stream);
 
 /* ---- hipGraph helpers: capture the launches issued on `stream` between begin/end ---- */
 int vc_stream_create(void** stream);

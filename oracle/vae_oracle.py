@@ -1,8 +1,9 @@
-"""CPU restatement of the FLUX AutoEncoder decode path — TEST INFRASTRUCTURE ONLY (tests/, smoke, bench cpu leg).
+"""CPU restatement of the FLUX AutoEncoder (encode + decode) — TEST INFRASTRUCTURE ONLY (tests/, smoke, bench cpu leg).
 
 Follows the reference's vendored twin models/modules/autoencoder.py: `swish` :21-22, `AttnBlock` :25-52,
-`ResnetBlock.forward` :69-82, `Upsample.forward` :103-106, `Decoder.forward` :237-259, `AutoEncoder.decode` :306-308.
-Weights are addressed by the reference's state-dict keys (`decoder.*`).  Two modes:
+`ResnetBlock.forward` :69-82, `Downsample.forward` :91-95, `Upsample.forward` :103-106, `Encoder.forward` :159-180,
+`Decoder.forward` :237-259, `DiagonalGaussian.forward` :268-275, `AutoEncoder.encode/decode` :301-308.
+Weights are addressed by the reference's state-dict keys (`encoder.*`, `decoder.*`).  Two modes:
   fp32  exact reference semantics in float32
   bf16  every tensor the reference materialises when the module runs in bfloat16 (conv / GroupNorm / sigmoid / product /
         add outputs, q k v, attention output) is rounded to bf16; accumulations stay f32
@@ -19,9 +20,9 @@ def _r(x: torch.Tensor, bf16: bool) -> torch.Tensor:
     return x.to(torch.bfloat16).to(torch.float32) if bf16 else x
 
 
-def _conv(sd, key, x, bf16, padding):
+def _conv(sd, key, x, bf16, padding, stride=1):
     w, b = sd[key + ".weight"].float(), sd[key + ".bias"].float()
-    return _r(F.conv2d(x, w, b, stride=1, padding=padding), bf16)
+    return _r(F.conv2d(x, w, b, stride=stride, padding=padding), bf16)
 
 
 def _group_norm(sd, key, x, bf16, groups=32, eps=1e-6):
@@ -83,3 +84,34 @@ def decode(sd: dict, z: torch.Tensor, params: dict, mode: str = "fp32", taps: di
     dsd = {k[len("decoder."):]: v for k, v in sd.items() if k.startswith("decoder.")}
     z = _r(_r(_r(z.float(), bf16) / params["scale_factor"], bf16) + params["shift_factor"], bf16)
     return decoder_forward(dsd, z, params, mode, taps)
+
+
+def encoder_forward(sd: dict, x: torch.Tensor, params: dict, mode: str = "fp32") -> torch.Tensor:
+    """Encoder.forward (autoencoder.py:159-180) -> moments [B, 2z, h, w]. sd keys relative to the encoder."""
+    bf16 = mode == "bf16"
+    nres, nblk = len(params["ch_mult"]), params["num_res_blocks"]
+    h = _conv(sd, "conv_in", _r(x.float(), bf16), bf16, 1)
+    for lvl in range(nres):
+        for i in range(nblk):
+            h = _resnet(sd, f"down.{lvl}.block.{i}", h, bf16)
+        if lvl != nres - 1:
+            h = F.pad(h, (0, 1, 0, 1), mode="constant", value=0)
+            h = _conv(sd, f"down.{lvl}.downsample.conv", h, bf16, 0, stride=2)
+    h = _resnet(sd, "mid.block_1", h, bf16)
+    h = _attn(sd, "mid.attn_1", h, bf16)
+    h = _resnet(sd, "mid.block_2", h, bf16)
+    h = _swish(_group_norm(sd, "norm_out", h, bf16), bf16)
+    return _conv(sd, "conv_out", h, bf16, 1)
+
+
+def encode(sd: dict, x: torch.Tensor, params: dict, noise: torch.Tensor | None, mode: str = "fp32") -> torch.Tensor:
+    """AutoEncoder.encode (autoencoder.py:301-304) with the DiagonalGaussian noise as an input (None -> the mean)."""
+    bf16 = mode == "bf16"
+    esd = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
+    mom = encoder_forward(esd, x, params, mode)
+    mean, logvar = torch.chunk(mom, 2, dim=1)
+    z = mean
+    if noise is not None:
+        std = _r(torch.exp(_r(0.5 * logvar, bf16)), bf16)
+        z = _r(mean + _r(std * _r(noise.float(), bf16), bf16), bf16)
+    return _r(params["scale_factor"] * _r(z - params["shift_factor"], bf16), bf16)

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
 REF = os.environ.get("VC_REFERENCE", "/root/reference")
 sys.path.insert(0, REPO)
-from tests.procedural import TINY_AE, procedural_ae_param, tiny_ae_latent  # noqa: E402
+from tests.procedural import TINY_AE, procedural_ae_param, tiny_ae_image, tiny_ae_latent, tiny_ae_noise  # noqa: E402
 
 
 def main():
@@ -27,9 +27,9 @@ def main():
     sd = {k: procedural_ae_param(k, v.shape) for k, v in ae.state_dict().items()}
     ae.load_state_dict(sd)
     out = {}
-    keys = [k for k in sd if k.startswith("decoder.")]
-    out["decoder_keys"] = np.array(keys)
-    out["decoder_shapes"] = np.array([";".join(map(str, sd[k].shape)) for k in keys])
+    keys = list(sd)
+    out["keys"] = np.array(keys)
+    out["shapes"] = np.array([";".join(map(str, sd[k].shape)) for k in keys])
     with torch.no_grad():
         for name, (h, w) in {"sq": (4, 4), "rect": (4, 6)}.items():
             z = tiny_ae_latent(h, w, seed=5 if name == "sq" else 6)
@@ -44,6 +44,20 @@ def main():
             out[f"{name}_tap_mid_block_1"] = hcur.numpy()
             hcur = d.mid.attn_1(hcur)
             out[f"{name}_tap_mid_attn_1"] = hcur.numpy()
+        # encode path: image -> moments -> z, with the DiagonalGaussian noise fixed (torch.randn_like is patched to
+        # return the procedural tensor, so the reference's own encode() consumes it)
+        for name, (H, W) in {"sq": (16, 16), "rect": (16, 24)}.items():
+            img = tiny_ae_image(H, W)
+            noise = tiny_ae_noise(H // 2, W // 2)
+            out[f"{name}_img"] = img.numpy()
+            out[f"{name}_noise"] = noise.numpy()
+            out[f"{name}_moments_fp32"] = ae.encoder(img).numpy()
+            real = torch.randn_like
+            torch.randn_like = lambda t, **kw: noise.to(t.dtype)
+            try:
+                out[f"{name}_encode_fp32"] = ae.encode(img).numpy()
+            finally:
+                torch.randn_like = real
         ae16 = AutoEncoder(AutoEncoderParams(**TINY_AE)).eval()
         ae16.load_state_dict(sd)
         ae16 = ae16.to(torch.bfloat16)

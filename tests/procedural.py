@@ -97,3 +97,11 @@ def procedural_ae_param(key: str, shape) -> torch.Tensor:
 
 def tiny_ae_latent(h: int, w: int, seed: int = 5) -> torch.Tensor:
     return ptensor((1, TINY_AE["z_channels"], h, w), seed, q=5, kmax=96)      # |z| <= 3
+
+
+def tiny_ae_image(H: int, W: int, seed: int = 7) -> torch.Tensor:
+    return ptensor((1, TINY_AE["in_channels"], H, W), seed, q=7, kmax=127)    # pixels in [-1, 1]
+
+
+def tiny_ae_noise(h: int, w: int, seed: int = 8) -> torch.Tensor:
+    return ptensor((1, TINY_AE["z_channels"], h, w), seed, q=5, kmax=80)

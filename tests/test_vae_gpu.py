@@ -31,6 +31,17 @@ def bf(t):
     return t.to(torch.bfloat16).to(DEV)
 
 
+@pytest.mark.parametrize("H,W,C", [(4, 4, 64), (3, 5, 128), (1, 1, 8)])
+def test_im2col3x3_stride2_is_exact(hip, H, W, C):
+    """Downsample: pad (0,1,0,1) then 3x3 stride 2 (autoencoder.py:91-95)."""
+    x = bf(ptensor((4 * H * W, C), 12, q=4))
+    col = torch.empty(H * W, 9 * C, dtype=torch.bfloat16, device=DEV)
+    hip.im2col3x3(x, col, H, W, down=True)
+    img = F.pad(x.float().view(2 * H, 2 * W, C).permute(2, 0, 1)[None], (0, 1, 0, 1))
+    ref = F.unfold(img, kernel_size=3, padding=0, stride=2)[0].view(C, 9, H * W).permute(2, 1, 0).reshape(H * W, 9 * C)
+    assert torch.equal(col.float(), ref)
+
+
 @pytest.mark.parametrize("H,W,C,up", [(4, 4, 64, False), (6, 10, 128, False), (8, 12, 64, True), (2, 2, 8, True)])
 def test_im2col3x3_is_exact(hip, H, W, C, up):
     hs, ws = (H // 2, W // 2) if up else (H, W)
@@ -90,8 +101,8 @@ def test_transpose_and_layout_kernels(hip):
 
 
 def tiny_model():
-    from visualcloze_amd.vae import AutoEncoderDecoder, AutoEncoderParams
-    ae = AutoEncoderDecoder(AutoEncoderParams(**TINY_AE))
+    from visualcloze_amd.vae import AutoEncoder, AutoEncoderParams
+    ae = AutoEncoder(AutoEncoderParams(**TINY_AE))
     sd = {k: procedural_ae_param(k, v.shape) for k, v in ae.state_dict().items()}
     ae.load_state_dict(sd)
     return ae.to(DEV).to(torch.bfloat16), sd
@@ -112,8 +123,8 @@ def test_tiny_decode_matches_reference_golden_and_oracle(hip, name):
 
 def test_flux_width_decoder_matches_oracle(hip):
     """Full FLUX AutoEncoder geometry (ch 128, mult 1-2-4-4, 2 res blocks, z 16) on an 8x8 latent -> 64x64 image."""
-    from visualcloze_amd.vae import FLUX_AE, AutoEncoderDecoder, AutoEncoderParams
-    ae = AutoEncoderDecoder(AutoEncoderParams(**FLUX_AE))
+    from visualcloze_amd.vae import FLUX_AE, AutoEncoder, AutoEncoderParams
+    ae = AutoEncoder(AutoEncoderParams(**FLUX_AE))
     sd = {k: procedural_ae_param(k, v.shape) for k, v in ae.state_dict().items()}
     ae.load_state_dict(sd)
     ae = ae.to(DEV).to(torch.bfloat16)
@@ -126,3 +137,51 @@ def test_flux_width_decoder_matches_oracle(hip):
     assert rel_l2(out, o32) <= 3.0 * noise + 2e-3, (rel_l2(out, o32), noise)
     out2 = ae.decode(z.to(DEV).to(torch.bfloat16)).float().cpu()
     assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("name", ["sq", "rect"])
+def test_tiny_encode_matches_reference_golden_and_oracle(hip, name):
+    ae, sd = tiny_model()
+    img, noise = torch.tensor(G[f"{name}_img"]), torch.tensor(G[f"{name}_noise"])
+    mom = ae.encoder(img.to(DEV).to(torch.bfloat16)).float().cpu()
+    ref_m = torch.tensor(G[f"{name}_moments_fp32"])
+    esd = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
+    noise_m = rel_l2(VO.encoder_forward(esd, img, TINY_AE, "bf16"), ref_m)
+    assert mom.shape == ref_m.shape
+    assert rel_l2(mom, ref_m) <= 3.0 * noise_m + 2e-3, (rel_l2(mom, ref_m), noise_m)
+    z = ae.encode(img.to(DEV).to(torch.bfloat16), noise=noise.to(DEV)).float().cpu()
+    ref_z = torch.tensor(G[f"{name}_encode_fp32"])
+    o16 = VO.encode(sd, img, TINY_AE, noise, "bf16")
+    nz = rel_l2(o16, ref_z)
+    assert rel_l2(z, ref_z) <= 3.0 * nz + 2e-3, (rel_l2(z, ref_z), nz)
+    zm = ae.encode(img.to(DEV).to(torch.bfloat16), sample=False).float().cpu()        # sample=False -> the mean
+    assert rel_l2(zm, VO.encode(sd, img, TINY_AE, None, "bf16")) <= 2.0 * nz + 2e-3
+
+
+def test_gaussian_sample_kernel_rounding(hip):
+    """scale * ((mean + exp(0.5*logvar) * noise) - shift) with torch's own bf16 rounding sequence."""
+    Z, h, w = 4, 3, 5
+    mom = bf(ptensor((h * w, 8), 31, q=5))
+    noise = bf(ptensor((Z, h, w), 32, q=5))
+    out = torch.empty(Z, h, w, dtype=torch.bfloat16, device=DEV)
+    hip.gaussian_sample(mom, noise, out, 0.3611, 0.1159)
+    m = mom.t().reshape(8, h, w)
+    mean, logvar = m[:Z], m[Z:]
+    ref = 0.3611 * ((mean + torch.exp(0.5 * logvar) * noise) - 0.1159)       # bf16 tensor arithmetic
+    assert (out.float() - ref.float()).abs().max().item() <= 2 ** -7 * ref.float().abs().max().item()
+
+
+def test_flux_width_encoder_matches_oracle(hip):
+    from visualcloze_amd.vae import FLUX_AE, AutoEncoder, AutoEncoderParams
+    ae = AutoEncoder(AutoEncoderParams(**FLUX_AE))
+    sd = {k: procedural_ae_param(k, v.shape) for k, v in ae.state_dict().items()}
+    ae.load_state_dict(sd)
+    ae = ae.to(DEV).to(torch.bfloat16)
+    img = ptensor((1, 3, 64, 64), 41, q=7, kmax=127)
+    mom = ae.encoder(img.to(DEV).to(torch.bfloat16)).float().cpu()
+    esd = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
+    o32 = VO.encoder_forward(esd, img, FLUX_AE, "fp32")
+    o16 = VO.encoder_forward(esd, img, FLUX_AE, "bf16")
+    noise = rel_l2(o16, o32)
+    assert mom.shape == (1, 32, 8, 8)
+    assert rel_l2(mom, o32) <= 3.0 * noise + 2e-3, (rel_l2(mom, o32), noise)

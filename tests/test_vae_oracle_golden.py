@@ -13,8 +13,8 @@ G = np.load(os.path.join(os.path.dirname(__file__), "golden", "vae_golden.npz"))
 
 
 def tiny_sd():
-    keys = [str(k) for k in G["decoder_keys"]]
-    shapes = [tuple(int(x) for x in str(s).split(";")) for s in G["decoder_shapes"]]
+    keys = [str(k) for k in G["keys"]]
+    shapes = [tuple(int(x) for x in str(s).split(";")) for s in G["shapes"]]
     return {k: procedural_ae_param(k, s) for k, s in zip(keys, shapes)}
 
 
@@ -30,7 +30,7 @@ def test_oracle_fp32_matches_reference(name):
     taps = {}
     out = VO.decode(sd, z, TINY_AE, "fp32")
     assert rel_l2(out, G[f"{name}_decode_fp32"]) < 2e-5
-    dsd = {k[len("decoder."):]: v for k, v in sd.items()}
+    dsd = {k[len("decoder."):]: v for k, v in sd.items() if k.startswith("decoder.")}
     out2 = VO.decoder_forward(dsd, z, TINY_AE, "fp32", taps)
     assert rel_l2(out2, G[f"{name}_decoder_fp32"]) < 2e-5
     for t in ("conv_in", "mid.block_1", "mid.attn_1"):
@@ -49,21 +49,32 @@ def test_oracle_bf16_mode_tracks_reference_bf16_module():
     assert rel_l2(o16, ref16) < 2.0 * noise + 1e-3
 
 
+@pytest.mark.parametrize("name", ["sq", "rect"])
+def test_oracle_encode_fp32_matches_reference(name):
+    sd = tiny_sd()
+    img, noise = torch.tensor(G[f"{name}_img"]), torch.tensor(G[f"{name}_noise"])
+    esd = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
+    assert rel_l2(VO.encoder_forward(esd, img, TINY_AE, "fp32"), G[f"{name}_moments_fp32"]) < 2e-5
+    assert rel_l2(VO.encode(sd, img, TINY_AE, noise, "fp32"), G[f"{name}_encode_fp32"]) < 2e-5
+
+
 def test_state_dict_contract():
-    from visualcloze_amd.vae import AutoEncoderDecoder, AutoEncoderParams
-    ae = AutoEncoderDecoder(AutoEncoderParams(**TINY_AE))
+    from visualcloze_amd.vae import AutoEncoder, AutoEncoderParams
+    ae = AutoEncoder(AutoEncoderParams(**TINY_AE))
     mine = {k: tuple(v.shape) for k, v in ae.state_dict().items()}
-    keys = [str(k) for k in G["decoder_keys"]]
-    shapes = [tuple(int(x) for x in str(s).split(";")) for s in G["decoder_shapes"]]
-    assert list(mine) == keys                       # same names, same order as the reference's decoder.* entries
+    keys = [str(k) for k in G["keys"]]
+    shapes = [tuple(int(x) for x in str(s).split(";")) for s in G["shapes"]]
+    assert list(mine) == keys                       # same names, same order as the reference's AutoEncoder
     assert [mine[k] for k in keys] == shapes
 
 
 def test_decode_without_gpu_fails_loudly():
     from visualcloze_amd import hip
-    from visualcloze_amd.vae import AutoEncoderDecoder, AutoEncoderParams
+    from visualcloze_amd.vae import AutoEncoder, AutoEncoderParams
     if torch.cuda.is_available():
         pytest.skip("GPU present")
-    ae = AutoEncoderDecoder(AutoEncoderParams(**TINY_AE))
+    ae = AutoEncoder(AutoEncoderParams(**TINY_AE))
     with pytest.raises(hip.VclozeHipError):
         ae.decode(torch.zeros(1, TINY_AE["z_channels"], 4, 4))
+    with pytest.raises(hip.VclozeHipError):
+        ae.encode(torch.zeros(1, 3, 16, 16))

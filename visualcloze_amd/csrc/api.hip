@@ -95,6 +95,9 @@ int vc_nchw_to_nhwc(const void* src, int32_t src_is_f32, void* dst, int32_t C, i
 int vc_nhwc_to_nchw(const void* src, void* dst, int32_t dst_is_f32, int32_t C, int32_t Cp, int64_t HW, void* stream) {
   return vc_nhwc_to_nchw_launch(src, dst, dst_is_f32, C, Cp, HW, S(stream), ERRBUF);
 }
+int vc_gaussian_sample(const void* moments, int32_t Cp, const void* noise, void* out, int32_t Z, int64_t HW, float scale, float shift, void* stream) {
+  return vc_gaussian_sample_launch(moments, Cp, noise, out, Z, HW, scale, shift, S(stream), ERRBUF);
+}
 int vc_pack_latent(const void* latent, void* tokens, int32_t C, int32_t h, int32_t w, int64_t ld, int32_t col0, void* stream) {
   return vc_pack_latent_launch(latent, tokens, C, h, w, ld, col0, S(stream), ERRBUF);
 }

@@ -13,7 +13,10 @@
 
 namespace {
 
-__global__ void im2col3x3_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int H, int W, int C, int up) {
+// mode 0: same size, zero padding 1.  mode 1: source is the half-resolution map read at (yy>>1, xx>>1) (nearest 2x
+// upsampling folded in).  mode 2: stride-2 convolution of the source padded by one zero row/column at the bottom/right
+// (Downsample.forward, autoencoder.py:91-95): tap (dy, dx) of output (y, x) reads source (2y+dy, 2x+dx).
+__global__ void im2col3x3_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int H, int W, int C, int mode) {
   const int cpr = C >> 3;                                   // 16-B chunks per pixel
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long total = (long)H * W * 9 * cpr;
@@ -23,11 +26,17 @@ __global__ void im2col3x3_kernel(const bf16_t* __restrict__ src, bf16_t* __restr
   const int tap = (int)(rt % 9);
   const long row = rt / 9;
   const int y = (int)(row / W), x = (int)(row % W);
-  const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
   u32x4 v = {0u, 0u, 0u, 0u};
-  if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-    const int Ws = W >> up;
-    v = *(const u32x4*)(src + ((long)(yy >> up) * Ws + (xx >> up)) * C + c8 * 8);
+  if (mode == 2) {
+    const int Hs = 2 * H, Ws = 2 * W;
+    const int yy = 2 * y + tap / 3, xx = 2 * x + tap % 3;
+    if (yy < Hs && xx < Ws) v = *(const u32x4*)(src + ((long)yy * Ws + xx) * C + c8 * 8);
+  } else {
+    const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+    if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+      const int Ws = W >> mode;
+      v = *(const u32x4*)(src + ((long)(yy >> mode) * Ws + (xx >> mode)) * C + c8 * 8);
+    }
   }
   *(u32x4*)(dst + (row * 9 + tap) * C + c8 * 8) = v;
 }
@@ -190,6 +199,24 @@ __global__ void nhwc_to_nchw_kernel(const bf16_t* __restrict__ src, void* __rest
   if (dst_f32) ((float*)dst)[i] = bf2f(v); else ((bf16_t*)dst)[i] = v;
 }
 
+// DiagonalGaussian.forward + AutoEncoder.encode (autoencoder.py:268-275, :301-304): moments [HW, Cp] NHWC with mean in
+// channels [0, Z) and logvar in [Z, 2Z); out[c][p] = scale * ((mean + exp(0.5*logvar) * noise[c][p]) - shift), every
+// intermediate rounded to bf16 like the reference's bf16 tensors; noise == nullptr -> the mean (sample=False).
+__global__ void gaussian_sample_kernel(const bf16_t* __restrict__ mom, int Cp, const bf16_t* __restrict__ noise,
+                                       bf16_t* __restrict__ out, int Z, long HW, float scale, float shift) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= HW * Z) return;
+  const int c = (int)(i / HW);
+  const long p = i % HW;
+  float z = bf2f(mom[p * Cp + c]);
+  if (noise) {
+    const float lv = bf2f(mom[p * Cp + Z + c]);
+    const float sd = rbf(expf(rbf(0.5f * lv)));
+    z = rbf(z + rbf(sd * bf2f(noise[i])));
+  }
+  out[i] = f2bf(scale * rbf(z - shift));
+}
+
 }  // namespace
 
 #define VAE_LAUNCH_CHECK(what)                                                                   \
@@ -198,8 +225,8 @@ __global__ void nhwc_to_nchw_kernel(const bf16_t* __restrict__ src, void* __rest
 
 int vc_im2col3x3_launch(const void* src, void* dst, int H, int W, int C, int up, hipStream_t s, char* err, int errlen) {
   if (!src || !dst) { snprintf(err, errlen, "im2col3x3: null pointer"); return VC_ERR_ARG; }
-  if (H <= 0 || W <= 0 || C <= 0 || C % 8 || up < 0 || up > 1 || (up && ((H | W) & 1))) {
-    snprintf(err, errlen, "im2col3x3: bad shape H=%d W=%d C=%d up=%d (C %% 8 == 0; even H, W when upsampling)", H, W, C, up); return VC_ERR_ARG; }
+  if (H <= 0 || W <= 0 || C <= 0 || C % 8 || up < 0 || up > 2 || (up == 1 && ((H | W) & 1))) {
+    snprintf(err, errlen, "im2col3x3: bad shape H=%d W=%d C=%d mode=%d (C %% 8 == 0; even H, W when upsampling)", H, W, C, up); return VC_ERR_ARG; }
   const long total = (long)H * W * 9 * (C >> 3);
   hipLaunchKernelGGL(im2col3x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, H, W, C, up);
   VAE_LAUNCH_CHECK("im2col3x3");
@@ -256,5 +283,16 @@ int vc_nhwc_to_nchw_launch(const void* src, void* dst, int dst_f32, int C, int C
   const long total = HW * C;
   hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const bf16_t*)src, dst, dst_f32, C, Cp, (long)HW);
   VAE_LAUNCH_CHECK("nhwc_to_nchw");
+  return VC_OK;
+}
+
+int vc_gaussian_sample_launch(const void* moments, int Cp, const void* noise, void* out, int Z, int64_t HW, float scale, float shift,
+                              hipStream_t s, char* err, int errlen) {
+  if (!moments || !out) { snprintf(err, errlen, "gaussian_sample: null pointer"); return VC_ERR_ARG; }
+  if (Z <= 0 || Cp < 2 * Z || HW <= 0) { snprintf(err, errlen, "gaussian_sample: bad shape Z=%d Cp=%d HW=%ld", Z, Cp, (long)HW); return VC_ERR_ARG; }
+  const long total = HW * Z;
+  hipLaunchKernelGGL(gaussian_sample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const bf16_t*)moments, Cp,
+                     (const bf16_t*)noise, (bf16_t*)out, Z, (long)HW, scale, shift);
+  VAE_LAUNCH_CHECK("gaussian_sample");
   return VC_OK;
 }

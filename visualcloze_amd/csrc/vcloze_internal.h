@@ -31,3 +31,5 @@ int vc_softmax_rows_launch(void* x, int64_t ld, int rows, int cols, float scale,
 int vc_transpose_launch(const void* src, int64_t lds_, void* dst, int64_t ldd, int R, int Cc, hipStream_t s, char* err, int errlen);
 int vc_nchw_to_nhwc_launch(const void* src, int src_f32, void* dst, int C, int Cp, int64_t HW, float div, float add, hipStream_t s, char* err, int errlen);
 int vc_nhwc_to_nchw_launch(const void* src, void* dst, int dst_f32, int C, int Cp, int64_t HW, hipStream_t s, char* err, int errlen);
+int vc_gaussian_sample_launch(const void* moments, int Cp, const void* noise, void* out, int Z, int64_t HW, float scale, float shift,
+                              hipStream_t s, char* err, int errlen);

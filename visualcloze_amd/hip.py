@@ -70,6 +70,7 @@ SYMBOLS = {
     "vc_transpose": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _vp]),
     "vc_nchw_to_nhwc": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i64, C.c_float, C.c_float, _vp]),
     "vc_nhwc_to_nchw": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _vp]),
+    "vc_gaussian_sample": (C.c_int, [_vp, _i32, _vp, _vp, _i32, _i64, C.c_float, C.c_float, _vp]),
     "vc_stream_create": (C.c_int, [C.POINTER(_vp)]),
     "vc_stream_destroy": (C.c_int, [_vp]),
     "vc_stream_sync": (C.c_int, [_vp]),
@@ -310,13 +311,15 @@ def unpack_latent(tokens, latent, col0=0, stream=None):
 
 
 # ---- VAE decoder glue (activations NHWC bf16 [H*W, C]) ----
-def im2col3x3(src, dst, H, W, up=False, stream=None):
+def im2col3x3(src, dst, H, W, up=False, down=False, stream=None):
+    """(H, W) is the OUTPUT map; `up`: src is the half-resolution map (nearest 2x folded in); `down`: src is the
+    double-resolution map (pad (0,1,0,1) + stride 2)."""
     _bf16(src, "src"); _bf16(dst, "dst")
     Cc = src.shape[1]
-    hs, ws = (H >> 1, W >> 1) if up else (H, W)
-    if src.shape[0] != hs * ws or tuple(dst.shape) != (H * W, 9 * Cc) or not (src.is_contiguous() and dst.is_contiguous()):
+    hs, ws = (H >> 1, W >> 1) if up else (2 * H, 2 * W) if down else (H, W)
+    if (up and down) or src.shape[0] != hs * ws or tuple(dst.shape) != (H * W, 9 * Cc) or not (src.is_contiguous() and dst.is_contiguous()):
         raise VclozeHipError("im2col3x3: src [Hs*Ws, C] and dst [H*W, 9C] contiguous expected")
-    _check(lib().vc_im2col3x3(src.data_ptr(), dst.data_ptr(), H, W, Cc, int(bool(up)),
+    _check(lib().vc_im2col3x3(src.data_ptr(), dst.data_ptr(), H, W, Cc, 1 if up else 2 if down else 0,
                               stream if stream is not None else cur_stream()), "vc_im2col3x3")
 
 
@@ -370,6 +373,19 @@ def nhwc_to_nchw(src, dst, stream=None):
         raise VclozeHipError("nhwc_to_nchw: src [H*W, Cp >= C] expected")
     _check(lib().vc_nhwc_to_nchw(src.data_ptr(), dst.data_ptr(), int(dst.dtype == torch.float32), Cc, src.shape[1], HW,
                                  stream if stream is not None else cur_stream()), "vc_nhwc_to_nchw")
+
+
+def gaussian_sample(moments, noise, out, scale, shift, stream=None):
+    _bf16(moments, "moments"); _bf16(out, "out")
+    Z, HW = out.shape[0], out[0].numel()
+    if noise is not None:
+        _bf16(noise, "noise")
+        if noise.shape != out.shape or not noise.is_contiguous():
+            raise VclozeHipError("gaussian_sample: noise must match out [Z, h, w]")
+    if moments.shape[0] != HW or moments.shape[1] < 2 * Z or not (moments.is_contiguous() and out.is_contiguous()):
+        raise VclozeHipError("gaussian_sample: moments [H*W, Cp >= 2Z] and contiguous out [Z, h, w] expected")
+    _check(lib().vc_gaussian_sample(moments.data_ptr(), moments.shape[1], _p(noise), out.data_ptr(), Z, HW, scale, shift,
+                                    stream if stream is not None else cur_stream()), "vc_gaussian_sample")
 
 
 class Graph:

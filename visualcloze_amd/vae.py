@@ -1,8 +1,9 @@
-"""FLUX AutoEncoder **decoder** on MI355X (first slice).
+"""FLUX AutoEncoder (VAE encode / decode of row images) on MI355X.
 
 Mirrors the reference's vendored twin `models/modules/autoencoder.py` (classes `AttnBlock` :25-52, `ResnetBlock` :55-82,
-`Upsample` :98-106, `Decoder` :183-259, `AutoEncoder.decode` :306-308): same constructor arguments, same module tree and
-therefore the same `state_dict()` keys and shapes, so `ae.safetensors` decoder weights load unchanged.  Execution is
+`Downsample` :85-95, `Upsample` :98-106, `Encoder` :109-180, `Decoder` :183-259, `DiagonalGaussian` :262-275,
+`AutoEncoder` :277-311): same constructor arguments, same module tree and therefore the same `state_dict()` keys and
+shapes, so `ae.safetensors` loads unchanged.  Execution is
 NHWC bf16 on the HIP library: every 3x3 convolution is an im2col gather (`vc_im2col3x3`, which also folds the nearest
 2x upsampling) followed by the bf16 MFMA GEMM with fused bias / residual epilogue, GroupNorm+swish is `vc_groupnorm`,
 the mid-block attention (one head, head_dim = C) is two GEMMs around `vc_softmax_rows`.  There is no CPU or torch
@@ -105,38 +106,15 @@ class Upsample(nn.Module):           # autoencoder.py:98-106
         self.conv = _Conv(in_channels, in_channels, 3)
 
 
-class Decoder(nn.Module):            # autoencoder.py:183-259
-    def __init__(self, ch: int, out_ch: int, ch_mult: List[int], num_res_blocks: int, in_channels: int, resolution: int,
-                 z_channels: int):
+class Downsample(nn.Module):         # autoencoder.py:85-95
+    def __init__(self, in_channels: int):
         super().__init__()
-        self.ch, self.out_ch, self.z_channels = ch, out_ch, z_channels
-        self.num_resolutions = len(ch_mult)
-        self.num_res_blocks = num_res_blocks
-        self.resolution, self.in_channels = resolution, in_channels
-        self.ffactor = 2 ** (self.num_resolutions - 1)
-        block_in = ch * ch_mult[self.num_resolutions - 1]
-        self.conv_in = _Conv(z_channels, block_in, 3)
-        self.mid = nn.Module()
-        self.mid.block_1 = ResnetBlock(block_in, block_in)
-        self.mid.attn_1 = AttnBlock(block_in)
-        self.mid.block_2 = ResnetBlock(block_in, block_in)
-        self.up = nn.ModuleList()
-        for i_level in reversed(range(self.num_resolutions)):
-            block = nn.ModuleList()
-            block_out = ch * ch_mult[i_level]
-            for _ in range(self.num_res_blocks + 1):
-                block.append(ResnetBlock(block_in, block_out))
-                block_in = block_out
-            up = nn.Module()
-            up.block = block
-            up.attn = nn.ModuleList()
-            if i_level != 0:
-                up.upsample = Upsample(block_in)
-            self.up.insert(0, up)
-        self.norm_out = _GroupNorm(block_in)
-        self.conv_out = _Conv(block_in, out_ch, 3)
+        self.conv = _Conv(in_channels, in_channels, 3)
 
-    # ------------------------------------------------------------------ execution (NHWC bf16 on the HIP library)
+
+class _HipExec(nn.Module):
+    """Execution helpers shared by Encoder and Decoder: NHWC bf16 activations [H*W, C] on the HIP library."""
+
     def _scratch(self, dev, name, shape, dtype=torch.bfloat16):
         pool = self.__dict__.setdefault("_pool", {})
         t = pool.get(name)
@@ -148,11 +126,11 @@ class Decoder(nn.Module):            # autoencoder.py:183-259
             pool[name] = t
         return t[:n].view(*shape)
 
-    def _conv3(self, conv: _Conv, x, H, W, out, up=False, res=None):
-        """out[H*W, O_pad] = conv3x3(x) (+ res); x is [Hs*Ws, I_pad64]."""
+    def _conv3(self, conv: _Conv, x, H, W, out, up=False, down=False, res=None):
+        """out[H*W, O_pad] = conv3x3(x) (+ res); (H, W) is the output map, x the (possibly half / double size) input."""
         w, b = conv.prepared()
         col = self._scratch(x.device, "col", (H * W, 9 * x.shape[1]))
-        hip.im2col3x3(x, col, H, W, up=up)
+        hip.im2col3x3(x, col, H, W, up=up, down=down)
         self._gemm(col, w, b, out, res)
 
     def _conv1(self, conv: _Conv, x, out, res=None):
@@ -211,6 +189,114 @@ class Decoder(nn.Module):            # autoencoder.py:183-259
         self._conv1(blk.proj_out, o, out, res=x)
         return out
 
+
+class Encoder(_HipExec):             # autoencoder.py:109-180
+    def __init__(self, resolution: int, in_channels: int, ch: int, ch_mult: List[int], num_res_blocks: int, z_channels: int):
+        super().__init__()
+        self.ch, self.z_channels = ch, z_channels
+        self.num_resolutions = len(ch_mult)
+        self.num_res_blocks = num_res_blocks
+        self.resolution, self.in_channels = resolution, in_channels
+        self.conv_in = _Conv(in_channels, ch, 3)
+        in_ch_mult = (1,) + tuple(ch_mult)
+        self.in_ch_mult = in_ch_mult
+        self.down = nn.ModuleList()
+        block_in = ch
+        for i_level in range(self.num_resolutions):
+            block = nn.ModuleList()
+            block_in = ch * in_ch_mult[i_level]
+            block_out = ch * ch_mult[i_level]
+            for _ in range(self.num_res_blocks):
+                block.append(ResnetBlock(block_in, block_out))
+                block_in = block_out
+            down = nn.Module()
+            down.block = block
+            down.attn = nn.ModuleList()
+            if i_level != self.num_resolutions - 1:
+                down.downsample = Downsample(block_in)
+            self.down.append(down)
+        self.mid = nn.Module()
+        self.mid.block_1 = ResnetBlock(block_in, block_in)
+        self.mid.attn_1 = AttnBlock(block_in)
+        self.mid.block_2 = ResnetBlock(block_in, block_in)
+        self.norm_out = _GroupNorm(block_in)
+        self.conv_out = _Conv(block_in, 2 * z_channels, 3)
+
+    def _moments_one(self, img):
+        """img [in_channels, H, W] -> (moments NHWC [h*w, pad8(2z)], h, w)   (Encoder.forward, :159-180)"""
+        dev = img.device
+        _, H, W = img.shape
+        f = 2 ** (self.num_resolutions - 1)
+        if H % f or W % f:
+            raise ValueError(f"Encoder: image size {H}x{W} must be a multiple of {f}")
+        x0 = self._scratch(dev, "zin", (H * W, _pad_to(self.in_channels, 64)))
+        hip.nchw_to_nhwc(img, x0, 1.0, 0.0)
+        cur = self._scratch(dev, "xa", (H * W, self.conv_in.cout))
+        self._conv3(self.conv_in, x0, H, W, cur)
+        flip = ["b", "a"]
+        k = 0
+        for i_level in range(self.num_resolutions):
+            for blk in self.down[i_level].block:
+                cur = self._resnet(blk, cur, H, W, flip[k & 1]); k += 1
+            if i_level != self.num_resolutions - 1:
+                H, W = H // 2, W // 2
+                nxt = self._scratch(dev, "x" + flip[k & 1], (H * W, cur.shape[1])); k += 1
+                self._conv3(self.down[i_level].downsample.conv, cur, H, W, nxt, down=True)
+                cur = nxt
+        cur = self._resnet(self.mid.block_1, cur, H, W, flip[k & 1]); k += 1
+        cur = self._attn(self.mid.attn_1, cur, flip[k & 1]); k += 1
+        cur = self._resnet(self.mid.block_2, cur, H, W, flip[k & 1]); k += 1
+        t = self._scratch(dev, "t0", (H * W, cur.shape[1]))
+        self._norm(self.norm_out, cur, t, True)
+        mom = self._scratch(dev, "yout", (H * W, _pad_to(2 * self.z_channels, 8)))
+        self._conv3(self.conv_out, t, H, W, mom)
+        return mom, H, W
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x [B, in_channels, H, W] -> moments [B, 2*z_channels, H/8, W/8] bf16 (the reference's Encoder.forward)."""
+        hip.require_gpu()
+        if x.dim() != 4 or x.shape[1] != self.in_channels:
+            raise ValueError(f"Encoder expects [B, {self.in_channels}, H, W], got {tuple(x.shape)}")
+        outs = []
+        for xi in x:
+            mom, h, w = self._moments_one(xi.contiguous())
+            o = torch.empty(2 * self.z_channels, h, w, dtype=torch.bfloat16, device=x.device)
+            hip.nhwc_to_nchw(mom, o)
+            outs.append(o)
+        return torch.stack(outs)
+
+
+class Decoder(_HipExec):             # autoencoder.py:183-259
+    def __init__(self, ch: int, out_ch: int, ch_mult: List[int], num_res_blocks: int, in_channels: int, resolution: int,
+                 z_channels: int):
+        super().__init__()
+        self.ch, self.out_ch, self.z_channels = ch, out_ch, z_channels
+        self.num_resolutions = len(ch_mult)
+        self.num_res_blocks = num_res_blocks
+        self.resolution, self.in_channels = resolution, in_channels
+        self.ffactor = 2 ** (self.num_resolutions - 1)
+        block_in = ch * ch_mult[self.num_resolutions - 1]
+        self.conv_in = _Conv(z_channels, block_in, 3)
+        self.mid = nn.Module()
+        self.mid.block_1 = ResnetBlock(block_in, block_in)
+        self.mid.attn_1 = AttnBlock(block_in)
+        self.mid.block_2 = ResnetBlock(block_in, block_in)
+        self.up = nn.ModuleList()
+        for i_level in reversed(range(self.num_resolutions)):
+            block = nn.ModuleList()
+            block_out = ch * ch_mult[i_level]
+            for _ in range(self.num_res_blocks + 1):
+                block.append(ResnetBlock(block_in, block_out))
+                block_in = block_out
+            up = nn.Module()
+            up.block = block
+            up.attn = nn.ModuleList()
+            if i_level != 0:
+                up.upsample = Upsample(block_in)
+            self.up.insert(0, up)
+        self.norm_out = _GroupNorm(block_in)
+        self.conv_out = _Conv(block_in, out_ch, 3)
+
     def forward(self, z: torch.Tensor) -> torch.Tensor:
         """z: [B, z_channels, h, w] (f32 or bf16) -> image [B, out_ch, 8h, 8w] bf16 (the reference's Decoder.forward)."""
         hip.require_gpu()
@@ -251,19 +337,42 @@ class Decoder(nn.Module):            # autoencoder.py:183-259
         return img
 
 
-class AutoEncoderDecoder(nn.Module):
-    """`AutoEncoder` restricted to its decode path (autoencoder.py:277-308); `decoder.*` keys as in ae.safetensors."""
+class AutoEncoder(nn.Module):
+    """autoencoder.py:277-311.  `encode` takes the Gaussian noise as an argument (the reference draws
+    `torch.randn_like(mean)` inside DiagonalGaussian, :272; pass `noise=None` to draw the same way here, or
+    `sample=False` for the mean)."""
 
     def __init__(self, params: AutoEncoderParams):
         super().__init__()
+        self.encoder = Encoder(resolution=params.resolution, in_channels=params.in_channels, ch=params.ch,
+                               ch_mult=params.ch_mult, num_res_blocks=params.num_res_blocks, z_channels=params.z_channels)
         self.decoder = Decoder(resolution=params.resolution, in_channels=params.in_channels, ch=params.ch,
                                out_ch=params.out_ch, ch_mult=params.ch_mult, num_res_blocks=params.num_res_blocks,
                                z_channels=params.z_channels)
         self.scale_factor = params.scale_factor
         self.shift_factor = params.shift_factor
 
+    def encode(self, x: torch.Tensor, noise: Optional[torch.Tensor] = None, sample: bool = True) -> torch.Tensor:
+        hip.require_gpu()
+        enc = self.encoder
+        if x.dim() != 4 or x.shape[1] != enc.in_channels:
+            raise ValueError(f"encode expects [B, {enc.in_channels}, H, W], got {tuple(x.shape)}")
+        outs = []
+        for i, xi in enumerate(x):
+            mom, h, w = enc._moments_one(xi.contiguous())
+            z = torch.empty(enc.z_channels, h, w, dtype=torch.bfloat16, device=x.device)
+            n = None
+            if sample:
+                n = (noise[i] if noise is not None else torch.randn_like(z)).to(torch.bfloat16).contiguous()
+            hip.gaussian_sample(mom, n, z, self.scale_factor, self.shift_factor)
+            outs.append(z)
+        return torch.stack(outs)
+
     def decode(self, z: torch.Tensor) -> torch.Tensor:
         hip.require_gpu()
         if z.dim() != 4 or z.shape[1] != self.decoder.z_channels:
             raise ValueError(f"decode expects [B, {self.decoder.z_channels}, h, w], got {tuple(z.shape)}")
         return torch.stack([self.decoder._decode_one(zi.contiguous(), self.scale_factor, self.shift_factor) for zi in z])
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.decode(self.encode(x))

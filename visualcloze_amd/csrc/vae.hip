@@ -79,16 +79,27 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
   }
 }
 
-// stats[2g] = mean, stats[2g+1] = rstd
-__global__ void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats, int nblk, int G, float inv_n, float eps) {
-  const int g = threadIdx.x;
-  if (g >= G) return;
+// stats[2g] = mean, stats[2g+1] = rstd.  One 256-thread block per group: thread t adds partials t, t+256, ... in that
+// order, then a fixed-shape tree over the 256 thread sums - deterministic, and parallel enough for the 1152 partial
+// blocks of a 384x384 map.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats, int nblk, int G, float inv_n, float eps) {
+  __shared__ double rs[256], rq[256];
+  const int g = blockIdx.x, t = threadIdx.x;
   double s = 0.0, q = 0.0;
-  for (int b = 0; b < nblk; ++b) { s += part[(long)b * 2 * G + 2 * g]; q += part[(long)b * 2 * G + 2 * g + 1]; }
-  const double mean = s * inv_n;
-  const double var = q * inv_n - mean * mean;
-  stats[2 * g] = (float)mean;
-  stats[2 * g + 1] = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)eps));
+  for (int b = t; b < nblk; b += 256) { s += part[(long)b * 2 * G + 2 * g]; q += part[(long)b * 2 * G + 2 * g + 1]; }
+  rs[t] = s; rq[t] = q;
+  __syncthreads();
+#pragma unroll
+  for (int w = 128; w > 0; w >>= 1) {
+    if (t < w) { rs[t] += rs[t + w]; rq[t] += rq[t + w]; }
+    __syncthreads();
+  }
+  if (t == 0) {
+    const double mean = rs[0] * inv_n;
+    const double var = rq[0] * inv_n - mean * mean;
+    stats[2 * g] = (float)mean;
+    stats[2 * g + 1] = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)eps));
+  }
 }
 
 __global__ void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ stats, const bf16_t* __restrict__ gamma,
@@ -244,7 +255,7 @@ int vc_groupnorm_launch(const void* x, const void* gamma, const void* beta, void
   float* stats = (float*)scratch;
   float* part = stats + 2 * G;
   hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk), dim3(256), 0, s, (const bf16_t*)x, part, (long)HW, C, G);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(64), 0, s, part, stats, nblk, G, 1.0f / ((float)HW * (float)(C / G)), eps);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(G), dim3(256), 0, s, part, stats, nblk, G, 1.0f / ((float)HW * (float)(C / G)), eps);
   const long chunks = HW * (C >> 3);
   hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, s, (const bf16_t*)x, stats,
                      (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)y, (long)HW, C, G, swish);

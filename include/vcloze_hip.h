@@ -132,8 +132,10 @@ int vc_unpack_latent(const void* tokens, int64_t ld, int32_t col0, void* latent,
  * groupnorm:   nn.GroupNorm(G, C, eps, affine) over the whole [HW, C] map, f32 statistics (two-level, deterministic),
  *              y = bf16(.), then bf16(y*sigmoid(y)) if swish (autoencoder.py:21-22,30,63,65,234; :70-77,257-258).
  *              scratch: >= (ceil(HW/128) + 1) * 2 * G floats of device memory.
- * softmax_rows: x[r, 0:cols] <- bf16(softmax(scale * x[r, :])) in place, f32 internal, cols <= 16384
- *              (scaled_dot_product_attention of AttnBlock.attention, :47).
+ * softmax_rows: x[r, 0:cols] <- bf16(softmax(v)) in place, v = bf16(scale * x[r, :]) (+ bias[r, :], rounded to bf16 again),
+ *              f32 internal, cols <= 16384; bias NULL or bf16 [rows, cols] (T5 relative position bias); causal_period
+ *              P > 0 masks columns j > r % P (CLIP text)   (scaled_dot_product_attention of AttnBlock.attention, :47;
+ *              T5Attention / CLIPAttention of transformers).
  * transpose:   dst[c, r] = src[r, c] (V^T operand of the P.V GEMM).
  * nchw_to_nhwc: dst[p, c] = bf16(src[c, p] / div + add), zero for C <= c < Cp  (decode: z / scale_factor + shift_factor,
  *              :306-307); src f32 or bf16.   nhwc_to_nchw: dst[c, p] = src[p, c] for c < C; dst f32 or bf16.
@@ -143,11 +145,26 @@ int vc_unpack_latent(const void* tokens, int64_t ld, int32_t col0, void* latent,
 int vc_im2col3x3(const void* src, void* dst, int32_t H, int32_t W, int32_t C, int32_t mode, void* stream);
 int vc_groupnorm(const void* x, const void* gamma, const void* beta, void* y, void* scratch, int64_t scratch_bytes,
                  int64_t HW, int32_t C, int32_t G, float eps, int32_t swish, void* stream);
-int vc_softmax_rows(void* x, int64_t ld, int32_t rows, int32_t cols, float scale, void* stream);
+int vc_softmax_rows(void* x, int64_t ld, int32_t rows, int32_t cols, float scale, const void* bias, int64_t ld_bias,
+                    int32_t causal_period, void* stream);
 int vc_transpose(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int32_t rows, int32_t cols, void* stream);
 int vc_nchw_to_nhwc(const void* src, int32_t src_is_f32, void* dst, int32_t C, int32_t Cp, int64_t HW, float div, float add, void* stream);
 int vc_nhwc_to_nchw(const void* src, void* dst, int32_t dst_is_f32, int32_t C, int32_t Cp, int64_t HW, void* stream);
 int vc_gaussian_sample(const void* moments, int32_t Cp, const void* noise, void* out, int32_t Z, int64_t HW, float scale, float shift, void* stream);
+
+/* ---- text-encoder glue (reference call site models/modules/conditioner.py:5-37, arithmetic of
+ * transformers' T5EncoderModel / CLIPTextModel run in bf16).  Projections and per-head attention products are vc_gemm. ----
+ * embedding:  out[i, :] = table[clamp(ids[i]), :]                                       (nn.Embedding)
+ * rmsnorm:    y = bf16(w * bf16(x * rsqrt(mean(x^2) + eps))), f32 statistics, D <= 4096   (T5LayerNorm)
+ * layernorm:  y = bf16((x - mean) * rstd * w + b), f32 statistics, D <= 4096              (nn.LayerNorm, CLIP)
+ * mul / add:  y = bf16(a * b) / bf16(a + b), n % 8 == 0          (T5DenseGatedActDense product; CLIP token + position)
+ * quick_gelu: y = bf16(x * bf16(sigmoid(bf16(1.702 * x))))                                (CLIP hidden_act) */
+int vc_embedding(const int32_t* ids, const void* table, int64_t ld_table, int32_t vocab, void* out, int32_t L, int32_t D, void* stream);
+int vc_rmsnorm(const void* x, const void* weight, void* y, int32_t rows, int32_t D, float eps, void* stream);
+int vc_layernorm(const void* x, const void* weight, const void* bias, void* y, int32_t rows, int32_t D, float eps, void* stream);
+int vc_mul(const void* a, const void* b, void* y, int64_t n, void* stream);
+int vc_add(const void* a, const void* b, void* y, int64_t n, void* stream);
+int vc_quick_gelu(const void* x, void* y, int64_t n, void* stream);
 
 /* ---- hipGraph helpers: capture the launches issued on `stream` between begin/end ---- */
 int vc_stream_create(void** stream);

@@ -105,3 +105,35 @@ def tiny_ae_image(H: int, W: int, seed: int = 7) -> torch.Tensor:
 
 def tiny_ae_noise(h: int, w: int, seed: int = 8) -> torch.Tensor:
     return ptensor((1, TINY_AE["z_channels"], h, w), seed, q=5, kmax=80)
+
+
+# ---- text encoders: tiny geometries, head_dim 64 like the real models ----
+TINY_T5 = dict(vocab_size=128, d_model=128, d_kv=64, d_ff=256, num_layers=2, num_heads=2,
+               relative_attention_num_buckets=32, relative_attention_max_distance=128, layer_norm_epsilon=1e-6)
+TINY_CLIP = dict(vocab_size=128, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                 max_position_embeddings=24, layer_norm_eps=1e-5, eos_token_id=127)
+
+
+def procedural_text_param(key: str, shape) -> torch.Tensor:
+    seed = key_seed("txt:" + key)
+    shape = tuple(shape)
+    if "layer_norm" in key and key.endswith(".weight"):
+        return ptensor(shape, seed, q=8, kmax=64, offset=1.0)
+    if key.endswith(".bias"):
+        return ptensor(shape, seed, q=8, kmax=32)
+    if "relative_attention_bias" in key:
+        return ptensor(shape, seed, q=5, kmax=64)            # |bias| <= 2
+    if "embedding" in key or key.startswith("shared") or "embed_tokens" in key:
+        return ptensor(shape, seed, q=6, kmax=96)            # |e| <= 1.5
+    fan_in = shape[-1]
+    q = int(round(math.log2(73.0 * math.sqrt(fan_in))))
+    return ptensor(shape, seed, q=q, kmax=127)
+
+
+def tiny_ids(L: int, vocab: int, seed: int, eos: int | None = None, eos_at: int | None = None) -> torch.Tensor:
+    h = _hash(np.arange(L, dtype=np.uint64), seed)
+    ids = (h % np.uint64(vocab - 1)).astype(np.int64)       # never the last id, which the CLIP case reserves for EOS
+    if eos is not None:
+        ids[eos_at] = eos
+        ids[eos_at + 1:] = 0
+    return torch.tensor(ids)

@@ -83,9 +83,22 @@ int vc_groupnorm(const void* x, const void* gamma, const void* beta, void* y, vo
                  int64_t HW, int32_t C, int32_t G, float eps, int32_t swish, void* stream) {
   return vc_groupnorm_launch(x, gamma, beta, y, scratch, scratch_bytes, HW, C, G, eps, swish, S(stream), ERRBUF);
 }
-int vc_softmax_rows(void* x, int64_t ld, int32_t rows, int32_t cols, float scale, void* stream) {
-  return vc_softmax_rows_launch(x, ld, rows, cols, scale, S(stream), ERRBUF);
+int vc_softmax_rows(void* x, int64_t ld, int32_t rows, int32_t cols, float scale, const void* bias, int64_t ld_bias,
+                    int32_t causal_period, void* stream) {
+  return vc_softmax_rows_launch(x, ld, rows, cols, scale, bias, ld_bias, causal_period, S(stream), ERRBUF);
 }
+int vc_embedding(const int32_t* ids, const void* table, int64_t ld_table, int32_t vocab, void* out, int32_t L, int32_t D, void* stream) {
+  return vc_embedding_launch(ids, table, ld_table, vocab, out, L, D, S(stream), ERRBUF);
+}
+int vc_rmsnorm(const void* x, const void* weight, void* y, int32_t rows, int32_t D, float eps, void* stream) {
+  return vc_rownorm_launch(x, weight, nullptr, y, rows, D, eps, 0, S(stream), ERRBUF);
+}
+int vc_layernorm(const void* x, const void* weight, const void* bias, void* y, int32_t rows, int32_t D, float eps, void* stream) {
+  return vc_rownorm_launch(x, weight, bias, y, rows, D, eps, 1, S(stream), ERRBUF);
+}
+int vc_mul(const void* a, const void* b, void* y, int64_t n, void* stream) { return vc_ewise_launch(a, b, y, n, 0, S(stream), ERRBUF); }
+int vc_add(const void* a, const void* b, void* y, int64_t n, void* stream) { return vc_ewise_launch(a, b, y, n, 1, S(stream), ERRBUF); }
+int vc_quick_gelu(const void* x, void* y, int64_t n, void* stream) { return vc_ewise_launch(x, nullptr, y, n, 2, S(stream), ERRBUF); }
 int vc_transpose(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int32_t rows, int32_t cols, void* stream) {
   return vc_transpose_launch(src, ld_src, dst, ld_dst, rows, cols, S(stream), ERRBUF);
 }

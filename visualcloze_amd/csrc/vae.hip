@@ -131,19 +131,29 @@ __global__ void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __res
   *(u32x4*)(y + i * 8) = o;
 }
 
-// one 256-thread block per row; cols <= 256 * 64
-__global__ __launch_bounds__(256) void softmax_rows_kernel(bf16_t* __restrict__ x, long ld, int cols, float scale) {
+// one 256-thread block per row; cols <= 256 * 64.  v = bf16(scale * x) [+ bias, rounded to bf16 again]; causal: columns
+// j > (row % causal_period) are masked (CLIP text).  softmax in f32, result bf16 in place.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(bf16_t* __restrict__ x, long ld, int cols, float scale,
+                                                           const bf16_t* __restrict__ bias, long ldb, int causal_period) {
   __shared__ float red[8];
   bf16_t* row = x + (long)blockIdx.x * ld;
+  const bf16_t* brow = bias ? bias + (long)blockIdx.x * ldb : nullptr;
   const int tid = threadIdx.x;
+  const int limit = causal_period > 0 ? min(cols, (int)(blockIdx.x % causal_period) + 1) : cols;
   constexpr int MAXV = 64;
   float v[MAXV];
   float mx = -INFINITY;
 #pragma unroll
   for (int k = 0; k < MAXV; ++k) {
     const int c = k * 256 + tid;
-    v[k] = c < cols ? bf2f(row[c]) * scale : -INFINITY;
-    mx = fmaxf(mx, v[k]);
+    float t = -INFINITY;
+    if (c < limit) {
+      t = bf2f(row[c]) * scale;
+      if (scale != 1.0f) t = rbf(t);
+      if (brow) t = rbf(t + bf2f(brow[c]));
+    }
+    v[k] = t;
+    mx = fmaxf(mx, t);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
@@ -263,10 +273,12 @@ int vc_groupnorm_launch(const void* x, const void* gamma, const void* beta, void
   return VC_OK;
 }
 
-int vc_softmax_rows_launch(void* x, int64_t ld, int rows, int cols, float scale, hipStream_t s, char* err, int errlen) {
+int vc_softmax_rows_launch(void* x, int64_t ld, int rows, int cols, float scale, const void* bias, int64_t ldb, int causal_period,
+                           hipStream_t s, char* err, int errlen) {
   if (!x) { snprintf(err, errlen, "softmax_rows: null pointer"); return VC_ERR_ARG; }
-  if (rows <= 0 || cols <= 0 || cols > 256 * 64 || ld < cols) { snprintf(err, errlen, "softmax_rows: bad shape rows=%d cols=%d (cols <= 16384)", rows, cols); return VC_ERR_ARG; }
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, s, (bf16_t*)x, (long)ld, cols, scale);
+  if (rows <= 0 || cols <= 0 || cols > 256 * 64 || ld < cols || (bias && ldb < cols) || causal_period < 0) {
+    snprintf(err, errlen, "softmax_rows: bad shape rows=%d cols=%d (cols <= 16384)", rows, cols); return VC_ERR_ARG; }
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, s, (bf16_t*)x, (long)ld, cols, scale, (const bf16_t*)bias, (long)ldb, causal_period);
   VAE_LAUNCH_CHECK("softmax_rows");
   return VC_OK;
 }

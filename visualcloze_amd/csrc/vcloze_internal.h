@@ -27,9 +27,13 @@ int vc_sdedit_mix_launch(const void* noise, const void* latent, float strength, 
 int vc_im2col3x3_launch(const void* src, void* dst, int H, int W, int C, int up, hipStream_t s, char* err, int errlen);
 int vc_groupnorm_launch(const void* x, const void* gamma, const void* beta, void* y, void* scratch, int64_t scratch_bytes,
                         int64_t HW, int C, int G, float eps, int swish, hipStream_t s, char* err, int errlen);
-int vc_softmax_rows_launch(void* x, int64_t ld, int rows, int cols, float scale, hipStream_t s, char* err, int errlen);
+int vc_softmax_rows_launch(void* x, int64_t ld, int rows, int cols, float scale, const void* bias, int64_t ldb, int causal_period,
+                           hipStream_t s, char* err, int errlen);
 int vc_transpose_launch(const void* src, int64_t lds_, void* dst, int64_t ldd, int R, int Cc, hipStream_t s, char* err, int errlen);
 int vc_nchw_to_nhwc_launch(const void* src, int src_f32, void* dst, int C, int Cp, int64_t HW, float div, float add, hipStream_t s, char* err, int errlen);
 int vc_nhwc_to_nchw_launch(const void* src, void* dst, int dst_f32, int C, int Cp, int64_t HW, hipStream_t s, char* err, int errlen);
 int vc_gaussian_sample_launch(const void* moments, int Cp, const void* noise, void* out, int Z, int64_t HW, float scale, float shift,
                               hipStream_t s, char* err, int errlen);
+int vc_embedding_launch(const int32_t* ids, const void* table, int64_t ldt, int V, void* out, int L, int D, hipStream_t s, char* err, int errlen);
+int vc_rownorm_launch(const void* x, const void* w, const void* b, void* y, int rows, int D, float eps, int affine_ln, hipStream_t s, char* err, int errlen);
+int vc_ewise_launch(const void* a, const void* b, void* y, int64_t n, int op, hipStream_t s, char* err, int errlen);

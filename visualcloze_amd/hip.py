@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VC_HIP_LIB") or os.path.join(_HERE, "lib", "libvcloze_hip.so")   # VC_HIP_LIB: profiling build
 CSRC = os.path.join(_HERE, "csrc")
 
+GEMM_MAX_PROBLEMS = 4          # VC_GEMM_MAX_PROBLEMS: grouped problems per vc_gemm launch
 EPI_BIAS, EPI_GELU, EPI_GATE_RES, EPI_SILU = 0, 1, 2, 3
 
 
@@ -66,7 +67,13 @@ SYMBOLS = {
     "vc_unpack_latent": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _i32, _i32, _vp]),
     "vc_im2col3x3": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "vc_groupnorm": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, C.c_float, _i32, _vp]),
-    "vc_softmax_rows": (C.c_int, [_vp, _i64, _i32, _i32, C.c_float, _vp]),
+    "vc_softmax_rows": (C.c_int, [_vp, _i64, _i32, _i32, C.c_float, _vp, _i64, _i32, _vp]),
+    "vc_embedding": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i32, _i32, _vp]),
+    "vc_rmsnorm": (C.c_int, [_vp, _vp, _vp, _i32, _i32, C.c_float, _vp]),
+    "vc_layernorm": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, C.c_float, _vp]),
+    "vc_mul": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "vc_add": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "vc_quick_gelu": (C.c_int, [_vp, _vp, _i64, _vp]),
     "vc_transpose": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _vp]),
     "vc_nchw_to_nhwc": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i64, C.c_float, C.c_float, _vp]),
     "vc_nhwc_to_nchw": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _vp]),
@@ -337,12 +344,67 @@ def groupnorm_scratch_floats(HW, groups=32):
     return ((HW + 127) // 128 + 1) * 2 * groups
 
 
-def softmax_rows(x, scale, stream=None):
+def softmax_rows(x, scale, bias=None, causal_period=0, stream=None):
     _bf16(x, "x")
     if x.dim() != 2 or x.stride(1) != 1:
         raise VclozeHipError("softmax_rows: 2-D tensor with contiguous rows expected")
-    _check(lib().vc_softmax_rows(x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], scale,
+    ldb = 0
+    if bias is not None:
+        _bf16(bias, "bias")
+        if bias.dim() != 2 or bias.stride(1) != 1 or bias.shape != x.shape:
+            raise VclozeHipError("softmax_rows: bias must match x")
+        ldb = bias.stride(0)
+    _check(lib().vc_softmax_rows(x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], scale, _p(bias), ldb, causal_period,
                                  stream if stream is not None else cur_stream()), "vc_softmax_rows")
+
+
+# ---- text-encoder glue ----
+def embedding(ids, table, out, stream=None):
+    _bf16(table, "table"); _bf16(out, "out")
+    if ids.dtype != torch.int32 or not ids.is_cuda or ids.dim() != 1 or not ids.is_contiguous():
+        raise VclozeHipError("embedding: ids must be a contiguous CUDA int32 vector")
+    if table.stride(1) != 1 or not out.is_contiguous() or tuple(out.shape) != (ids.shape[0], table.shape[1]):
+        raise VclozeHipError("embedding: out [L, D] contiguous expected")
+    _check(lib().vc_embedding(ids.data_ptr(), table.data_ptr(), table.stride(0), table.shape[0], out.data_ptr(), ids.shape[0],
+                              table.shape[1], stream if stream is not None else cur_stream()), "vc_embedding")
+
+
+def rmsnorm(x, weight, y, eps, stream=None):
+    _bf16(x, "x"); _bf16(weight, "weight"); _bf16(y, "y")
+    if not (x.is_contiguous() and y.is_contiguous()) or x.shape != y.shape or weight.numel() != x.shape[1]:
+        raise VclozeHipError("rmsnorm: contiguous [rows, D] x, y and weight [D] expected")
+    _check(lib().vc_rmsnorm(x.data_ptr(), weight.data_ptr(), y.data_ptr(), x.shape[0], x.shape[1], eps,
+                            stream if stream is not None else cur_stream()), "vc_rmsnorm")
+
+
+def layernorm(x, weight, bias, y, eps, stream=None):
+    _bf16(x, "x"); _bf16(weight, "weight"); _bf16(bias, "bias"); _bf16(y, "y")
+    if not (x.is_contiguous() and y.is_contiguous()) or x.shape != y.shape or weight.numel() != x.shape[1]:
+        raise VclozeHipError("layernorm: contiguous [rows, D] x, y and weight/bias [D] expected")
+    _check(lib().vc_layernorm(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), x.shape[0], x.shape[1], eps,
+                              stream if stream is not None else cur_stream()), "vc_layernorm")
+
+
+def _ew(fn, name, a, b, y, stream):
+    for t in (a, b, y):
+        if t is not None:
+            _bf16(t, name)
+            if not t.is_contiguous() or t.numel() != y.numel():
+                raise VclozeHipError(f"{name}: contiguous tensors of equal size expected")
+    args = [a.data_ptr()] + ([b.data_ptr()] if b is not None else []) + [y.data_ptr(), y.numel(), stream if stream is not None else cur_stream()]
+    _check(fn(*args), name)
+
+
+def mul(a, b, y, stream=None):
+    _ew(lib().vc_mul, "vc_mul", a, b, y, stream)
+
+
+def add(a, b, y, stream=None):
+    _ew(lib().vc_add, "vc_add", a, b, y, stream)
+
+
+def quick_gelu(x, y, stream=None):
+    _ew(lib().vc_quick_gelu, "vc_quick_gelu", x, None, y, stream)
 
 
 def transpose(src, dst, stream=None):

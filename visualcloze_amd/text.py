@@ -1,0 +1,341 @@
+"""T5 encoder and CLIP text model on MI355X (text part).
+
+The reference wraps transformers' `T5EncoderModel` / `CLIPTextModel` in `HFEmbedder`
+(`models/modules/conditioner.py:5-37`; loaded by `models/util.py::load_t5 / load_clip`, called from
+`models/sampling.py::prepare_modified`): T5 returns `last_hidden_state` for 512 padded tokens with `attention_mask=None`
+(padding is attended), CLIP returns `pooler_output` for 77 tokens.  The classes here keep the module tree and
+`state_dict()` keys of the Hugging Face checkpoints (`encoder.block.N.layer.0.SelfAttention.q.weight`, ...,
+`text_model.encoder.layers.N.self_attn.q_proj.weight`, ...), take `input_ids` (tokenisation is host work) and run on
+the HIP library: projections and the per-head attention products on the bf16 MFMA GEMM (heads grouped four to a
+launch), T5LayerNorm / LayerNorm, row softmax with the relative-position bias or the causal mask, gated-GELU product and
+quick-GELU as HBM-bound kernels.  There is no torch / CPU fallback.
+
+The arithmetic lives in transformers (third party, not in /root/reference; the reference pins no version): parity is
+pinned against the transformers build in this image (tests/golden/make_text_golden.py) and anchored on the call site above.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import hip
+
+
+@dataclass
+class T5Config:                      # google/t5-v1_1-xxl encoder, the checkpoint load_t5 names (models/util.py)
+    vocab_size: int = 32128
+    d_model: int = 4096
+    d_kv: int = 64
+    d_ff: int = 10240
+    num_layers: int = 24
+    num_heads: int = 64
+    relative_attention_num_buckets: int = 32
+    relative_attention_max_distance: int = 128
+    layer_norm_epsilon: float = 1e-6
+
+
+@dataclass
+class CLIPTextConfig:                # openai/clip-vit-large-patch14 text tower (load_clip)
+    vocab_size: int = 49408
+    hidden_size: int = 768
+    intermediate_size: int = 3072
+    num_hidden_layers: int = 12
+    num_attention_heads: int = 12
+    max_position_embeddings: int = 77
+    layer_norm_eps: float = 1e-5
+    eos_token_id: int = 49407
+
+
+class _Lin(nn.Module):
+    def __init__(self, cin: int, cout: int, bias: bool):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(cout))
+        else:
+            self.register_parameter("bias", None)
+
+
+class _Norm(nn.Module):
+    def __init__(self, d: int, bias: bool):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(d))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(d))
+
+
+class _Emb(nn.Module):
+    def __init__(self, n: int, d: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(n, d))
+
+
+def _bf(t):
+    return t.detach().to(torch.bfloat16)
+
+
+class _Exec:
+    """Shared launch helpers: activations are [L, D] bf16 row-major."""
+
+    def _scratch(self, dev, name, shape, dtype=torch.bfloat16):
+        pool = self.__dict__.setdefault("_pool", {})
+        t = pool.get(name)
+        n = 1
+        for s in shape:
+            n *= s
+        if t is None or t.numel() < n or t.dtype != dtype or t.device != dev:
+            t = torch.empty(n, dtype=dtype, device=dev)
+            pool[name] = t
+        return t[:n].view(*shape)
+
+    def _ones(self, dev, n):
+        o = self._scratch(dev, "ones%d" % n, (n,))
+        o.fill_(1.0)
+        return o
+
+    def _linear(self, lin: _Lin, a, out, epi=hip.EPI_BIAS, res=None):
+        b = _bf(lin.bias) if lin.bias is not None else None
+        if res is None:
+            hip.gemm(hip.make_problem(a, _bf(lin.weight), b, out), epi=epi)
+        else:   # residual add: gated-residual epilogue with a gate of ones
+            hip.gemm(hip.make_problem(a, _bf(lin.weight), b, out, res=res, gate=self._ones(a.device, out.shape[1]),
+                                      rows_per_batch=a.shape[0]), epi=hip.EPI_GATE_RES)
+
+    def _heads_attention(self, q, k, v, L, H, dh, scale, bias, causal_period, tag):
+        """softmax(scale * q_h k_h^T (+ bias_h, causal)) v_h for every head; q, k, v, result are [L, H*dh]."""
+        dev = q.device
+        s = self._scratch(dev, "S" + tag, (H * L, L))
+        for h0 in range(0, H, hip.GEMM_MAX_PROBLEMS):
+            probs = [hip.make_problem(q[:, h * dh:(h + 1) * dh], k[:, h * dh:(h + 1) * dh], None, s[h * L:(h + 1) * L])
+                     for h in range(h0, min(H, h0 + hip.GEMM_MAX_PROBLEMS))]
+            hip.gemm(probs, epi=hip.EPI_BIAS)
+        hip.softmax_rows(s, scale, bias=bias, causal_period=causal_period)
+        vt = self._scratch(dev, "VT" + tag, (H * dh, L))
+        hip.transpose(v, vt)
+        o = self._scratch(dev, "O" + tag, (L, H * dh))
+        for h0 in range(0, H, hip.GEMM_MAX_PROBLEMS):
+            probs = [hip.make_problem(s[h * L:(h + 1) * L], vt[h * dh:(h + 1) * dh], None, o[:, h * dh:(h + 1) * dh])
+                     for h in range(h0, min(H, h0 + hip.GEMM_MAX_PROBLEMS))]
+            hip.gemm(probs, epi=hip.EPI_BIAS)
+        return o
+
+
+# ------------------------------------------------------------------------------------------------------------ T5
+class _T5Attention(nn.Module):
+    def __init__(self, cfg: T5Config, has_bias_table: bool):
+        super().__init__()
+        inner = cfg.num_heads * cfg.d_kv
+        self.q, self.k, self.v = _Lin(cfg.d_model, inner, False), _Lin(cfg.d_model, inner, False), _Lin(cfg.d_model, inner, False)
+        self.o = _Lin(inner, cfg.d_model, False)
+        if has_bias_table:
+            self.relative_attention_bias = _Emb(cfg.relative_attention_num_buckets, cfg.num_heads)
+
+
+class _T5LayerSelfAttention(nn.Module):
+    def __init__(self, cfg, has_bias_table):
+        super().__init__()
+        self.SelfAttention = _T5Attention(cfg, has_bias_table)
+        self.layer_norm = _Norm(cfg.d_model, False)
+
+
+class _T5DenseGated(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.wi_0, self.wi_1 = _Lin(cfg.d_model, cfg.d_ff, False), _Lin(cfg.d_model, cfg.d_ff, False)
+        self.wo = _Lin(cfg.d_ff, cfg.d_model, False)
+
+
+class _T5LayerFF(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.DenseReluDense = _T5DenseGated(cfg)
+        self.layer_norm = _Norm(cfg.d_model, False)
+
+
+class _T5Block(nn.Module):
+    def __init__(self, cfg, has_bias_table):
+        super().__init__()
+        self.layer = nn.ModuleList([_T5LayerSelfAttention(cfg, has_bias_table), _T5LayerFF(cfg)])
+
+
+class _T5Stack(nn.Module):
+    def __init__(self, cfg, embed):
+        super().__init__()
+        self.embed_tokens = embed
+        self.block = nn.ModuleList([_T5Block(cfg, i == 0) for i in range(cfg.num_layers)])
+        self.final_layer_norm = _Norm(cfg.d_model, False)
+
+
+def t5_relative_buckets(L: int, num_buckets: int, max_distance: int) -> torch.Tensor:
+    """T5Attention._relative_position_bucket, bidirectional (transformers modeling_t5): [L, L] bucket ids for
+    relative_position = key - query."""
+    ctx = torch.arange(L)[:, None]
+    mem = torch.arange(L)[None, :]
+    rel = mem - ctx
+    nb = num_buckets // 2
+    buckets = (rel > 0).long() * nb
+    rel = rel.abs()
+    max_exact = nb // 2
+    is_small = rel < max_exact
+    large = max_exact + (torch.log(rel.float() / max_exact) / math.log(max_distance / max_exact) * (nb - max_exact)).long()
+    large = torch.min(large, torch.full_like(large, nb - 1))
+    return buckets + torch.where(is_small, rel, large)
+
+
+class T5EncoderModel(nn.Module, _Exec):
+    """`forward(input_ids [B, L]) -> last_hidden_state [B, L, d_model]` bf16; L must be a multiple of 64."""
+
+    def __init__(self, cfg: T5Config):
+        super().__init__()
+        self.cfg = cfg
+        self.shared = _Emb(cfg.vocab_size, cfg.d_model)
+        self.encoder = _T5Stack(cfg, self.shared)       # embed_tokens tied to shared, both keys in the state dict
+
+    def _position_bias(self, L, dev):
+        key = (L, self.encoder.block[0].layer[0].SelfAttention.relative_attention_bias.weight._version)
+        cache = self.__dict__.setdefault("_pb", {})
+        if cache.get("key") != key or cache["t"].device != dev:
+            cfg = self.cfg
+            b = t5_relative_buckets(L, cfg.relative_attention_num_buckets, cfg.relative_attention_max_distance).to(dev)
+            tab = _bf(self.encoder.block[0].layer[0].SelfAttention.relative_attention_bias.weight)     # [buckets, H]
+            cache["t"] = tab[b].permute(2, 0, 1).contiguous().view(cfg.num_heads * L, L)                # [H*L, L]
+            cache["key"] = key
+        return cache["t"]
+
+    def forward(self, input_ids: torch.Tensor) -> torch.Tensor:
+        hip.require_gpu()
+        cfg = self.cfg
+        if input_ids.dim() != 2 or input_ids.shape[1] % 64:
+            raise ValueError(f"T5EncoderModel expects input_ids [B, L] with L % 64 == 0, got {tuple(input_ids.shape)}")
+        outs = []
+        for ids in input_ids:
+            outs.append(self._encode_one(ids.to(torch.int32).contiguous()))
+        return torch.stack(outs)
+
+    def _encode_one(self, ids):
+        cfg, dev, L = self.cfg, ids.device, ids.shape[0]
+        D, H, dh, F = cfg.d_model, cfg.num_heads, cfg.d_kv, cfg.d_ff
+        inner = H * dh
+        bias = self._position_bias(L, dev)
+        x = self._scratch(dev, "x", (L, D))
+        hip.embedding(ids, _bf(self.shared.weight), x)
+        n = self._scratch(dev, "n", (L, D))
+        q, k, v = (self._scratch(dev, t, (L, inner)) for t in ("q", "k", "v"))
+        g, u = self._scratch(dev, "g", (L, F)), self._scratch(dev, "u", (L, F))
+        for blk in self.encoder.block:
+            sa, ff = blk.layer[0], blk.layer[1]
+            hip.rmsnorm(x, _bf(sa.layer_norm.weight), n, cfg.layer_norm_epsilon)
+            att = sa.SelfAttention
+            hip.gemm([hip.make_problem(n, _bf(att.q.weight), None, q), hip.make_problem(n, _bf(att.k.weight), None, k),
+                      hip.make_problem(n, _bf(att.v.weight), None, v)], epi=hip.EPI_BIAS)
+            o = self._heads_attention(q, k, v, L, H, dh, 1.0, bias, 0, "t5")       # T5 does not scale the scores
+            self._linear(att.o, o, x, res=x)
+            hip.rmsnorm(x, _bf(ff.layer_norm.weight), n, cfg.layer_norm_epsilon)
+            dd = ff.DenseReluDense
+            self._linear(dd.wi_0, n, g, epi=hip.EPI_GELU)                          # gelu_new = tanh GELU
+            self._linear(dd.wi_1, n, u)
+            hip.mul(g, u, g)
+            self._linear(dd.wo, g, x, res=x)
+        out = torch.empty(L, D, dtype=torch.bfloat16, device=dev)
+        hip.rmsnorm(x, _bf(self.encoder.final_layer_norm.weight), out, cfg.layer_norm_epsilon)
+        return out
+
+
+# ------------------------------------------------------------------------------------------------------------ CLIP
+class _CLIPAttention(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.k_proj, self.v_proj, self.q_proj, self.out_proj = (_Lin(d, d, True) for _ in range(4))
+
+
+class _CLIPMLP(nn.Module):
+    def __init__(self, d, f):
+        super().__init__()
+        self.fc1, self.fc2 = _Lin(d, f, True), _Lin(f, d, True)
+
+
+class _CLIPLayer(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.self_attn = _CLIPAttention(cfg.hidden_size)
+        self.layer_norm1 = _Norm(cfg.hidden_size, True)
+        self.mlp = _CLIPMLP(cfg.hidden_size, cfg.intermediate_size)
+        self.layer_norm2 = _Norm(cfg.hidden_size, True)
+
+
+class _CLIPEmbeddings(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.token_embedding = _Emb(cfg.vocab_size, cfg.hidden_size)
+        self.position_embedding = _Emb(cfg.max_position_embeddings, cfg.hidden_size)
+
+
+class _CLIPEncoder(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.layers = nn.ModuleList([_CLIPLayer(cfg) for _ in range(cfg.num_hidden_layers)])
+
+
+class _CLIPTextTransformer(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.embeddings = _CLIPEmbeddings(cfg)
+        self.encoder = _CLIPEncoder(cfg)
+        self.final_layer_norm = _Norm(cfg.hidden_size, True)
+
+
+class CLIPTextModel(nn.Module, _Exec):
+    """`forward(input_ids [B, L <= max_position_embeddings]) -> (pooler_output [B, D], last_hidden_state [B, L, D])`."""
+
+    def __init__(self, cfg: CLIPTextConfig):
+        super().__init__()
+        self.cfg = cfg
+        self.text_model = _CLIPTextTransformer(cfg)
+
+    def forward(self, input_ids: torch.Tensor):
+        hip.require_gpu()
+        cfg = self.cfg
+        if input_ids.dim() != 2 or input_ids.shape[1] > cfg.max_position_embeddings:
+            raise ValueError(f"CLIPTextModel expects input_ids [B, L <= {cfg.max_position_embeddings}], got {tuple(input_ids.shape)}")
+        hs = torch.stack([self._encode_one(ids.to(torch.int32).contiguous()) for ids in input_ids])
+        # pooled = hidden state at the EOS token (first occurrence), CLIPTextTransformer.forward
+        eos = (input_ids == cfg.eos_token_id).int().argmax(dim=-1)
+        pooled = hs[torch.arange(hs.shape[0], device=hs.device), eos]
+        return pooled, hs
+
+    def _encode_one(self, ids):
+        cfg, dev, L = self.cfg, ids.device, ids.shape[0]
+        D, H, F = cfg.hidden_size, cfg.num_attention_heads, cfg.intermediate_size
+        dh = D // H
+        Lp = (L + 63) // 64 * 64                       # rows L..Lp-1 are padding: causal masking keeps them out of rows < L
+        tm = self.text_model
+        idp = torch.zeros(Lp, dtype=torch.int32, device=dev)
+        idp[:L] = ids
+        x = self._scratch(dev, "x", (Lp, D))
+        hip.embedding(idp, _bf(tm.embeddings.token_embedding.weight), x)
+        pos = self._scratch(dev, "pos", (Lp, D))
+        pos.zero_()
+        pos[:L] = _bf(tm.embeddings.position_embedding.weight)[:L]
+        hip.add(x, pos, x)
+        n = self._scratch(dev, "n", (Lp, D))
+        q, k, v = (self._scratch(dev, t, (Lp, D)) for t in ("q", "k", "v"))
+        f1, f2 = self._scratch(dev, "f1", (Lp, F)), self._scratch(dev, "f2", (Lp, F))
+        for lyr in tm.encoder.layers:
+            hip.layernorm(x, _bf(lyr.layer_norm1.weight), _bf(lyr.layer_norm1.bias), n, cfg.layer_norm_eps)
+            at = lyr.self_attn
+            hip.gemm([hip.make_problem(n, _bf(at.q_proj.weight), _bf(at.q_proj.bias), q),
+                      hip.make_problem(n, _bf(at.k_proj.weight), _bf(at.k_proj.bias), k),
+                      hip.make_problem(n, _bf(at.v_proj.weight), _bf(at.v_proj.bias), v)], epi=hip.EPI_BIAS)
+            o = self._heads_attention(q, k, v, Lp, H, dh, float(dh) ** -0.5, None, Lp, "clip")
+            self._linear(at.out_proj, o, x, res=x)
+            hip.layernorm(x, _bf(lyr.layer_norm2.weight), _bf(lyr.layer_norm2.bias), n, cfg.layer_norm_eps)
+            self._linear(lyr.mlp.fc1, n, f1)
+            hip.quick_gelu(f1, f2)
+            self._linear(lyr.mlp.fc2, f2, x, res=x)
+        out = torch.empty(Lp, D, dtype=torch.bfloat16, device=dev)
+        hip.layernorm(x, _bf(tm.final_layer_norm.weight), _bf(tm.final_layer_norm.bias), out, cfg.layer_norm_eps)
+        return out[:L]

@@ -131,8 +131,9 @@ __global__ void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __res
   *(u32x4*)(y + i * 8) = o;
 }
 
-// one 256-thread block per row; cols <= 256 * 64.  v = bf16(scale * x) [+ bias, rounded to bf16 again]; causal: columns
+// one 256-thread block per row; cols <= 256 * MAXV (MAXV picked from cols at launch, up to 64).  v = bf16(scale * x) [+ bias, rounded to bf16 again]; causal: columns
 // j > (row % causal_period) are masked (CLIP text).  softmax in f32, result bf16 in place.
+template <int MAXV>   // register slots per thread: cols <= 256 * MAXV
 __global__ __launch_bounds__(256) void softmax_rows_kernel(bf16_t* __restrict__ x, long ld, int cols, float scale,
                                                            const bf16_t* __restrict__ bias, long ldb, int causal_period) {
   __shared__ float red[8];
@@ -140,7 +141,6 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(bf16_t* __restrict__ 
   const bf16_t* brow = bias ? bias + (long)blockIdx.x * ldb : nullptr;
   const int tid = threadIdx.x;
   const int limit = causal_period > 0 ? min(cols, (int)(blockIdx.x % causal_period) + 1) : cols;
-  constexpr int MAXV = 64;
   float v[MAXV];
   float mx = -INFINITY;
 #pragma unroll
@@ -278,7 +278,8 @@ int vc_softmax_rows_launch(void* x, int64_t ld, int rows, int cols, float scale,
   if (!x) { snprintf(err, errlen, "softmax_rows: null pointer"); return VC_ERR_ARG; }
   if (rows <= 0 || cols <= 0 || cols > 256 * 64 || ld < cols || (bias && ldb < cols) || causal_period < 0) {
     snprintf(err, errlen, "softmax_rows: bad shape rows=%d cols=%d (cols <= 16384)", rows, cols); return VC_ERR_ARG; }
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, s, (bf16_t*)x, (long)ld, cols, scale, (const bf16_t*)bias, (long)ldb, causal_period);
+  auto fn = cols <= 512 ? softmax_rows_kernel<2> : cols <= 2048 ? softmax_rows_kernel<8> : cols <= 8192 ? softmax_rows_kernel<32> : softmax_rows_kernel<64>;
+  hipLaunchKernelGGL(fn, dim3(rows), dim3(256), 0, s, (bf16_t*)x, (long)ld, cols, scale, (const bf16_t*)bias, (long)ldb, causal_period);
   VAE_LAUNCH_CHECK("softmax_rows");
   return VC_OK;
 }

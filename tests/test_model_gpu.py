@@ -222,3 +222,61 @@ def test_latent_pipeline_grid_and_sdedit_vs_oracle(model):
     st2, ev = O.sample_euler(model_fn2, x0, cond2, O.time_grid(4, 12, False, 1.0, strength=0.4), P)
     assert len(ev) == 3 and abs(ev[0] - 0.6) < 1e-6
     assert rel_l2(up[0], O.unpack_latent(st2[-1][0], 4, 12)) < 3e-2
+
+
+def test_generate_grid_pixels_to_pixels_vs_chained_oracles(model):
+    """The whole tensor path of process_images (VAE encode -> pack -> T5/CLIP -> fused sampler -> unpack -> VAE decode)
+    on tiny models, against the CPU oracles chained the same way in bf16 mode."""
+    import oracle.flux_oracle as O
+    from oracle import text_oracle as TO
+    from oracle import vae_oracle as VO
+    from tests.procedural import TINY, TINY_T5, procedural_ae_param, procedural_text_param, ptensor, tiny_ids
+    from visualcloze_amd import pipeline
+    from visualcloze_amd.text import CLIPTextConfig, CLIPTextModel, T5Config, T5EncoderModel
+    from visualcloze_amd.vae import AutoEncoder, AutoEncoderParams
+    m, sd = model
+    dev = "cuda"
+    AE = dict(resolution=32, in_channels=3, ch=64, out_ch=3, ch_mult=[1, 1, 1, 1], num_res_blocks=1, z_channels=16,
+              scale_factor=0.3611, shift_factor=0.1159)                         # 8x down like the FLUX AE
+    CL = dict(vocab_size=128, hidden_size=TINY["vec_in_dim"], intermediate_size=128, num_hidden_layers=1,
+              num_attention_heads=1, max_position_embeddings=16, layer_norm_eps=1e-5, eos_token_id=127)
+    ae = AutoEncoder(AutoEncoderParams(**AE)); asd = {k: procedural_ae_param(k, v.shape) for k, v in ae.state_dict().items()}
+    ae.load_state_dict(asd); ae = ae.to(dev).to(torch.bfloat16)
+    t5 = T5EncoderModel(T5Config(**TINY_T5)); tsd = {k: procedural_text_param(k, v.shape) for k, v in t5.state_dict().items()}
+    tsd["encoder.embed_tokens.weight"] = tsd["shared.weight"]
+    t5.load_state_dict(tsd); t5 = t5.to(dev).to(torch.bfloat16)
+    clip = CLIPTextModel(CLIPTextConfig(**CL)); csd = {k: procedural_text_param(k, v.shape) for k, v in clip.state_dict().items()}
+    clip.load_state_dict(csd); clip = clip.to(dev).to(torch.bfloat16)
+    assert TINY_T5["d_model"] == TINY["context_in_dim"]
+    H, W = 32, 64                                                                   # two rows of two 32x32 images
+    rows = [ptensor((3, H, W), 201 + i, q=7) for i in range(2)]
+    masks = [torch.zeros(1, 1, H, W), torch.cat((torch.zeros(1, 1, H, W // 2), torch.ones(1, 1, H, W // 2)), -1)]
+    enoise = [ptensor((1, 16, H // 8, W // 8), 211 + i, q=5) for i in range(2)]
+    t5_ids, clip_ids = tiny_ids(64, 128, seed=5), tiny_ids(16, 128, seed=6, eos=127, eos_at=7)
+    c = lambda t: t.to(dev, torch.bfloat16)  # noqa: E731
+    got = pipeline.generate_grid(m, ae, t5, clip, [c(r) for r in rows], [c(mm) for mm in masks], t5_ids[None].to(dev),
+                                 clip_ids[None].to(dev), seed=3, cfg=30.0, steps=4, encode_noise=[c(n) for n in enoise],
+                                 decode_rows=[1])
+    torch.cuda.synchronize()
+    # ---- the same chain with the oracles (bf16 rounding points) ----
+    G = O.FluxGeometry(**TINY)
+    P = O.Prec("bf16", "merged")
+    lat = [VO.encode(asd, r[None], AE, n, "bf16") for r, n in zip(rows, enoise)]
+    rng = torch.Generator(device=dev).manual_seed(3)
+    noise = [torch.randn([1, 16, H // 8, W // 8], device=dev, generator=rng).to(torch.bfloat16).float().cpu() for _ in rows]
+    txt = TO.t5_encode(tsd, t5_ids, TINY_T5, "bf16")[None]
+    vec = TO.clip_text(csd, clip_ids, CL, "bf16")[0][None]
+    img, ids, msk = O.prepare_grid([noise])
+    cond = torch.cat([torch.cat([O.pack_latent(l[0]) for l in lat]), torch.cat([O.pack_mask(mm[0, 0]) for mm in masks])], -1)[None]
+    T = txt.shape[1]
+
+    def model_fn(xin, tm):
+        return O.flux_forward(sd, G, xin, ids, txt, torch.zeros(1, T, 3), tm, vec, torch.ones(1, T, dtype=torch.int32), msk,
+                              torch.full((1,), 30.0), P=P)
+    states, _ = O.sample_euler(model_fn, img, cond, O.time_grid(4, img.shape[1], True, 1), P)
+    k = (H // 16) * (W // 16)
+    row1 = O.unpack_latent(states[-1][0, k:2 * k], H // 8, W // 8)
+    want = ((VO.decode(asd, row1[None], AE, "bf16")[0] + 1.0) / 2.0).clamp(0.0, 1.0)
+    assert got[0].shape == (3, H, W)
+    assert float(got[0].min()) >= 0.0 and float(got[0].max()) <= 1.0
+    assert rel_l2(got[0], want) < 6e-2, rel_l2(got[0], want)       # VAE + text + 3 evaluations + VAE, all in bf16

@@ -1,13 +1,17 @@
-"""Latent-space part of `VisualClozeModel.process_images` / `.upsampling` (visualcloze.py:147-245, 363-434) on the
-MI355X path: everything between the VAE / text encoders and the VAE decoder.  VAE and T5/CLIP stay with the caller
-(out of scope), so inputs are row latents, pixel fill masks and text embeddings.
+"""`VisualClozeModel.process_images` / `.upsampling` (visualcloze.py:147-245, 363-434) on the MI355X path.
 
-    rows = denoise_grid(model, noise_rows, cond_latent_rows, mask_rows, txt, vec, cfg=30, steps=30)
-    up   = sdedit_upsample(model, noise, latent, blank_latent, txt, vec, cfg=30, steps=10, strength=0.4)
+    rows = denoise_grid(model, noise_rows, cond_latent_rows, mask_rows, txt, vec, cfg=30, steps=30)       # latent space
+    up   = sdedit_upsample(model, noise, latent, blank_latent, txt, vec, cfg=30, steps=10, strength=0.4)  # latent space
+    imgs = generate_grid(model, ae, t5, clip, row_images, row_masks, t5_ids, clip_ids, seed, ...)         # pixels in/out
+
+`generate_grid` chains the whole tensor path of `process_images` (visualcloze.py:363-434): VAE-encode the grid rows,
+pack latents + fill masks into `cond`, draw the per-row noise, encode the prompt with T5 / CLIP, run the fused sampler,
+unpack, VAE-decode and map to [0, 1].  Image loading / resizing (PIL) and tokenisation are host work and stay with the
+caller: inputs are row tensors in [-1, 1] and token ids.
 """
 from __future__ import annotations
 
-from typing import List, Sequence
+from typing import List, Optional, Sequence
 
 import torch
 
@@ -56,3 +60,34 @@ def sdedit_upsample(model, noise: torch.Tensor, latent: torch.Tensor, blank_late
         time_shifting_factor=1.0, strength=strength)                                   # :184-193
     sample = fn(x0, model.forward, _kwargs(img_ids, img_mask, txt, vec, cond, cfg, dev))[-1][:1]
     return packing.unpack_rows(sample, [(h, w)])[0]
+
+
+@torch.no_grad()
+def generate_grid(model, ae, t5, clip, row_images: List[torch.Tensor], row_masks: List[torch.Tensor],
+                  t5_ids: torch.Tensor, clip_ids: torch.Tensor, seed: int, cfg: float = 30.0, steps: int = 30,
+                  encode_noise: Optional[List[torch.Tensor]] = None, decode_rows: Optional[Sequence[int]] = None,
+                  solver: str = "euler", time_shifting_factor=1) -> List[torch.Tensor]:
+    """One grid, pixels in, pixels out (visualcloze.py:363-434).
+
+    row_images[i]: [3, H, W_row] in [-1, 1] (the images of grid row i side by side); row_masks[i]: [1, 1, H, W_row]
+    pixel fill mask (1 = generate); t5_ids [1, 512], clip_ids [1, 77]; `seed` drives the initial noise exactly like
+    `torch.Generator(device).manual_seed(seed)` + one `torch.randn` per row (:394-399).  `encode_noise` are the VAE's
+    DiagonalGaussian samples per row (None: drawn with torch.randn_like, as the reference's encode does).
+    Returns the decoded rows `decode_rows` (default: all) as [3, H, W_row] tensors in [0, 1] (:430-432)."""
+    dev = row_images[0].device
+    lat = []
+    for i, img in enumerate(row_images):                                               # :377-378
+        n = None if encode_noise is None else encode_noise[i]
+        lat.append(ae.encode(img[None].to(torch.bfloat16), noise=n))
+    rng = torch.Generator(device=dev).manual_seed(int(seed))                           # :394
+    noise = [torch.randn([1, 16, img.shape[-2] // 8, img.shape[-1] // 8], device=dev, generator=rng).to(torch.bfloat16)
+             for img in row_images]                                                    # :395-399
+    txt = t5(t5_ids)                                                                   # prepare_modified -> HFEmbedder
+    vec, _ = clip(clip_ids)
+    rows = denoise_grid(model, noise, lat, row_masks, txt, vec, cfg=cfg, steps=steps, solver=solver,
+                        time_shifting_factor=time_shifting_factor)
+    out = []
+    for i in (range(len(rows)) if decode_rows is None else decode_rows):
+        img = ae.decode(rows[i])[0]                                                    # :430
+        out.append(((img.float() + 1.0) / 2.0).clamp_(0.0, 1.0))                       # :431-432
+    return out

@@ -185,3 +185,15 @@ def test_flux_width_encoder_matches_oracle(hip):
     noise = rel_l2(o16, o32)
     assert mom.shape == (1, 32, 8, 8)
     assert rel_l2(mom, o32) <= 3.0 * noise + 2e-3, (rel_l2(mom, o32), noise)
+
+
+def test_decoder_attention_with_odd_token_count(hip):
+    """h*w not a multiple of 8 (a 400x400-pixel image has a 50x50 latent): padded key rows / score columns stay zero."""
+    ae, sd = tiny_model()
+    z = ptensor((1, TINY_AE["z_channels"], 5, 7), 51, q=5, kmax=96)
+    out = ae.decode(z.to(DEV).to(torch.bfloat16)).float().cpu()
+    o32 = VO.decode(sd, z, TINY_AE, "fp32")
+    o16 = VO.decode(sd, z, TINY_AE, "bf16")
+    noise = rel_l2(o16, o32)
+    assert out.shape == o32.shape
+    assert rel_l2(out, o32) <= 3.0 * noise + 2e-3, (rel_l2(out, o32), noise)

@@ -169,15 +169,16 @@ class _HipExec(nn.Module):
         dev, (L, Cc) = x.device, x.shape
         t = self._scratch(dev, "t0", (L, Cc))
         self._norm(blk.norm, x, t, False)
-        q, k, v = (self._scratch(dev, n, (L, Cc)) for n in ("aq", "ak", "av"))
-        self._conv1(blk.q, t, q); self._conv1(blk.k, t, k); self._conv1(blk.v, t, v)
-        if L % 8:
-            raise hip.VclozeHipError(f"AttnBlock: h*w = {L} must be a multiple of 8")
-        Lp = _pad_to(L, 64)                                  # K of the P.V GEMM; the pad columns of P and V^T stay zero
+        Lk, Lp = _pad_to(L, 8), _pad_to(L, 64)               # N of the S GEMM / K of the P.V GEMM; pads stay zero
+        q, v = self._scratch(dev, "aq", (L, Cc)), self._scratch(dev, "av", (L, Cc))
+        k = self._scratch(dev, "ak", (Lk, Cc))
+        if Lk != L:
+            k[L:].zero_()                                    # zero key rows -> zero score columns L..Lk-1
+        self._conv1(blk.q, t, q); self._conv1(blk.k, t, k[:L]); self._conv1(blk.v, t, v)
         s = self._scratch(dev, "as", (L, Lp))
         if Lp != L:
             s.zero_()
-        hip.gemm(hip.make_problem(q, k, None, s[:, :L]), epi=hip.EPI_BIAS)                  # S = Q K^T  [L, L]
+        hip.gemm(hip.make_problem(q, k, None, s[:, :Lk]), epi=hip.EPI_BIAS)                 # S = Q K^T  [L, L]
         hip.softmax_rows(s[:, :L], float(Cc) ** -0.5)
         vt = self._scratch(dev, "avt", (Cc, Lp))
         if Lp != L:

@@ -237,3 +237,38 @@ def test_graph_replay_with_device_step_counter(hip):
             g.launch()
             st.synchronize()
             check(out, R.gemm_ref(a, w, bias, 2, res, gates[i]))
+
+
+def test_gemm_randomised_shape_sweep(hip):
+    """Seeded sweep over ragged shapes for the two tiles the cost model picks (128x128, 256x192 + loader waves): M not a
+    multiple of any tile, N only a multiple of 8 (bias / staging slices that end mid-tile), K = 64 ... 1024 (1 to 16
+    K-tiles: prologue-only, ring wrap-around), with and without bias, every epilogue, plus a 3-problem grouped launch."""
+    g = torch.Generator().manual_seed(2024)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))  # noqa: E731
+    for it in range(14):
+        M, N, K = ri(1, 700), 8 * ri(1, 60), 64 * ri(1, 16)
+        epi = it % 4
+        a, w = rnd(M, K, seed=100 + it), rnd(N, K, scale=K ** -0.5, seed=200 + it)
+        bias = rnd(N, seed=300 + it) if it % 3 else None
+        res, gate = rnd(M, N, seed=400 + it), rnd(N, seed=500 + it)
+        for cfg in (1, 36, 0):
+            out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+            p = hip.make_problem(a, w, bias, out, res=res if epi == 2 else None, gate=gate if epi == 2 else None)
+            hip.gemm(p, epi=epi, tile_cfg=cfg)
+            torch.cuda.synchronize()
+            check(out, R.gemm_ref(a, w, bias if bias is not None else torch.zeros(N, dtype=torch.bfloat16, device=DEV), epi, res, gate))
+    # grouped: three problems of different M / N sharing K
+    K = 192
+    probs, refs, outs, keep = [], [], [], []     # GemmProblem holds raw pointers: the operands must stay referenced
+    for j, (M, N) in enumerate([(300, 200), (17, 456), (260, 8)]):
+        a, w, b = rnd(M, K, seed=600 + j), rnd(N, K, scale=K ** -0.5, seed=610 + j), rnd(N, seed=620 + j)
+        o = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        keep.append((a, w, b))
+        probs.append(hip.make_problem(a, w, b, o)); outs.append(o); refs.append(R.gemm_ref(a, w, b, 0))
+    for cfg in (1, 36):
+        for o in outs:
+            o.fill_(float("nan"))
+        hip.gemm(probs, epi=0, tile_cfg=cfg)
+        torch.cuda.synchronize()
+        for o, r in zip(outs, refs):
+            check(o, r)

@@ -178,6 +178,7 @@ def make_problem(a, w, bias, out, res=None, gate=None, rows_per_batch=None, gate
     if gate is not None:
         _bf16(gate, "gate")
         p.gate, p.gate_bstride = gate.data_ptr(), gate_bstride
+    p._keep = (a, w, bias, out, res, gate)   # the struct carries raw pointers: keep the operands alive with it
     return p
 
 

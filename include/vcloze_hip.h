@@ -143,6 +143,12 @@ int vc_unpack_latent(const void* tokens, int64_t ld, int32_t col0, void* latent,
  *              scale * ((mean + exp(0.5*logvar) * noise) - shift); noise [Z, HW] bf16 or NULL for the mean
  *              (DiagonalGaussian.forward :268-275, AutoEncoder.encode :301-304). */
 int vc_im2col3x3(const void* src, void* dst, int32_t H, int32_t W, int32_t C, int32_t mode, void* stream);
+/* conv3x3: the same convolution as vc_im2col3x3 + vc_gemm in ONE launch, no [H*W, 9C] matrix in HBM: the GEMM's loader
+ * waves gather the taps from the NHWC map x, which must carry ONE EXTRA ZERO ROW after its Hs*Ws pixel rows (the source
+ * of every out-of-image tap).  w [O, 9*C] with K ordered (dy, dx, c), C % 64 == 0, O % 8 == 0; out [H*W, O] row stride
+ * ldc; res/gate NULL -> y = bf16(acc + bias), else y = bf16(res + bf16(gate * bf16(acc + bias))) (gate [O]). */
+int vc_conv3x3(const void* x, const void* w, const void* bias, void* out, int64_t ldc, const void* res, int64_t ldres,
+               const void* gate, int32_t H, int32_t W, int32_t C, int32_t O, int32_t mode, void* stream);
 int vc_groupnorm(const void* x, const void* gamma, const void* beta, void* y, void* scratch, int64_t scratch_bytes,
                  int64_t HW, int32_t C, int32_t G, float eps, int32_t swish, void* stream);
 int vc_softmax_rows(void* x, int64_t ld, int32_t rows, int32_t cols, float scale, const void* bias, int64_t ld_bias,

@@ -197,3 +197,27 @@ def test_decoder_attention_with_odd_token_count(hip):
     noise = rel_l2(o16, o32)
     assert out.shape == o32.shape
     assert rel_l2(out, o32) <= 3.0 * noise + 2e-3, (rel_l2(out, o32), noise)
+
+
+@pytest.mark.parametrize("H,W,C,O,mode", [(4, 4, 64, 64, 0), (9, 13, 128, 200, 0), (8, 12, 64, 72, 1), (3, 5, 64, 8, 2),
+                                          (40, 56, 256, 128, 0), (34, 30, 64, 320, 1)])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_conv3x3_implicit_gemm_equals_im2col_plus_gemm(hip, H, W, C, O, mode, with_res):
+    """One-launch convolution (the loader waves gather the taps) vs the explicit im2col matrix + GEMM: bit-identical."""
+    up, down = mode == 1, mode == 2
+    hs, ws = (H // 2, W // 2) if up else (2 * H, 2 * W) if down else (H, W)
+    x = torch.zeros(hs * ws + 1, C, dtype=torch.bfloat16, device=DEV)          # last row = the zero row
+    x[:-1] = bf(ptensor((hs * ws, C), 61, q=5))
+    w, b = bf(ptensor((O, 9 * C), 62, q=9)), bf(ptensor((O,), 63, q=6))
+    res, gate = bf(ptensor((H * W, O), 64, q=5)), torch.ones(O, dtype=torch.bfloat16, device=DEV)
+    col = torch.empty(H * W, 9 * C, dtype=torch.bfloat16, device=DEV)
+    hip.im2col3x3(x[:-1], col, H, W, up=up, down=down)
+    ref = torch.empty(H * W, O, dtype=torch.bfloat16, device=DEV)
+    if with_res:
+        hip.gemm(hip.make_problem(col, w, b, ref, res=res, gate=gate, rows_per_batch=H * W), epi=hip.EPI_GATE_RES)
+    else:
+        hip.gemm(hip.make_problem(col, w, b, ref), epi=hip.EPI_BIAS)
+    out = torch.full((H * W, O), float("nan"), dtype=torch.bfloat16, device=DEV)
+    hip.conv3x3(x, w, b, out, H, W, up=up, down=down, res=res if with_res else None, gate=gate if with_res else None)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)

@@ -111,6 +111,10 @@ int vc_nhwc_to_nchw(const void* src, void* dst, int32_t dst_is_f32, int32_t C, i
 int vc_gaussian_sample(const void* moments, int32_t Cp, const void* noise, void* out, int32_t Z, int64_t HW, float scale, float shift, void* stream) {
   return vc_gaussian_sample_launch(moments, Cp, noise, out, Z, HW, scale, shift, S(stream), ERRBUF);
 }
+int vc_conv3x3(const void* x, const void* w, const void* bias, void* out, int64_t ldc, const void* res, int64_t ldres,
+               const void* gate, int32_t H, int32_t W, int32_t C, int32_t O, int32_t mode, void* stream) {
+  return vc_conv3x3_launch(x, w, bias, out, ldc, res, ldres, gate, H, W, C, O, mode, S(stream), ERRBUF);
+}
 int vc_pack_latent(const void* latent, void* tokens, int32_t C, int32_t h, int32_t w, int64_t ld, int32_t col0, void* stream) {
   return vc_pack_latent_launch(latent, tokens, C, h, w, ld, col0, S(stream), ERRBUF);
 }

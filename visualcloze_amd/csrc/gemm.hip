@@ -14,6 +14,7 @@
 // Double-buffered LDS, one barrier per K-tile. Operands are swapped in the MFMA (D = W_frag x A_frag)
 // so each lane ends up with 4 consecutive n of one row m -> 8-byte epilogue stores.
 // Up to two problems per launch ("grouped": img + txt streams of a DoubleStreamBlock share a grid).
+#include <string.h>
 #include "common.h"
 #include "vcloze_internal.h"
 
@@ -21,8 +22,12 @@ namespace {
 
 constexpr int BK = 64;
 
-template <int BM, int BN, int WM, int WN, int EPI, int PP>
+// CONV (loader-wave schedule only): the A operand is the im2col matrix of a 3x3 convolution over an NHWC map, gathered
+// on the fly by the loader waves - K-tile kt lies inside tap kt*64 / C, row m is output pixel (m / W, m % W), out-of-
+// image taps read a zero row appended to the map.  Geometry rides in the A-addressing fields (vc_conv3x3_launch).
+template <int BM, int BN, int WM, int WN, int EPI, int PP, bool CONV = false>
 __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_kernel(const VcGemmArgs args) {
+  static_assert(!CONV || PP == 2, "the implicit-convolution A operand is gathered by loader waves");
   constexpr int NCW = WM * WN;                       // compute waves
   constexpr int NT = (NCW + (PP == 2 ? 4 : 0)) * 64;  // PP == 2 adds 4 loader waves (one per SIMD)
   constexpr int NS = PP == 2 ? 256 : NT;              // threads that stage operand tiles
@@ -90,6 +95,37 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
     const int grow = min(n0 + row, N - 1);
     b_off[i] = (uint32_t)grow * (uint32_t)P.ldw + slot * 8;
   }
+  // implicit 3x3 convolution: (y, x) of the output pixel each A piece of this thread belongs to, packed y << 16 | x
+  const int cvC = (int)P.lda, cvW = P.a_rpb, cvH = (int)(P.a_bstride & 0xffffffff), cvMode = (int)(P.a_bstride >> 32);
+  uint32_t cv_yx[CONV ? A_IT : 1];
+  int cv_dy = 0, cv_dx = 0, cv_c0 = 0;               // tap and channel offset of the K-tile being staged
+  if constexpr (CONV) {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int grow = min(m0 + ((i * NS + stid) >> 3), M - 1);
+      cv_yx[i] = ((uint32_t)(grow / cvW) << 16) | (uint32_t)(grow % cvW);
+    }
+  }
+  auto conv_set_k = [&](int k0) {                     // k0 is wave-uniform
+    const int tap = k0 / cvC;
+    cv_c0 = k0 - tap * cvC;
+    cv_dy = tap / 3;
+    cv_dx = tap - cv_dy * 3;
+  };
+  auto conv_src = [&](int i) -> const bf16_t* {
+    const int y = (int)(cv_yx[CONV ? i : 0] >> 16), x = (int)(cv_yx[CONV ? i : 0] & 0xffff);
+    long src;
+    if (cvMode == 2) {                                // pad (0,1,0,1) + stride 2 over a [2H, 2W] map
+      const int yy = 2 * y + cv_dy, xx = 2 * x + cv_dx;
+      src = (yy < 2 * cvH && xx < 2 * cvW) ? (long)yy * (2 * cvW) + xx : 4L * cvH * cvW;
+    } else {
+      const int yy = y + cv_dy - 1, xx = x + cv_dx - 1;
+      const bool ok = yy >= 0 && yy < cvH && xx >= 0 && xx < cvW;
+      if (cvMode == 1) src = ok ? (long)(yy >> 1) * (cvW >> 1) + (xx >> 1) : (long)(cvH >> 1) * (cvW >> 1);   // nearest 2x
+      else src = ok ? (long)yy * cvW + xx : (long)cvH * cvW;
+    }
+    return Ab + src * cvC + cv_c0 + (((stid & 7) ^ ((stid >> 3) & 7)) << 3);
+  };
 
   auto stage = [&](int buf, int k0) {
 #ifdef VC_GEMM_NO_DMA     // analysis builds only: core side of the loop alone (operands of K-tile 0 reused)
@@ -108,7 +144,10 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
   // followed by the tile's bias slice
   constexpr int W_RING0 = 2 * A_BYTES;
   constexpr int LW_BIAS_OFF = 2 * A_BYTES + 3 * B_BYTES;
-  auto stage_a_piece = [&](int slot, int k0, int i) { glds16(Ab + a_off[i] + k0, smem + slot * A_BYTES + (i * NS + swave * 64) * 16); };
+  auto stage_a_piece = [&](int slot, int k0, int i) {
+    if constexpr (CONV) glds16(conv_src(i), smem + slot * A_BYTES + (i * NS + swave * 64) * 16);   // (conv_set_k(k0) done by the caller)
+    else glds16(Ab + a_off[i] + k0, smem + slot * A_BYTES + (i * NS + swave * 64) * 16);
+  };
   auto stage_w_piece = [&](int slot, int k0, int i) { glds16(Wb + b_off[i] + k0, smem + W_RING0 + slot * B_BYTES + (i * NS + swave * 64) * 16); };
 
   // ---- fragment read offsets ----
@@ -189,6 +228,7 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
       for (int kt = 0; kt < nk; ++kt) {
         const int as1 = (kt & 1) ^ 1, k1 = (kt + 1) * BK, kd = (kt + WD) * BK;
         const bool more1 = kt + 1 < nk, mored = kt + WD < nk;
+        if constexpr (CONV) conv_set_k(k1);
         // piece j of round t: j < A_IT -> A(t+1) piece j, else W(t+2) piece j - A_IT
         auto piece = [&](int j) {
 #ifdef VC_GEMM_NO_DMA     // analysis builds only: core side of the loop alone
@@ -423,7 +463,51 @@ hipError_t launch_cfg(const VcGemmArgs& a, int total_tiles, hipStream_t s) {
   return hipGetLastError();
 }
 
+// 3x3 convolution over an NHWC map as ONE GEMM launch: the loader waves gather the im2col rows on the fly
+hipError_t launch_conv(const VcGemmArgs& a, int total_tiles, hipStream_t s) {
+  constexpr int BM = 256, BN = 192, NT = 12 * 64;
+  constexpr int LDS_STAGES = (2 * BM + 3 * BN) * BK * 2 + BN * 2, LDS_EPI = BM * (BN * 2 + 16);
+  constexpr int LDS = LDS_STAGES > LDS_EPI ? LDS_STAGES : LDS_EPI;
+  void (*fn)(const VcGemmArgs) = a.epi == VC_EPI_GATE_RES ? gemm_bf16_kernel<BM, BN, 4, 2, VC_EPI_GATE_RES, 2, true>
+                                                          : gemm_bf16_kernel<BM, BN, 4, 2, VC_EPI_BIAS, 2, true>;
+  static bool attr_done[2] = {false, false};
+  const int k = a.epi == VC_EPI_GATE_RES ? 1 : 0;
+  if (!attr_done[k]) {
+    hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return e;
+    attr_done[k] = true;
+  }
+  hipLaunchKernelGGL(fn, dim3(total_tiles), dim3(NT), LDS, s, a);
+  return hipGetLastError();
+}
+
 }  // namespace
+
+// y[H*W, O] = conv3x3(x) + bias (+ gate * . + res): x is an NHWC map [Hs*Ws + 1, C] whose LAST row is zero (the source of
+// every out-of-image tap), w is [O, 9*C] with K ordered (dy, dx, c).  mode 0: same size; 1: x is the half-resolution map
+// (nearest 2x upsampling folded in); 2: x is the double-resolution map, pad (0,1,0,1) + stride 2.
+int vc_conv3x3_launch(const void* x, const void* w, const void* bias, void* out, int64_t ldc, const void* res, int64_t ldres,
+                      const void* gate, int H, int W, int C, int O, int mode, hipStream_t s, char* err, int errlen) {
+  if (!x || !w || !out) { snprintf(err, errlen, "conv3x3: null pointer"); return VC_ERR_ARG; }
+  if (H <= 0 || W <= 0 || W >= 65536 || H >= 65536 || C <= 0 || C % 64 || O <= 0 || O % 8 || ldc % 8 || ldc < O || mode < 0 || mode > 2 ||
+      (mode == 1 && ((H | W) & 1)) || (res && (!gate || ldres % 8)) || (int64_t)H * W >= (1LL << 31) / 4) {
+    snprintf(err, errlen, "conv3x3: bad arguments H=%d W=%d C=%d O=%d mode=%d (C %% 64 == 0, O %% 8 == 0)", H, W, C, O, mode); return VC_ERR_ARG; }
+  VcGemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.nprob = 1;
+  a.epi = res ? VC_EPI_GATE_RES : VC_EPI_BIAS;
+  VcGemmProblem& p = a.p[0];
+  p.A = x; p.W = w; p.bias = bias; p.C = out; p.res = res; p.gate = gate;
+  p.lda = C;                                   // channels per tap = row stride of the map
+  p.a_rpb = W;                                 // output width
+  p.a_bstride = (int64_t)H | ((int64_t)mode << 32);
+  p.ldw = 9 * (int64_t)C; p.ldc = ldc; p.ldres = ldres;
+  p.M = H * W; p.N = O; p.K = 9 * C; p.rows_per_batch = p.M;
+  p.tiles_m = (p.M + 255) / 256; p.tiles_n = (p.N + 191) / 192; p.tile_start = 0;
+  hipError_t e = launch_conv(a, p.tiles_m * p.tiles_n, s);
+  if (e != hipSuccess) { snprintf(err, errlen, "conv3x3 launch: %s", hipGetErrorString(e)); return VC_ERR_HIP; }
+  return VC_OK;
+}
 
 // tile_cfg: 0 = auto, 1 = 128x128 (4 waves), 2 = 256x128, 3 = 256x256, 4 = 256x192, 5 = 256x288 (8 waves each)
 int vc_gemm_launch(VcGemmArgs a, int tile_cfg, hipStream_t s, char* err, int errlen) {

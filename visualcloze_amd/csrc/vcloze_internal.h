@@ -37,3 +37,5 @@ int vc_gaussian_sample_launch(const void* moments, int Cp, const void* noise, vo
 int vc_embedding_launch(const int32_t* ids, const void* table, int64_t ldt, int V, void* out, int L, int D, hipStream_t s, char* err, int errlen);
 int vc_rownorm_launch(const void* x, const void* w, const void* b, void* y, int rows, int D, float eps, int affine_ln, hipStream_t s, char* err, int errlen);
 int vc_ewise_launch(const void* a, const void* b, void* y, int64_t n, int op, hipStream_t s, char* err, int errlen);
+int vc_conv3x3_launch(const void* x, const void* w, const void* bias, void* out, int64_t ldc, const void* res, int64_t ldres,
+                      const void* gate, int H, int W, int C, int O, int mode, hipStream_t s, char* err, int errlen);

@@ -66,6 +66,7 @@ SYMBOLS = {
     "vc_pack_mask": (C.c_int, [_vp, _vp, _i32, _i32, _i64, _i32, _vp]),
     "vc_unpack_latent": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _i32, _i32, _vp]),
     "vc_im2col3x3": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "vc_conv3x3": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vc_groupnorm": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, C.c_float, _i32, _vp]),
     "vc_softmax_rows": (C.c_int, [_vp, _i64, _i32, _i32, C.c_float, _vp, _i64, _i32, _vp]),
     "vc_embedding": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i32, _i32, _vp]),
@@ -329,6 +330,22 @@ def im2col3x3(src, dst, H, W, up=False, down=False, stream=None):
         raise VclozeHipError("im2col3x3: src [Hs*Ws, C] and dst [H*W, 9C] contiguous expected")
     _check(lib().vc_im2col3x3(src.data_ptr(), dst.data_ptr(), H, W, Cc, 1 if up else 2 if down else 0,
                               stream if stream is not None else cur_stream()), "vc_im2col3x3")
+
+
+def conv3x3(x, w, bias, out, H, W, up=False, down=False, res=None, gate=None, stream=None):
+    """One-launch 3x3 convolution (implicit GEMM).  x: [Hs*Ws + 1, C] NHWC map whose last row is zero; w [O, 9C];
+    out [H*W, O]; optional residual: out = res + gate * (conv + bias)."""
+    _bf16(x, "x"); _bf16(w, "w"); _bf16(out, "out")
+    Cc, O = x.shape[1], w.shape[0]
+    hs, ws = (H >> 1, W >> 1) if up else (2 * H, 2 * W) if down else (H, W)
+    if (up and down) or x.shape[0] != hs * ws + 1 or not x.is_contiguous() or w.shape[1] != 9 * Cc or not w.is_contiguous() \
+            or tuple(out.shape) != (H * W, O) or out.stride(1) != 1:
+        raise VclozeHipError("conv3x3: x [Hs*Ws + 1, C] (last row zero), w [O, 9C], out [H*W, O] expected")
+    if res is not None:
+        _bf16(res, "res"); _bf16(gate, "gate")
+    _check(lib().vc_conv3x3(x.data_ptr(), w.data_ptr(), _p(bias), out.data_ptr(), out.stride(0), _p(res),
+                            res.stride(0) if res is not None else 0, _p(gate), H, W, Cc, O, 1 if up else 2 if down else 0,
+                            stream if stream is not None else cur_stream()), "vc_conv3x3")
 
 
 def groupnorm(x, gamma, beta, y, scratch, groups=32, eps=1e-6, swish=False, stream=None):

@@ -4,8 +4,9 @@ Mirrors the reference's vendored twin `models/modules/autoencoder.py` (classes `
 `Downsample` :85-95, `Upsample` :98-106, `Encoder` :109-180, `Decoder` :183-259, `DiagonalGaussian` :262-275,
 `AutoEncoder` :277-311): same constructor arguments, same module tree and therefore the same `state_dict()` keys and
 shapes, so `ae.safetensors` loads unchanged.  Execution is
-NHWC bf16 on the HIP library: every 3x3 convolution is an im2col gather (`vc_im2col3x3`, which also folds the nearest
-2x upsampling) followed by the bf16 MFMA GEMM with fused bias / residual epilogue, GroupNorm+swish is `vc_groupnorm`,
+NHWC bf16 on the HIP library: every 3x3 convolution is ONE launch of the bf16 MFMA GEMM whose loader waves gather the
+taps straight from the NHWC map (`vc_conv3x3`: implicit GEMM, nearest-2x upsampling / stride-2 downsampling folded into
+the addressing, fused bias / residual epilogue), GroupNorm+swish is `vc_groupnorm`,
 the mid-block attention (one head, head_dim = C) is two GEMMs around `vc_softmax_rows`.  There is no CPU or torch
 fallback: without the GPU library `decode` raises.
 
@@ -126,47 +127,62 @@ class _HipExec(nn.Module):
             pool[name] = t
         return t[:n].view(*shape)
 
-    def _conv3(self, conv: _Conv, x, H, W, out, up=False, down=False, res=None):
-        """out[H*W, O_pad] = conv3x3(x) (+ res); (H, W) is the output map, x the (possibly half / double size) input."""
+    def _act(self, dev, name, HW, C):
+        """Activation map [HW + 1, C]: rows 0..HW-1 are the pixels, row HW is the zero row that vc_conv3x3 reads for
+        every out-of-image tap (writers only touch rows < HW)."""
+        t = self._scratch(dev, name, (HW + 1, C))
+        t[HW].zero_()
+        return t
+
+    def _conv3(self, conv: _Conv, xz, H, W, out, up=False, down=False, res=None):
+        """out[H*W, O_pad] = conv3x3(x) (+ res); (H, W) is the output map; xz is an `_act` map (zero row appended) of the
+        same, half (`up`) or double (`down`) resolution.  One launch: the GEMM's loader waves gather the taps."""
         w, b = conv.prepared()
-        col = self._scratch(x.device, "col", (H * W, 9 * x.shape[1]))
-        hip.im2col3x3(x, col, H, W, up=up, down=down)
-        self._gemm(col, w, b, out, res)
+        gate = None if res is None else self._ones(xz.device, out.shape[1])     # x + h (autoencoder.py:82) = gate of ones
+        hip.conv3x3(xz, w, b, out, H, W, up=up, down=down, res=res, gate=gate)
+
+    def _ones(self, dev, n):
+        pool = self.__dict__.setdefault("_pool", {})
+        o = pool.get("ones%d" % n)
+        if o is None or o.device != dev:
+            o = torch.ones(n, dtype=torch.bfloat16, device=dev)       # filled once, never written again
+            pool["ones%d" % n] = o
+        return o
 
     def _conv1(self, conv: _Conv, x, out, res=None):
         w, b = conv.prepared()
-        self._gemm(x, w, b, out, res)
-
-    def _gemm(self, a, w, b, out, res):
         if res is None:
-            hip.gemm(hip.make_problem(a, w, b, out), epi=hip.EPI_BIAS)
-        else:   # x + h (autoencoder.py:82, :52): the gated-residual epilogue with a gate of ones
-            ones = self._scratch(a.device, "ones%d" % out.shape[1], (out.shape[1],))
-            ones.fill_(1.0)
-            hip.gemm(hip.make_problem(a, w, b, out, res=res, gate=ones, rows_per_batch=a.shape[0]), epi=hip.EPI_GATE_RES)
+            hip.gemm(hip.make_problem(x, w, b, out), epi=hip.EPI_BIAS)
+        else:
+            hip.gemm(hip.make_problem(x, w, b, out, res=res, gate=self._ones(x.device, out.shape[1]), rows_per_batch=x.shape[0]),
+                     epi=hip.EPI_GATE_RES)
 
     def _norm(self, gn: _GroupNorm, x, y, swish):
         sc = self._scratch(x.device, "gn", (hip.groupnorm_scratch_floats(x.shape[0]),), torch.float32)
         hip.groupnorm(x, gn.weight.detach().to(torch.bfloat16), gn.bias.detach().to(torch.bfloat16), y, sc, swish=swish)
 
     def _resnet(self, blk: ResnetBlock, x, H, W, tag):
+        """x: `_act` map [HW+1, Cin]; returns an `_act` map [HW+1, Cout]."""
         dev, HW = x.device, H * W
-        t = self._scratch(dev, "t0", (HW, blk.in_channels))
-        self._norm(blk.norm1, x, t, True)
+        t = self._act(dev, "t0", HW, blk.in_channels)
+        self._norm(blk.norm1, x[:HW], t[:HW], True)
         h = self._scratch(dev, "t1", (HW, blk.out_channels))
         self._conv3(blk.conv1, t, H, W, h)
-        t2 = self._scratch(dev, "t2", (HW, blk.out_channels))
-        self._norm(blk.norm2, h, t2, True)
+        t2 = self._act(dev, "t2", HW, blk.out_channels)
+        self._norm(blk.norm2, h, t2[:HW], True)
+        r = x[:HW]
         if blk.in_channels != blk.out_channels:
             sc = self._scratch(dev, "t3", (HW, blk.out_channels))
-            self._conv1(blk.nin_shortcut, x, sc)
-            x = sc
-        out = self._scratch(dev, "x" + tag, (HW, blk.out_channels))
-        self._conv3(blk.conv2, t2, H, W, out, res=x)
+            self._conv1(blk.nin_shortcut, x[:HW], sc)
+            r = sc
+        out = self._act(dev, "x" + tag, HW, blk.out_channels)
+        self._conv3(blk.conv2, t2, H, W, out[:HW], res=r)
         return out
 
-    def _attn(self, blk: AttnBlock, x, tag):
-        dev, (L, Cc) = x.device, x.shape
+    def _attn(self, blk: AttnBlock, xz, tag):
+        """xz: `_act` map [L+1, C]; returns an `_act` map."""
+        dev, L, Cc = xz.device, xz.shape[0] - 1, xz.shape[1]
+        x = xz[:L]
         t = self._scratch(dev, "t0", (L, Cc))
         self._norm(blk.norm, x, t, False)
         Lk, Lp = _pad_to(L, 8), _pad_to(L, 64)               # N of the S GEMM / K of the P.V GEMM; pads stay zero
@@ -186,8 +202,8 @@ class _HipExec(nn.Module):
         hip.transpose(v, vt[:, :L])
         o = self._scratch(dev, "ao", (L, Cc))
         hip.gemm(hip.make_problem(s, vt, None, o), epi=hip.EPI_BIAS)                        # O = P V
-        out = self._scratch(dev, "x" + tag, (L, Cc))
-        self._conv1(blk.proj_out, o, out, res=x)
+        out = self._act(dev, "x" + tag, L, Cc)
+        self._conv1(blk.proj_out, o, out[:L], res=x)
         return out
 
 
@@ -225,15 +241,22 @@ class Encoder(_HipExec):             # autoencoder.py:109-180
 
     def _moments_one(self, img):
         """img [in_channels, H, W] -> (moments NHWC [h*w, pad8(2z)], h, w)   (Encoder.forward, :159-180)"""
-        dev = img.device
         _, H, W = img.shape
         f = 2 ** (self.num_resolutions - 1)
         if H % f or W % f:
             raise ValueError(f"Encoder: image size {H}x{W} must be a multiple of {f}")
-        x0 = self._scratch(dev, "zin", (H * W, _pad_to(self.in_channels, 64)))
-        hip.nchw_to_nhwc(img, x0, 1.0, 0.0)
-        cur = self._scratch(dev, "xa", (H * W, self.conv_in.cout))
-        self._conv3(self.conv_in, x0, H, W, cur)
+        h, w = H // f, W // f
+        mom = self._scratch(img.device, "yout", (h * w, _pad_to(2 * self.z_channels, 8)))
+        self._moments_into(img, mom)
+        return mom, h, w
+
+    def _moments_into(self, img, mom):
+        dev = img.device
+        _, H, W = img.shape
+        x0 = self._act(dev, "zin", H * W, _pad_to(self.in_channels, 64))
+        hip.nchw_to_nhwc(img, x0[:H * W], 1.0, 0.0)
+        cur = self._act(dev, "xa", H * W, self.conv_in.cout)
+        self._conv3(self.conv_in, x0, H, W, cur[:H * W])
         flip = ["b", "a"]
         k = 0
         for i_level in range(self.num_resolutions):
@@ -241,17 +264,15 @@ class Encoder(_HipExec):             # autoencoder.py:109-180
                 cur = self._resnet(blk, cur, H, W, flip[k & 1]); k += 1
             if i_level != self.num_resolutions - 1:
                 H, W = H // 2, W // 2
-                nxt = self._scratch(dev, "x" + flip[k & 1], (H * W, cur.shape[1])); k += 1
-                self._conv3(self.down[i_level].downsample.conv, cur, H, W, nxt, down=True)
+                nxt = self._act(dev, "x" + flip[k & 1], H * W, cur.shape[1]); k += 1
+                self._conv3(self.down[i_level].downsample.conv, cur, H, W, nxt[:H * W], down=True)
                 cur = nxt
         cur = self._resnet(self.mid.block_1, cur, H, W, flip[k & 1]); k += 1
         cur = self._attn(self.mid.attn_1, cur, flip[k & 1]); k += 1
         cur = self._resnet(self.mid.block_2, cur, H, W, flip[k & 1]); k += 1
-        t = self._scratch(dev, "t0", (H * W, cur.shape[1]))
-        self._norm(self.norm_out, cur, t, True)
-        mom = self._scratch(dev, "yout", (H * W, _pad_to(2 * self.z_channels, 8)))
+        t = self._act(dev, "t0", H * W, cur.shape[1])
+        self._norm(self.norm_out, cur[:H * W], t[:H * W], True)
         self._conv3(self.conv_out, t, H, W, mom)
-        return mom, H, W
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x [B, in_channels, H, W] -> moments [B, 2*z_channels, H/8, W/8] bf16 (the reference's Encoder.forward)."""
@@ -309,13 +330,20 @@ class Decoder(_HipExec):             # autoencoder.py:183-259
         return torch.stack(outs)
 
     def _decode_one(self, z, div, add):
+        _, h, w = z.shape
+        f = self.ffactor
+        img = torch.empty(self.out_ch, f * h, f * w, dtype=torch.bfloat16, device=z.device)
+        self._decode_into(z, div, add, img)
+        return img
+
+    def _decode_into(self, z, div, add, img):
         dev = z.device
         _, h, w = z.shape
         H, W = h, w
-        x0 = self._scratch(dev, "zin", (H * W, _pad_to(self.z_channels, 64)))
-        hip.nchw_to_nhwc(z, x0, div, add)
-        cur = self._scratch(dev, "xa", (H * W, self.conv_in.cout))
-        self._conv3(self.conv_in, x0, H, W, cur)
+        x0 = self._act(dev, "zin", H * W, _pad_to(self.z_channels, 64))
+        hip.nchw_to_nhwc(z, x0[:H * W], div, add)
+        cur = self._act(dev, "xa", H * W, self.conv_in.cout)
+        self._conv3(self.conv_in, x0, H, W, cur[:H * W])
         flip = ["b", "a"]
         k = 0
         cur = self._resnet(self.mid.block_1, cur, H, W, flip[k & 1]); k += 1
@@ -326,16 +354,14 @@ class Decoder(_HipExec):             # autoencoder.py:183-259
                 cur = self._resnet(blk, cur, H, W, flip[k & 1]); k += 1
             if i_level != 0:
                 H, W = 2 * H, 2 * W
-                nxt = self._scratch(dev, "x" + flip[k & 1], (H * W, cur.shape[1])); k += 1
-                self._conv3(self.up[i_level].upsample.conv, cur, H, W, nxt, up=True)
+                nxt = self._act(dev, "x" + flip[k & 1], H * W, cur.shape[1]); k += 1
+                self._conv3(self.up[i_level].upsample.conv, cur, H, W, nxt[:H * W], up=True)
                 cur = nxt
-        t = self._scratch(dev, "t0", (H * W, cur.shape[1]))
-        self._norm(self.norm_out, cur, t, True)
+        t = self._act(dev, "t0", H * W, cur.shape[1])
+        self._norm(self.norm_out, cur[:H * W], t[:H * W], True)
         y = self._scratch(dev, "yout", (H * W, _pad_to(self.out_ch, 8)))
         self._conv3(self.conv_out, t, H, W, y)
-        img = torch.empty(self.out_ch, H, W, dtype=torch.bfloat16, device=dev)
         hip.nhwc_to_nchw(y, img)
-        return img
 
 
 class AutoEncoder(nn.Module):

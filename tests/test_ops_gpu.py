@@ -31,7 +31,7 @@ def hip():
     return h
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 19, 20, 21, 36])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 19, 20, 21, 34, 36])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
 @pytest.mark.parametrize("shape", [(128, 128, 64), (200, 192, 128), (37, 64, 256), (513, 264, 384), (1, 512, 256)])
 def test_gemm(hip, cfg, epi, shape):

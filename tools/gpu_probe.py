@@ -209,7 +209,7 @@ def probe_graph():
 def main():
     print("device:", torch.cuda.get_device_name(0), "lib:", hip.LIB_PATH)
     hip.require_gpu()
-    for cfg in (1, 2, 3, 4, 5, 19, 20, 21, 36):
+    for cfg in (1, 2, 3, 4, 5, 19, 20, 21, 34, 36):
         for epi in (0, 1, 2, 3):
             probe_gemm(128, 128, 64, epi, cfg)
         probe_gemm(200, 192, 128, 0, cfg)

@@ -463,9 +463,11 @@ hipError_t launch_cfg(const VcGemmArgs& a, int total_tiles, hipStream_t s) {
   return hipGetLastError();
 }
 
-// 3x3 convolution over an NHWC map as ONE GEMM launch: the loader waves gather the im2col rows on the fly
+// 3x3 convolution over an NHWC map as ONE GEMM launch: the loader waves gather the im2col rows on the fly.
+// BN = 128 for O <= 128 (the 128-channel levels of the VAE and its 3-channel conv_out), else 192.
+template <int BN>
 hipError_t launch_conv(const VcGemmArgs& a, int total_tiles, hipStream_t s) {
-  constexpr int BM = 256, BN = 192, NT = 12 * 64;
+  constexpr int BM = 256, NT = 12 * 64;
   constexpr int LDS_STAGES = (2 * BM + 3 * BN) * BK * 2 + BN * 2, LDS_EPI = BM * (BN * 2 + 16);
   constexpr int LDS = LDS_STAGES > LDS_EPI ? LDS_STAGES : LDS_EPI;
   void (*fn)(const VcGemmArgs) = a.epi == VC_EPI_GATE_RES ? gemm_bf16_kernel<BM, BN, 4, 2, VC_EPI_GATE_RES, 2, true>
@@ -503,13 +505,15 @@ int vc_conv3x3_launch(const void* x, const void* w, const void* bias, void* out,
   p.a_bstride = (int64_t)H | ((int64_t)mode << 32);
   p.ldw = 9 * (int64_t)C; p.ldc = ldc; p.ldres = ldres;
   p.M = H * W; p.N = O; p.K = 9 * C; p.rows_per_batch = p.M;
-  p.tiles_m = (p.M + 255) / 256; p.tiles_n = (p.N + 191) / 192; p.tile_start = 0;
-  hipError_t e = launch_conv(a, p.tiles_m * p.tiles_n, s);
+  const int bn = O <= 128 ? 128 : 192;
+  p.tiles_m = (p.M + 255) / 256; p.tiles_n = (p.N + bn - 1) / bn; p.tile_start = 0;
+  hipError_t e = bn == 128 ? launch_conv<128>(a, p.tiles_m * p.tiles_n, s) : launch_conv<192>(a, p.tiles_m * p.tiles_n, s);
   if (e != hipSuccess) { snprintf(err, errlen, "conv3x3 launch: %s", hipGetErrorString(e)); return VC_ERR_HIP; }
   return VC_OK;
 }
 
-// tile_cfg: 0 = auto, 1 = 128x128 (4 waves), 2 = 256x128, 3 = 256x256, 4 = 256x192, 5 = 256x288 (8 waves each)
+// tile_cfg: 0 = auto, 1 = 128x128 (4 waves), 2 = 256x128, 3 = 256x256, 4 = 256x192, 5 = 256x288 (8 waves each);
+// +16 = ping-pong main loop (3, 4, 5), +32 = ping-pong with loader waves (2, 4)
 int vc_gemm_launch(VcGemmArgs a, int tile_cfg, hipStream_t s, char* err, int errlen) {
   if (a.nprob < 1 || a.nprob > VC_GEMM_MAX_PROBLEMS) { snprintf(err, errlen, "gemm: nprob must be 1..%d", VC_GEMM_MAX_PROBLEMS); return VC_ERR_ARG; }
   for (int i = 0; i < a.nprob; ++i) {
@@ -551,7 +555,7 @@ int vc_gemm_launch(VcGemmArgs a, int tile_cfg, hipStream_t s, char* err, int err
       if (t < best) { best = t; tile_cfg = c; pp = cand_pp[ci]; }
     }
   }
-  if (tile_cfg < 1 || tile_cfg > 5 || pp > 2 || (pp && tile_cfg < 3) || (pp == 2 && tile_cfg != 4)) { snprintf(err, errlen, "gemm: bad tile_cfg %d", tile_cfg); return VC_ERR_ARG; }
+  if (tile_cfg < 1 || tile_cfg > 5 || pp > 2 || (pp == 1 && tile_cfg < 3) || (pp == 2 && tile_cfg != 4 && tile_cfg != 2)) { snprintf(err, errlen, "gemm: bad tile_cfg %d", tile_cfg); return VC_ERR_ARG; }
   const int bm = cfg_bm[tile_cfg], bn = cfg_bn[tile_cfg];
   int total = 0;
   for (int i = 0; i < a.nprob; ++i) {
@@ -563,7 +567,7 @@ int vc_gemm_launch(VcGemmArgs a, int tile_cfg, hipStream_t s, char* err, int err
   hipError_t e;
   switch (tile_cfg) {
     case 1: e = launch_cfg<128, 128, 2, 2, 0>(a, total, s); break;
-    case 2: e = launch_cfg<256, 128, 4, 2, 0>(a, total, s); break;
+    case 2: e = pp == 2 ? launch_cfg<256, 128, 4, 2, 2>(a, total, s) : launch_cfg<256, 128, 4, 2, 0>(a, total, s); break;
     case 3: e = pp ? launch_cfg<256, 256, 2, 4, 1>(a, total, s) : launch_cfg<256, 256, 2, 4, 0>(a, total, s); break;
     case 4: e = pp == 2 ? launch_cfg<256, 192, 4, 2, 2>(a, total, s) : pp ? launch_cfg<256, 192, 4, 2, 1>(a, total, s) : launch_cfg<256, 192, 4, 2, 0>(a, total, s); break;
     default: e = pp ? launch_cfg<256, 288, 4, 2, 1>(a, total, s) : launch_cfg<256, 288, 4, 2, 0>(a, total, s); break;

@@ -537,14 +537,15 @@ int vc_gemm_launch(VcGemmArgs a, int tile_cfg, hipStream_t s, char* err, int err
   if (tile_cfg == 0) {
     // Cost model fitted on MI355X (M=3968 FLUX shapes): time = block-rounds on 256 CUs x (tile area x (K + fixed
     // prologue/epilogue charge) / streaming efficiency of that tile).  Candidates: 128x128 simple loop (2 blocks per
-    // CU; small or skinny problems) and 256x192 with loader waves (1 block per CU), which beat the 256x256 / 256x192
-    // ping-pong and the 256x288 tiles on every FLUX shape in an interleaved A/B (tools/gemm_ab.py); those stay
-    // selectable by number.  For M <= 4096, 256x192 gives N=3072 / 9216 / 12288 exactly 1 / 3 / 4 rounds.
-    static const int cand[2] = {1, 4};
-    static const int cand_pp[2] = {0, 2};
-    static const double eff[2] = {0.55, 0.94}, ovh[2] = {500.0, 350.0};
+    // CU; small or skinny problems), 256x192 with loader waves (1 block per CU), which beat the 256x256 / 256x192
+    // ping-pong and the 256x288 tiles on every FLUX shape in an interleaved A/B (tools/gemm_ab.py; those stay
+    // selectable by number), and its 256x128 sibling.  For M <= 4096, 256x192 gives N=3072 / 9216 / 12288 exactly
+    // 1 / 3 / 4 rounds.
+    static const int cand[3] = {1, 4, 2};
+    static const int cand_pp[3] = {0, 2, 2};        // 256x128 with loaders: more blocks when M is short (L = 1664: 168 vs 112)
+    static const double eff[3] = {0.55, 0.94, 0.84}, ovh[3] = {500.0, 350.0, 350.0};
     double best = 1e300;
-    for (int ci = 0; ci < 2; ++ci) {
+    for (int ci = 0; ci < 3; ++ci) {
       const int c = cand[ci];
       long tiles = 0;
       for (int i = 0; i < a.nprob; ++i)

@@ -259,6 +259,9 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
       bar();
     } else {
       const int grp = wave >> 2;
+      // static priority for the younger half (waves 4-7 lose every age-based arbitration otherwise) and no per-segment
+      // s_setprio flips: +0.5...2.5 % over setprio(1) around each MFMA block (tools/gemm_ab.py)
+      if (grp == 1) __builtin_amdgcn_s_setprio(1);
       bar();
       VC_PHASE_STAMP(1);
       if (grp == 1) bar();
@@ -275,7 +278,6 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
           for (int j = 0; j < NI; ++j) bfr[j] = *(const bf16x8*)(base_b + ((b_rd + j * 16 * 128) ^ (kk * 64)));
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           bar();
-          __builtin_amdgcn_s_setprio(1);
 #ifdef VC_GEMM_NO_MFMA
 #pragma unroll
           for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(af[i]));
@@ -288,7 +290,6 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
             for (int j = 0; j < NI; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
 #endif
-          __builtin_amdgcn_s_setprio(0);
           bar();
         }
         ws = ws == WD ? 0 : ws + 1;

@@ -141,9 +141,7 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
       if (B_CH % NS == 0 || i * NS + swave * 64 < B_CH) glds16(Wb + b_off[i] + k0, sb + (i * NS + swave * 64) * 16);
   };
   // PP == 2 (loader waves): A lives in a 2-deep ring, W in a 3-deep ring (2*A_BYTES + 3*B_BYTES = 136 KB for 256x192),
-  // followed by the tile's bias slice
   constexpr int W_RING0 = 2 * A_BYTES;
-  constexpr int LW_BIAS_OFF = 2 * A_BYTES + 3 * B_BYTES;
   auto stage_a_piece = [&](int slot, int k0, int i) {
     if constexpr (CONV) glds16(conv_src(i), smem + slot * A_BYTES + (i * NS + swave * 64) * 16);   // (conv_set_k(k0) done by the caller)
     else glds16(Ab + a_off[i] + k0, smem + slot * A_BYTES + (i * NS + swave * 64) * 16);
@@ -206,14 +204,6 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
     constexpr int P0 = (NPIECE + 2) / 3, P1 = (NPIECE - P0 + 1) / 2;   // pieces issued in intervals 4t / 4t+1 (rest: 4t+2)
     constexpr int WD = 2;                               // W is issued WD tiles ahead into a ring of WD+1 slots
     if (wave >= NCW) {
-      // the tile's bias slice goes to LDS now (zeros where there is none): epilogue pass 1 then needs no global load
-      // between the last MFMA and its first LDS write (24 dependent 8-B loads cost ~3 us per block there)
-      if (stid < BN / 4) {
-        const int col = stid * 4;
-        u32x2 bb = {0u, 0u};
-        if (P.bias && n0 + col < N) bb = *(const u32x2*)((const bf16_t*)P.bias + n0 + col);
-        *(u32x2*)(smem + LW_BIAS_OFF + col * 2) = bb;
-      }
 #pragma unroll
       for (int i = 0; i < A_IT; ++i) stage_a_piece(0, 0, i);
 #pragma unroll
@@ -262,6 +252,19 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
       // static priority for the younger half (waves 4-7 lose every age-based arbitration otherwise) and no per-segment
       // s_setprio flips: +0.5...2.5 % over setprio(1) around each MFMA block (tools/gemm_ab.py)
       if (grp == 1) __builtin_amdgcn_s_setprio(1);
+      // the accumulators start at the bias (6 8-B loads per lane, hidden under the wait for the first K-tile): epilogue
+      // pass 1 is then convert + LDS write only (it was VALU-bound on the bias unpack/add: 6.9 k cycles per block)
+      if (P.bias) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const int col = n0 + wn * TN + j * 16 + fq * 4;
+          u32x2 bb = {0u, 0u};
+          if (col < N) bb = *(const u32x2*)((const bf16_t*)P.bias + col);
+          const f32x4 b4 = {lo_bf(bb[0]), hi_bf(bb[0]), lo_bf(bb[1]), hi_bf(bb[1])};
+#pragma unroll
+          for (int i = 0; i < MI; ++i) acc[i][j] = b4;
+        }
+      }
       bar();
       VC_PHASE_STAMP(1);
       if (grp == 1) bar();
@@ -373,6 +376,40 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
   }
 
   VC_PHASE_STAMP(2);
+  int etid = tid;                       // opaque copy: keeps the epilogue's address arithmetic below the K loop
+  asm volatile("" : "+v"(etid));
+  // ---- gate/residual epilogue of the loader-wave kernel: the residual chunks (and the gate chunk: the column of a
+  // thread is the same in every pass-2 iteration) are requested NOW, so their HBM latency runs under pass 1 instead of
+  // twice inside pass 2 (pass 2 was 10.6 k cycles per block against 2.7 k for the plain epilogue) ----
+  constexpr int CPR = BN / 8;  // 16-B chunks per tile row
+  constexpr int P2_IT = (BM * CPR + NT - 1) / NT;
+  constexpr bool PREF = PP == 2 && EPI == VC_EPI_GATE_RES && NT % CPR == 0;
+  u32x4 rr_pre[PREF ? P2_IT : 1], gg_pre = {0u, 0u, 0u, 0u};
+  int gg_batch = -1;
+  long gate_step = 0;
+  if (EPI == VC_EPI_GATE_RES && args.step_ptr) gate_step = (long)(*args.step_ptr) * args.gate_step_stride;
+  // batch index of a tile row for the gate: rows_per_batch >= BM means at most one batch edge inside the tile
+  int gb_lo = 0, gb_edge = 0x7fffffff;
+  if (EPI == VC_EPI_GATE_RES) { gb_lo = m0 / P.rows_per_batch; gb_edge = (gb_lo + 1) * P.rows_per_batch; }
+  auto gate_batch = [&](int m) { return P.rows_per_batch >= BM ? gb_lo + (m >= gb_edge ? 1 : 0) : m / P.rows_per_batch; };
+  if constexpr (PREF) {
+    const bf16_t* __restrict__ res = (const bf16_t*)P.res;
+    const int n = n0 + (etid % CPR) * 8;
+#pragma unroll
+    for (int it = 0; it < P2_IT; ++it) {
+      const int m = m0 + (etid + it * NT) / CPR;
+      rr_pre[it] = u32x4{0u, 0u, 0u, 0u};
+      if (m < M && n < N && (etid + it * NT) < BM * CPR) {
+        const long rrow = P.c_rpb > 0 ? (long)(m / P.c_rpb) * P.c_bstride + (long)(m % P.c_rpb) * P.ldc : (long)m * P.ldres;
+        rr_pre[it] = *(const u32x4*)(res + rrow + n);
+      }
+    }
+    const int mf = m0 + etid / CPR;
+    if (mf < M && n < N) {
+      gg_batch = gate_batch(mf);
+      gg_pre = *(const u32x4*)((const bf16_t*)P.gate + gate_step + (long)gg_batch * P.gate_bstride + n);
+    }
+  }
   // ---- epilogue, pass 1: lane holds C[m = ..+fr][n = ..+fq*4 .. +3]; t = bf16(acc + bias) -> LDS tile ----
   // (the K loop ended on a barrier, so the staging buffers are free).  Rows are padded by 16 B: the 16 rows a
   // ds_write_b64 lane group touches then land on distinct bank pairs (2-way at worst).
@@ -387,8 +424,7 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
       const int col = wn * TN + j * 16 + fq * 4;
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
       if (PP == 2) {
-        const u32x2 bb = *(const u32x2*)(smem + LW_BIAS_OFF + col * 2);
-        v[0] += lo_bf(bb[0]); v[1] += hi_bf(bb[0]); v[2] += lo_bf(bb[1]); v[3] += hi_bf(bb[1]);
+        // bias already in the accumulators
       } else if (bias && n0 + col < N) {
         const u32x2 bb = *(const u32x2*)(bias + n0 + col);
         v[0] += lo_bf(bb[0]); v[1] += hi_bf(bb[0]); v[2] += lo_bf(bb[1]); v[3] += hi_bf(bb[1]);
@@ -399,18 +435,23 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
       *(u32x2*)(smem + row * EP_LD + col * 2) = o;
     }
   }
-  __syncthreads();
+  if constexpr (PREF) {   // LDS writes done; the residual prefetch stays in flight (__syncthreads would wait for it: vmcnt(0))
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  } else {
+    __syncthreads();
+  }
   VC_PHASE_STAMP(3);
 
   // ---- pass 2: row-major, 16 B per lane, whole rows per wave-instruction -> coalesced HBM traffic ----
   bf16_t* __restrict__ C = (bf16_t*)P.C;
   const bf16_t* __restrict__ res = (const bf16_t*)P.res;
   const bf16_t* __restrict__ gate = (const bf16_t*)P.gate;
-  long gate_step = 0;
-  if (EPI == VC_EPI_GATE_RES && args.step_ptr) gate_step = (long)(*args.step_ptr) * args.gate_step_stride;
-  constexpr int CPR = BN / 8;  // 16-B chunks per tile row
-#pragma unroll 4
-  for (int c = tid; c < BM * CPR; c += NT) {
+#pragma unroll PREF ? P2_IT : 4
+  for (int it = 0; it < (PREF ? P2_IT : BM * CPR); ++it) {
+    const int c = etid + it * NT;
+    if ((!PREF || BM * CPR % NT != 0) && c >= BM * CPR) break;
     const int row = c / CPR, cc = c % CPR;
     const int m = m0 + row, n = n0 + cc * 8;
     if (m >= M || n >= N) continue;
@@ -430,11 +471,23 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = pack2bf(silu_f(v[2 * e]), silu_f(v[2 * e + 1]));
     } else if (EPI == VC_EPI_GATE_RES) {
-      const u32x4 gg = *(const u32x4*)(gate + gate_step + (long)(m / P.rows_per_batch) * P.gate_bstride + n);
-      const u32x4 rr = *(const u32x4*)(res + (P.c_rpb > 0 ? crow : (long)m * P.ldres) + n);
+      u32x4 gg, rr;
+      if constexpr (PREF) {
+        const int bt = gate_batch(m);
+        gg = gg_pre;
+        if (bt != gg_batch) gg = *(const u32x4*)(gate + gate_step + (long)bt * P.gate_bstride + n);   // tile spans a batch edge
+        rr = rr_pre[it];
+      } else {
+        gg = *(const u32x4*)(gate + gate_step + (long)gate_batch(m) * P.gate_bstride + n);
+        rr = *(const u32x4*)(res + (P.c_rpb > 0 ? crow : (long)m * P.ldres) + n);
+      }
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        o[e] = pack2bf(lo_bf(rr[e]) + rbf(lo_bf(gg[e]) * v[2 * e]), hi_bf(rr[e]) + rbf(hi_bf(gg[e]) * v[2 * e + 1]));
+      for (int e = 0; e < 4; ++e) {   // out = res + bf16(gate * t), two elements per VALU op
+        const f32x2 gv = f32x2{lo_bf(gg[e]), hi_bf(gg[e])} * f32x2{v[2 * e], v[2 * e + 1]};
+        const uint32_t gb = pack2bf(gv[0], gv[1]);
+        const f32x2 sum = f32x2{lo_bf(rr[e]), hi_bf(rr[e])} + f32x2{lo_bf(gb), hi_bf(gb)};
+        o[e] = pack2bf(sum[0], sum[1]);
+      }
     }
     *(u32x4*)(C + crow + n) = o;
   }
@@ -444,7 +497,7 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
 template <int BM, int BN, int WM, int WN, int PP>
 hipError_t launch_cfg(const VcGemmArgs& a, int total_tiles, hipStream_t s) {
   constexpr int NT = (WM * WN + (PP == 2 ? 4 : 0)) * 64;
-  constexpr int LDS_STAGES = (PP == 2 ? 2 * BM + 3 * BN : 2 * (BM + BN)) * BK * 2 + (PP == 2 ? BN * 2 : 0), LDS_EPI = BM * (BN * 2 + 16);
+  constexpr int LDS_STAGES = (PP == 2 ? 2 * BM + 3 * BN : 2 * (BM + BN)) * BK * 2, LDS_EPI = BM * (BN * 2 + 16);
   constexpr int LDS = LDS_STAGES > LDS_EPI ? LDS_STAGES : LDS_EPI;
   void (*fn)(const VcGemmArgs) = nullptr;
   switch (a.epi) {
@@ -469,7 +522,7 @@ hipError_t launch_cfg(const VcGemmArgs& a, int total_tiles, hipStream_t s) {
 template <int BN>
 hipError_t launch_conv(const VcGemmArgs& a, int total_tiles, hipStream_t s) {
   constexpr int BM = 256, NT = 12 * 64;
-  constexpr int LDS_STAGES = (2 * BM + 3 * BN) * BK * 2 + BN * 2, LDS_EPI = BM * (BN * 2 + 16);
+  constexpr int LDS_STAGES = (2 * BM + 3 * BN) * BK * 2, LDS_EPI = BM * (BN * 2 + 16);
   constexpr int LDS = LDS_STAGES > LDS_EPI ? LDS_STAGES : LDS_EPI;
   void (*fn)(const VcGemmArgs) = a.epi == VC_EPI_GATE_RES ? gemm_bf16_kernel<BM, BN, 4, 2, VC_EPI_GATE_RES, 2, true>
                                                           : gemm_bf16_kernel<BM, BN, 4, 2, VC_EPI_BIAS, 2, true>;

@@ -139,14 +139,14 @@ def flops_per_eval(T, N, D=3072, H=24, mlp=12288, depth=19, single=38, in_ch=384
 
 def pmc_traffic(kernel):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01g_pmc_summary.json: FETCH_SIZE and WRITE_SIZE in separate --pmc runs, KiB units; FETCH_SIZE x2 on
+    (profiles/r01h_pmc_summary.json: FETCH_SIZE and WRITE_SIZE in separate --pmc runs, KiB units; FETCH_SIZE x2 on
     gfx950 for wide coalesced reads, MI355X_MICROARCH.md §HBM).  PMC cannot be sampled from inside bench.py itself."""
-    path = os.path.join(REPO, "profiles", "r01g_pmc_summary.json")
+    path = os.path.join(REPO, "profiles", "r01h_pmc_summary.json")
     try:
         k = json.load(open(path))[kernel]
         fetch, write = 2.0 * k["FETCH_SIZE"] * 1024.0, k["WRITE_SIZE"] * 1024.0
         return dict(fetch_bytes=round(fetch), write_bytes=round(write), total_bytes=round(fetch + write),
-                    unit="bytes/launch", source="profiles/r01g_pmc_summary.json (rocprofv3 --pmc, FETCH_SIZE x2 gfx950 correction)")
+                    unit="bytes/launch", source="profiles/r01h_pmc_summary.json (rocprofv3 --pmc, FETCH_SIZE x2 gfx950 correction)")
     except Exception:
         return None
 

@@ -74,6 +74,17 @@ int vc_ln_modulate(const void* x, int64_t ldx, void* y, int64_t ldy, const void*
                    int64_t mod_bstride, int32_t rows, int32_t D, int32_t rows_per_batch,
                    const int32_t* step_ptr, int64_t mod_step_stride, void* stream);
 
+/* The same op over two row sets in ONE launch - the img and txt streams of a DoubleStreamBlock, which normalise
+ * different tensors with different modulation rows (layers.py:163-164 / 175-176 and 191 / 195).  b may be NULL. */
+typedef struct VcLnStream {
+  const void* x; int64_t ldx;        /* [rows, D] bf16, row stride ldx */
+  void* y; int64_t ldy;
+  const void* shift; const void* scale;
+  int32_t rows; int32_t rows_per_batch;
+} VcLnStream;
+int vc_ln_modulate2(const VcLnStream* a, const VcLnStream* b, int64_t mod_bstride, int32_t D, const int32_t* step_ptr,
+                    int64_t mod_step_stride, void* stream);
+
 /* QK-RMSNorm (layers.py:63-84) + RoPE (math.py:112-117) in place on q,k, and V transposed to
  * vt[b][h][d][Lpad] for the attention kernel.  qkv: token rows of stride ld (elements) holding
  * q | k | v at column offsets 0, H*128, 2*H*128 ("B L (K H D)", layers.py:166).

@@ -132,6 +132,26 @@ def test_ln_modulate(hip, rows, D):
     check(out, R.ln_modulate_ref(x, sh, sc))
 
 
+@pytest.mark.parametrize("rows_a,rows_b,D", [(10, 7, 256), (864, 128, 3072), (5, 1, 4096), (3, 0, 64)])
+def test_ln_modulate_two_streams_one_launch(hip, rows_a, rows_b, D):
+    """img + txt rows of a DoubleStreamBlock in one launch: bit-identical to two single launches; row counts that do
+    not fill a 4-row block straddle the stream boundary inside one workgroup."""
+    xa, xb = rnd(rows_a, D, scale=2.0, seed=1) + 0.5, rnd(max(rows_b, 1), D, scale=1.5, seed=4) - 0.25
+    sha, sca, shb, scb = rnd(2, D, seed=2), rnd(2, D, scale=0.3, seed=3), rnd(D, seed=5), rnd(D, scale=0.3, seed=6)
+    oa, ob = torch.full_like(xa, 7.0), torch.full_like(xb, 7.0)
+    rpb_a = (rows_a + 1) // 2                  # two "samples" in the first stream: batch b reads modulation row b
+    sets = [(xa, sha, sca, oa, rpb_a)] + ([(xb[:rows_b], shb, scb, ob[:rows_b], rows_b)] if rows_b else [])
+    hip.ln_modulate2(sets, mod_bstride=D)
+    torch.cuda.synchronize()
+    ra = hip.ln_modulate(xa, sha, sca, rows_per_batch=rpb_a, mod_bstride=D)
+    assert torch.equal(oa, ra)
+    check(oa[:rpb_a], R.ln_modulate_ref(xa[:rpb_a], sha[0], sca[0]))
+    check(oa[rpb_a:], R.ln_modulate_ref(xa[rpb_a:], sha[1], sca[1]))
+    if rows_b:
+        assert torch.equal(ob[:rows_b], hip.ln_modulate(xb[:rows_b], shb, scb))
+    assert (ob[rows_b:] == 7.0).all()          # nothing written past the second stream
+
+
 def rope_table(L):
     pos = torch.arange(L, dtype=torch.float64)[:, None] * torch.linspace(0.01, 1.0, 64, dtype=torch.float64)[None]
     return torch.stack([torch.cos(pos), torch.sin(pos)], -1).float().to(DEV).contiguous()

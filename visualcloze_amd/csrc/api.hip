@@ -42,6 +42,10 @@ int vc_ln_modulate(const void* x, int64_t ldx, void* y, int64_t ldy, const void*
   return vc_ln_modulate_launch(x, ldx, y, ldy, shift, scale, mod_bstride, rows, D, rows_per_batch, step_ptr,
                                mod_step_stride, S(stream), ERRBUF);
 }
+int vc_ln_modulate2(const VcLnStream* a, const VcLnStream* b, int64_t mod_bstride, int32_t D, const int32_t* step_ptr,
+                    int64_t mod_step_stride, void* stream) {
+  return vc_ln_modulate2_launch(a, b, mod_bstride, D, step_ptr, mod_step_stride, S(stream), ERRBUF);
+}
 int vc_qknorm_rope_vt(void* qkv, int64_t ld, int64_t bstride, const void* q_scale, const void* k_scale,
                       const void* q_scale2, const void* k_scale2, int32_t split, const float* rope,
                       int64_t rope_bstride, void* vt, int32_t B, int32_t L, int32_t Lpad, int32_t H, void* stream) {

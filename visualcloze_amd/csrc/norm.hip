@@ -11,15 +11,26 @@
 
 namespace {
 
+// One launch covers up to two row sets (the img and txt streams of a DoubleStreamBlock: different x / y / modulation
+// rows, same D): rows [0, rows) belong to the first set, [rows, rows + B.rows) to the second.
+struct LnStream2 {
+  const bf16_t* x; long ldx; bf16_t* y; long ldy; const bf16_t* shift; const bf16_t* scale; int rows; int rows_per_batch;
+};
+
 template <int NCH>
 __global__ __launch_bounds__(256) void ln_modulate_kernel(const bf16_t* __restrict__ x, long ldx, bf16_t* __restrict__ y,
                                                           long ldy, const bf16_t* __restrict__ shift,
                                                           const bf16_t* __restrict__ scale, long mod_bstride, int rows,
                                                           int D, int rows_per_batch, const int* __restrict__ step_ptr,
-                                                          long mod_step_stride) {
+                                                          long mod_step_stride, const LnStream2 second) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);   // wave-uniform
+  if (row >= rows) {
+    row -= rows;
+    if (row >= second.rows) return;
+    x = second.x; ldx = second.ldx; y = second.y; ldy = second.ldy; shift = second.shift; scale = second.scale;
+    rows_per_batch = second.rows_per_batch;
+  }
   long moff = (long)(row / rows_per_batch) * mod_bstride;
   if (step_ptr) moff += (long)(*step_ptr) * mod_step_stride;
   const bf16_t* xr = x + (long)row * ldx;
@@ -160,25 +171,40 @@ __global__ __launch_bounds__(256) void qknorm_rope_vt_kernel(bf16_t* __restrict_
 
 }  // namespace
 
-int vc_ln_modulate_launch(const void* x, int64_t ldx, void* y, int64_t ldy, const void* shift, const void* scale,
-                          int64_t mod_bstride, int32_t rows, int32_t D, int32_t rows_per_batch,
-                          const int32_t* step_ptr, int64_t mod_step_stride, hipStream_t s, char* err, int errlen) {
-  if (!x || !y || !shift || !scale) { snprintf(err, errlen, "ln_modulate: null pointer"); return VC_ERR_ARG; }
-  if (rows <= 0 || D <= 0 || rows_per_batch <= 0) { snprintf(err, errlen, "ln_modulate: empty input rows=%d D=%d", rows, D); return VC_ERR_ARG; }
-  if (D % 8 || D > 4096 || ldx % 8 || ldy % 8 || mod_bstride % 8 || mod_step_stride % 8) {
-    snprintf(err, errlen, "ln_modulate: D=%d must be a multiple of 8 and <= 4096 with 16-B aligned strides", D); return VC_ERR_ARG; }
-  const dim3 grid((rows + 3) / 4), block(256);
+int vc_ln_modulate2_launch(const VcLnStream* a, const VcLnStream* b, int64_t mod_bstride, int32_t D, const int32_t* step_ptr,
+                           int64_t mod_step_stride, hipStream_t s, char* err, int errlen) {
+  if (!a) { snprintf(err, errlen, "ln_modulate: null stream description"); return VC_ERR_ARG; }
+  const VcLnStream* set[2] = {a, b};
+  for (int i = 0; i < 2; ++i) {
+    const VcLnStream* q = set[i];
+    if (!q) continue;
+    if (!q->x || !q->y || !q->shift || !q->scale) { snprintf(err, errlen, "ln_modulate: null pointer"); return VC_ERR_ARG; }
+    if (q->rows <= 0 || D <= 0 || q->rows_per_batch <= 0) { snprintf(err, errlen, "ln_modulate: empty input rows=%d D=%d", q->rows, D); return VC_ERR_ARG; }
+    if (D % 8 || D > 4096 || q->ldx % 8 || q->ldy % 8 || mod_bstride % 8 || mod_step_stride % 8) {
+      snprintf(err, errlen, "ln_modulate: D=%d must be a multiple of 8 and <= 4096 with 16-B aligned strides", D); return VC_ERR_ARG; }
+  }
+  LnStream2 second = {nullptr, 0, nullptr, 0, nullptr, nullptr, 0, 1};
+  if (b) second = LnStream2{(const bf16_t*)b->x, (long)b->ldx, (bf16_t*)b->y, (long)b->ldy, (const bf16_t*)b->shift,
+                            (const bf16_t*)b->scale, b->rows, b->rows_per_batch};
+  const dim3 grid((a->rows + second.rows + 3) / 4), block(256);
   if (D <= 3072)
-    hipLaunchKernelGGL(ln_modulate_kernel<6>, grid, block, 0, s, (const bf16_t*)x, (long)ldx, (bf16_t*)y, (long)ldy,
-                       (const bf16_t*)shift, (const bf16_t*)scale, (long)mod_bstride, rows, D, rows_per_batch, step_ptr,
-                       (long)mod_step_stride);
+    hipLaunchKernelGGL(ln_modulate_kernel<6>, grid, block, 0, s, (const bf16_t*)a->x, (long)a->ldx, (bf16_t*)a->y, (long)a->ldy,
+                       (const bf16_t*)a->shift, (const bf16_t*)a->scale, (long)mod_bstride, a->rows, D, a->rows_per_batch,
+                       step_ptr, (long)mod_step_stride, second);
   else
-    hipLaunchKernelGGL(ln_modulate_kernel<8>, grid, block, 0, s, (const bf16_t*)x, (long)ldx, (bf16_t*)y, (long)ldy,
-                       (const bf16_t*)shift, (const bf16_t*)scale, (long)mod_bstride, rows, D, rows_per_batch, step_ptr,
-                       (long)mod_step_stride);
+    hipLaunchKernelGGL(ln_modulate_kernel<8>, grid, block, 0, s, (const bf16_t*)a->x, (long)a->ldx, (bf16_t*)a->y, (long)a->ldy,
+                       (const bf16_t*)a->shift, (const bf16_t*)a->scale, (long)mod_bstride, a->rows, D, a->rows_per_batch,
+                       step_ptr, (long)mod_step_stride, second);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { snprintf(err, errlen, "ln_modulate launch: %s", hipGetErrorString(e)); return VC_ERR_HIP; }
   return VC_OK;
+}
+
+int vc_ln_modulate_launch(const void* x, int64_t ldx, void* y, int64_t ldy, const void* shift, const void* scale,
+                          int64_t mod_bstride, int32_t rows, int32_t D, int32_t rows_per_batch,
+                          const int32_t* step_ptr, int64_t mod_step_stride, hipStream_t s, char* err, int errlen) {
+  const VcLnStream a = {x, ldx, y, ldy, shift, scale, rows, rows_per_batch};
+  return vc_ln_modulate2_launch(&a, nullptr, mod_bstride, D, step_ptr, mod_step_stride, s, err, errlen);
 }
 
 int vc_qknorm_rope_vt_launch(void* qkv, int64_t ld, int64_t bstride, const void* q_scale, const void* k_scale,

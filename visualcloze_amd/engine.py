@@ -207,6 +207,11 @@ class FluxEngine:
             hip.ln_modulate(x, self._mod(ws, name, idx), self._mod(ws, name, idx + 1), out=out, step_ptr=step_ptr,
                             mod_step_stride=mss, stream=s, rows_per_batch=rpb, mod_bstride=nm)
 
+        def ln2(name_i, name_t, idx):    # img + txt streams in one launch
+            hip.ln_modulate2([(XI, self._mod(ws, name_i, idx), self._mod(ws, name_i, idx + 1), XH_I, N),
+                              (XT, self._mod(ws, name_t, idx), self._mod(ws, name_t, idx + 1), XH_T, T)],
+                             step_ptr=step_ptr, mod_step_stride=mss, stream=s, mod_bstride=nm)
+
         def gated(names, As, outs, gates, rpbs, a_views):
             ps = []
             for n_, a_, o_, g_, rpb, av in zip(names, As, outs, gates, rpbs, a_views):
@@ -227,7 +232,7 @@ class FluxEngine:
         for i in range(self.g.depth):
             pf = f"double_blocks.{i}"
             im, tm = pf + ".img_mod.lin", pf + ".txt_mod.lin"
-            ln(XI, im, 0, XH_I, N); ln(XT, tm, 0, XH_T, T)
+            ln2(im, tm, 0)
             self._gemm([self._prob(pf + ".img_attn.qkv", XH_I, QKV[T:], **qkv_i),
                         self._prob(pf + ".txt_attn.qkv", XH_T, QKV[:T], **qkv_t)], s=s)
             hip.qknorm_rope_vt(QKV, Wn[pf + ".txt_attn.norm.query_norm.scale"], Wn[pf + ".txt_attn.norm.key_norm.scale"],
@@ -236,7 +241,7 @@ class FluxEngine:
             hip.attention(QKV, ws.VT, ATT, L, H, kv_len=kvl, variant=self.attn_variant, stream=s, B=B)
             gated((pf + ".img_attn.proj", pf + ".txt_attn.proj"), (ATT[T:], ATT[:T]), (XI, XT),
                   (self._mod(ws, im, 2), self._mod(ws, tm, 2)), (N, T), (att_i, att_t))
-            ln(XI, im, 3, XH_I, N); ln(XT, tm, 3, XH_T, T)
+            ln2(im, tm, 3)
             self._gemm([self._prob(pf + ".img_mlp.0", XH_I, HID_I), self._prob(pf + ".txt_mlp.0", XH_T, HID_T)],
                        epi=hip.EPI_GELU, s=s)
             gated((pf + ".img_mlp.2", pf + ".txt_mlp.2"), (HID_I, HID_T), (XI, XT),

@@ -52,6 +52,7 @@ SYMBOLS = {
     "vc_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "vc_gemm": (C.c_int, [C.POINTER(GemmArgs), C.c_int, _vp]),
     "vc_ln_modulate": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp]),
+    "vc_ln_modulate2": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i64, _vp]),
     "vc_qknorm_rope_vt": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp]),
     "vc_attention": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vc_timestep_embedding": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
@@ -214,6 +215,28 @@ def ln_modulate(x, shift, scale, out=None, step_ptr=None, mod_step_stride=0, str
                                 scale.data_ptr(), mod_bstride, rows, D, rows_per_batch or rows, _p(step_ptr), mod_step_stride,
                                 stream if stream is not None else cur_stream()), "vc_ln_modulate")
     return out
+
+
+class LnStream(C.Structure):
+    """VcLnStream of include/vcloze_hip.h."""
+    _fields_ = [("x", C.c_void_p), ("ldx", C.c_int64), ("y", C.c_void_p), ("ldy", C.c_int64), ("shift", C.c_void_p),
+                ("scale", C.c_void_p), ("rows", C.c_int32), ("rows_per_batch", C.c_int32)]
+
+
+def ln_modulate2(streams, step_ptr=None, mod_step_stride=0, stream=None, mod_bstride=0) -> None:
+    """LayerNorm + modulate over one or two row sets in one launch; streams: [(x, shift, scale, out, rows_per_batch), ...]
+    (the img and txt streams of a DoubleStreamBlock)."""
+    if not 1 <= len(streams) <= 2:
+        raise VclozeHipError("ln_modulate2 takes one or two row sets")
+    segs, D = [], streams[0][0].shape[1]
+    for (x, shift, scale, out, rpb) in streams:
+        _bf16(x, "x"); _bf16(out, "out")
+        if x.shape[1] != D or out.shape != x.shape:
+            raise VclozeHipError("ln_modulate2: row sets must share D, and out must match x")
+        segs.append(LnStream(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), shift.data_ptr(), scale.data_ptr(),
+                             x.shape[0], rpb or x.shape[0]))
+    _check(lib().vc_ln_modulate2(C.byref(segs[0]), C.byref(segs[1]) if len(segs) > 1 else None, mod_bstride, D,
+                                 _p(step_ptr), mod_step_stride, stream if stream is not None else cur_stream()), "vc_ln_modulate2")
 
 
 def qknorm_rope_vt(qkv, q_scale, k_scale, rope, vt, L, H, stream=None, q_scale2=None, k_scale2=None, split=0, B=1):

@@ -66,44 +66,41 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs a) 
   const bf16_t* __restrict__ vbase = a.vt + ((long)(b * a.H + h) * 128) * a.Lpad;
 
   // ---- staging offsets ----
-  uint32_t k_row[K_IT], k_col[K_IT], v_off[V_IT];
+  // 32-bit BYTE offsets from the wave-uniform K / Vt bases (scalar base + vector offset addressing): per tile a K
+  // piece costs one add and one min (keys past L - 1 re-read row L - 1; they are masked later), a V piece one add -
+  // the 64-bit multiply / add chains these replace were a quarter of the loop's VALU time.
+  uint32_t k_off[K_IT], k_max[K_IT], v_off[V_IT];
+  const uint32_t k_step = (uint32_t)KVB * (uint32_t)a.ld * 2u;
 #pragma unroll
   for (int i = 0; i < K_IT; ++i) {
     const int c = i * NT + tid;
     const int row = c >> 4;
-    k_row[i] = row;
-    k_col[i] = (((c & 15) ^ (row & 15)) << 3);
+    const uint32_t col = (uint32_t)(((c & 15) ^ (row & 15)) << 4);
+    k_off[i] = (uint32_t)row * (uint32_t)a.ld * 2u + col;
+    k_max[i] = (uint32_t)(L - 1) * (uint32_t)a.ld * 2u + col;
   }
 #pragma unroll
   for (int i = 0; i < V_IT; ++i) {
     const int c = i * NT + tid;
     const int d = c >> 3;
-    v_off[i] = (uint32_t)d * (uint32_t)a.Lpad + ((((c & 7) ^ ((d >> 1) & 7))) << 3);
+    v_off[i] = ((uint32_t)d * (uint32_t)a.Lpad + ((((c & 7) ^ ((d >> 1) & 7))) << 3)) * 2u;
   }
+  const char* kbytes = (const char*)kbase;
+  const char* vbytes = (const char*)vbase;
   // one LDS-DMA wave-instruction of tile kt: i < K_IT -> K piece i, else V piece i - K_IT
   auto stage_piece = [&](int buf, int kt, int i) {
     char* sk = smem + buf * STAGE;
     char* sv = sk + K_TILE;
 #pragma unroll
     for (int j = 0; j < K_IT; ++j)
-      if (i == j) {
-        const int key = min(kt * KVB + (int)k_row[j], L - 1);
-        glds16(kbase + (long)key * a.ld + k_col[j], sk + (j * NT + wave * 64) * 16);
-      }
+      if (i == j) glds16(kbytes + min(k_off[j] + (uint32_t)kt * k_step, k_max[j]), sk + (j * NT + wave * 64) * 16);
 #pragma unroll
     for (int j = 0; j < V_IT; ++j)
-      if (i == K_IT + j) glds16(vbase + v_off[j] + kt * KVB, sv + (j * NT + wave * 64) * 16);
+      if (i == K_IT + j) glds16(vbytes + (v_off[j] + (uint32_t)kt * (KVB * 2)), sv + (j * NT + wave * 64) * 16);
   };
   auto stage = [&](int buf, int kt) {
-    char* sk = smem + buf * STAGE;
-    char* sv = sk + K_TILE;
 #pragma unroll
-    for (int i = 0; i < K_IT; ++i) {
-      const int key = min(kt * KVB + (int)k_row[i], L - 1);
-      glds16(kbase + (long)key * a.ld + k_col[i], sk + (i * NT + wave * 64) * 16);
-    }
-#pragma unroll
-    for (int i = 0; i < V_IT; ++i) glds16(vbase + v_off[i] + kt * KVB, sv + (i * NT + wave * 64) * 16);
+    for (int i = 0; i < K_IT + V_IT; ++i) stage_piece(buf, kt, i);
   };
 
   const int nkt = (kvlen + KVB - 1) / KVB;
@@ -293,6 +290,7 @@ int vc_attention_launch(const void* qkv, int64_t ld, int64_t bstride, const void
   if (Lpad < L || Lpad % KVB) { snprintf(err, errlen, "attention: Lpad=%d must be a multiple of %d and >= L=%d", Lpad, KVB, L); return VC_ERR_ARG; }
   if (ld % 8 || ldo % 4 || bstride % 8) { snprintf(err, errlen, "attention: strides must keep 16-B row alignment"); return VC_ERR_ARG; }
   if ((uint64_t)128 * (uint64_t)Lpad >= (1ull << 31)) { snprintf(err, errlen, "attention: Lpad too large"); return VC_ERR_ARG; }
+  if ((uint64_t)(Lpad + KVB) * (uint64_t)ld * 2ull >= (1ull << 32)) { snprintf(err, errlen, "attention: one sample's K rows exceed 32-bit byte offsets (L=%d ld=%ld)", L, (long)ld); return VC_ERR_ARG; }
   AttnArgs a;
   a.qkv = (const bf16_t*)qkv; a.vt = (const bf16_t*)vt; a.out = (bf16_t*)out; a.kv_len = kv_len;
   a.ld = ld; a.bstride = bstride; a.ldo = ldo; a.out_bstride = out_bstride;

@@ -80,21 +80,24 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
   const int stid = PP == 2 ? (tid - NCW * 64) & 255 : tid;   // staging thread / wave index (PP == 2: loader waves)
   const int swave = PP == 2 ? (wave - NCW) & 3 : wave;
   uint32_t a_off[A_IT], b_off[B_IT];
+  auto staging_offsets = [&]() {   // loader-wave kernels run this inside the loader branch only: nothing of it is live in compute waves
 #pragma unroll
-  for (int i = 0; i < A_IT; ++i) {
-    const int c = i * NS + stid;
-    const int row = c >> 3, slot = (c & 7) ^ (row & 7);
-    const int grow = min(m0 + row, M - 1);
-    a_off[i] = (P.a_rpb > 0 ? (uint32_t)(grow / P.a_rpb) * (uint32_t)P.a_bstride + (uint32_t)(grow % P.a_rpb) * (uint32_t)P.lda
-                            : (uint32_t)grow * (uint32_t)P.lda) + slot * 8;
-  }
+    for (int i = 0; i < A_IT; ++i) {
+      const int c = i * NS + stid;
+      const int row = c >> 3, slot = (c & 7) ^ (row & 7);
+      const int grow = min(m0 + row, M - 1);
+      a_off[i] = (P.a_rpb > 0 ? (uint32_t)(grow / P.a_rpb) * (uint32_t)P.a_bstride + (uint32_t)(grow % P.a_rpb) * (uint32_t)P.lda
+                              : (uint32_t)grow * (uint32_t)P.lda) + slot * 8;
+    }
 #pragma unroll
-  for (int i = 0; i < B_IT; ++i) {
-    const int c = i * NS + stid;
-    const int row = c >> 3, slot = (c & 7) ^ (row & 7);
-    const int grow = min(n0 + row, N - 1);
-    b_off[i] = (uint32_t)grow * (uint32_t)P.ldw + slot * 8;
-  }
+    for (int i = 0; i < B_IT; ++i) {
+      const int c = i * NS + stid;
+      const int row = c >> 3, slot = (c & 7) ^ (row & 7);
+      const int grow = min(n0 + row, N - 1);
+      b_off[i] = (uint32_t)grow * (uint32_t)P.ldw + slot * 8;
+    }
+  };
+  if constexpr (PP != 2) staging_offsets();
   // implicit 3x3 convolution: (y, x) of the output pixel each A piece of this thread belongs to, packed y << 16 | x
   const int cvC = (int)P.lda, cvW = P.a_rpb, cvH = (int)(P.a_bstride & 0xffffffff), cvMode = (int)(P.a_bstride >> 32);
   uint32_t cv_yx[CONV ? A_IT : 1];
@@ -204,6 +207,7 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
     constexpr int P0 = (NPIECE + 2) / 3, P1 = (NPIECE - P0 + 1) / 2;   // pieces issued in intervals 4t / 4t+1 (rest: 4t+2)
     constexpr int WD = 2;                               // W is issued WD tiles ahead into a ring of WD+1 slots
     if (wave >= NCW) {
+      staging_offsets();
 #pragma unroll
       for (int i = 0; i < A_IT; ++i) stage_a_piece(0, 0, i);
 #pragma unroll

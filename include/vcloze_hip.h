@@ -64,7 +64,9 @@ typedef struct VcGemmArgs {
 } VcGemmArgs;
 
 /* Replaces torch.nn.functional.linear (+ fused neighbours) on the hot path.
- * tile_cfg: 0 auto, 1 = 128x128, 2 = 256x128, 3 = 256x256. */
+ * tile_cfg: 0 = chosen by the launcher's cost model (what the product path passes); a fixed tile for tests and A/B runs:
+ * 1 = 128x128, 2 = 256x128, 3 = 256x256, 4 = 256x192, 5 = 256x288, +16 = ping-pong main loop (3, 4, 5),
+ * +32 = ping-pong with loader waves (2, 4). */
 int vc_gemm(const VcGemmArgs* args, int tile_cfg, void* stream);
 
 /* LayerNorm(eps=1e-6, no affine) + AdaLN modulate: y = bf16((1+scale)*LN(x) + shift).

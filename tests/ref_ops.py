@@ -1,5 +1,5 @@
 """Plain-PyTorch f32 references of the individual HIP ops (same rounding points as the kernels).
-Used by the -m gpu op tests and tools/gpu_probe.py; runs on whatever device the inputs live on."""
+Used by the -m gpu op tests and tests/tools/gpu_probe.py; runs on whatever device the inputs live on."""
 import torch
 
 

@@ -4,7 +4,7 @@ import sys
 
 import torch
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 import oracle.flux_oracle as O  # noqa: E402
 from tests.procedural import TINY, tiny_inputs  # noqa: E402

@@ -9,7 +9,7 @@ import traceback
 
 import torch
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 from tests import ref_ops as R  # noqa: E402
 from visualcloze_amd import hip  # noqa: E402

@@ -1,6 +1,6 @@
 """VAE encode / decode timing on one MI355X: FLUX AutoEncoder geometry, procedural weights, HIP events.
 
-    python tools/vae_bench.py [--cpu]      # --cpu also times the fp32 CPU oracle on a 64x64 image / 8x8 latent
+    python tools/vae_bench.py
 """
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -62,7 +62,7 @@ def timeit(fn, n=5):
 
 
 def main():
-    ap = argparse.ArgumentParser(); ap.add_argument("--cpu", action="store_true"); a = ap.parse_args()
+    argparse.ArgumentParser().parse_args()
     hip.require_gpu()
     ae = AutoEncoder(AutoEncoderParams(**FLUX_AE))
     sd = {k: procedural_ae_param(k, v.shape) for k, v in ae.state_dict().items()}
@@ -78,14 +78,6 @@ def main():
         fd, fe = conv_flops(ae, H, W, True), conv_flops(ae, H, W, False)
         rec["cases"].append({"image": f"{H}x{W}", "decode_ms": round(md, 3), "decode_tflops": round(fd / md / 1e9, 1), "decode_gflop": round(fd / 1e9, 1),
                              "encode_ms": round(me, 3), "encode_tflops": round(fe / me / 1e9, 1), "encode_gflop": round(fe / 1e9, 1)})
-    if a.cpu:
-        from oracle import vae_oracle as VO
-        zc = ptensor((1, 16, 8, 8), 3, q=5, kmax=96)
-        t0 = time.time(); VO.decode(sd, zc, FLUX_AE, "fp32"); td = time.time() - t0
-        ic = ptensor((1, 3, 64, 64), 4, q=7)
-        t0 = time.time(); VO.encode(sd, ic, FLUX_AE, None, "fp32"); te = time.time() - t0
-        rec["cpu_oracle_fp32_64x64"] = {"decode_s": round(td, 3), "encode_s": round(te, 3), "threads": torch.get_num_threads(),
-                                        "decode_tflops": round(conv_flops(ae, 64, 64, True) / td / 1e12, 3)}
     print(json.dumps(rec))
 
 

@@ -99,13 +99,13 @@ class Job:
     """Drives the engine exactly as transport._sample_fused does, but one solver step per call."""
 
     def __init__(self, model, x, kw, num_points):
-        from visualcloze_amd.transport import solver_time_grid
+        from visualcloze_amd.transport import model_times, solver_time_grid
         self.model, self.eng = model, model.engine()
         self.x, self.kw = x, kw
         N, T = x.shape[1], kw["txt"].shape[1]
         t = solver_time_grid(num_points, N, 0, 1, True, 1)
         self.S = num_points - 1
-        self.eval_t = torch.ones(self.S) * (1 - t[:-1])
+        self.eval_t = model_times(t, x)
         self.dts = (t[1:] - t[:-1]).contiguous()
         self.ws = self.eng.workspace(T, N, self.S, x.shape[0])
         self.s = self.eng.stream.cuda_stream

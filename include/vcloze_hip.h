@@ -21,9 +21,12 @@ extern "C" {
 #define VC_ERR_HIP (-2)
 #define VC_ERR_STATE (-3)
 
-#define VC_ABI_VERSION 1
+#define VC_ABI_VERSION 2
 int vc_abi_version(void);
 const char* vc_last_error(void);
+/* sizeof(VcGemmProblem), sizeof(VcGemmArgs), sizeof(VcLnStream) as this library was compiled: a binding checks them
+ * against its own mirrors at load time, so a stale .so cannot silently disagree with the caller's structs. */
+void vc_struct_sizes(int32_t out[3]);
 /* number of visible devices / name of device 0 ("" when none) — fails loudly, never falls back */
 int vc_device_count(void);
 int vc_device_info(int dev, char* name, int namelen, int* cu_count, int64_t* hbm_bytes);

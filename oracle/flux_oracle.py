@@ -342,7 +342,8 @@ def sample_euler(model_fn, x: Tensor, cond: Optional[Tensor], t: Tensor, P: Prec
     B = x.shape[0]
     evals = []
     for i in range(len(t) - 1):
-        ti = torch.ones(B) * t[i]
+        # torchdiffeq's _PerturbFunc hands the drift t.to(y.dtype): a bf16 state sees bf16(t_i) (dt stays f32-derived)
+        ti = torch.ones(B) * P.r(t[i])
         tm = torch.ones_like(ti) * (1 - ti)
         xin = torch.cat((x, cond), dim=-1) if cond is not None else x
         v = model_fn(xin, tm)

@@ -73,9 +73,11 @@ def install_shims():
         assert method == "euler"
         ys = [y0]
         for i in range(len(t) - 1):
-            dt = t[i + 1] - t[i]
+            dt = t[i + 1] - t[i]                 # 0-dim f32: `dt * f` takes f's dtype (bf16 state -> bf16 update)
             calls["t"].append(float(t[i]))
-            ys.append(ys[-1] + dt * func(t[i], ys[-1]))
+            # torchdiffeq hands the drift `t.to(y.dtype)` (_PerturbFunc.forward): with the bf16 state of
+            # visualcloze.py:399 the model sees 1 - bf16(t_i) while dt still comes from the f32 grid
+            ys.append(ys[-1] + dt * func(t[i].to(y0.dtype), ys[-1]))
         return torch.stack(ys)
 
     td.odeint, td._calls = odeint, calls
@@ -208,6 +210,24 @@ def main():
                     txt=inp["txt"].bfloat16(), txt_ids=inp["txt_ids"], txt_mask=inp["txt_mask"], y=inp["y"].bfloat16(),
                     img_ids=inp["img_ids"], img_mask=inp["img_mask"], guidance=inp["guidance"].bfloat16())
         out["flux_b1_ref_bf16"] = yb.float().numpy()
+        # the same sampler with the bf16 state / bf16 model of the pipeline (visualcloze.py:363,399): pins the
+        # timestep the model sees (1 - bf16(t_i)) and the bf16 Euler update
+        fn = sampler.sample_ode(sampling_method="euler", num_steps=5, atol=1e-6, rtol=1e-3, reverse=False,
+                                do_shift=True, time_shifting_factor=1)
+        seen = []
+        kwb = dict(txt=inp["txt"].bfloat16(), txt_ids=inp["txt_ids"], txt_mask=inp["txt_mask"], y=inp["y"].bfloat16(),
+                   img_ids=inp["img_ids"], img_mask=inp["img_mask"], cond=inp["cond"].bfloat16(),
+                   guidance=inp["guidance"].bfloat16())
+
+        def mb_fwd(x, timesteps, **k):
+            seen.append(float(timesteps[0]))
+            assert timesteps.dtype == torch.float32
+            return mb.forward(x, timesteps=timesteps, **k)
+        with torch.autocast("cpu", torch.bfloat16):
+            trajb = fn(inp["x"].bfloat16(), mb_fwd, kwb)
+        assert trajb.dtype == torch.bfloat16
+        out["traj_bf16_model_t"] = np.array(seen, dtype=np.float64)
+        out["traj_bf16_states"] = trajb.float().numpy()
 
     # ---------------- latent-grid packer: the tensor part of prepare_modified (models/sampling.py:37-118) -------------
     # models.sampling imports cv2 / models.util (imwatermark) through image_embedders: stub those two modules.

@@ -19,7 +19,7 @@ def test_abi_exports_every_declared_symbol():
     assert declared == set(hip.SYMBOLS), declared ^ set(hip.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert hip.lib().vc_abi_version() == 1
+    assert hip.lib().vc_abi_version() == hip.ABI_VERSION
 
 
 def test_struct_layout_matches_header():
@@ -101,3 +101,20 @@ def test_transport_surface():
     # first evaluation at 1 - t[0]; the reference's own shifted grid starts at 6e-8, not exactly 0 (golden vectors)
     assert abs(seen[0][0] - 1.0) < 1e-6 and seen[0][1] == 5
     assert torch.allclose(out, torch.full_like(out, -1.0), atol=1e-6)     # integral of -1 over [0,1]
+
+
+def test_model_times_follow_the_state_dtype(golden):
+    """B2: torchdiffeq hands the drift t.to(y.dtype); with a bf16 state Flux sees 1 - bf16(t_i) (pinned by the
+    reference's own bf16 run, tests/golden traj_bf16_model_t), with an f32 state the f32 grid."""
+    import numpy as np
+    from visualcloze_amd.transport import model_times, solver_time_grid
+    t = solver_time_grid(5, 24, 0, 1, True, 1)
+    got = model_times(t, torch.zeros(1, 24, 64, dtype=torch.bfloat16))
+    assert got.dtype == torch.float32 and np.array_equal(got.double().numpy(), golden["traj_bf16_model_t"])
+    assert torch.equal(model_times(t, torch.zeros(1, 24, 64)), 1 - t[:-1])
+    # foreign-callable path: same rounding
+    from visualcloze_amd.transport import Sampler, create_transport
+    fn = Sampler(create_transport()).sample_ode(sampling_method="euler", num_steps=5, do_shift=True, time_shifting_factor=1)
+    seen = []
+    fn(torch.zeros(1, 24, 2, dtype=torch.bfloat16), lambda x, timesteps, **kw: (seen.append(float(timesteps[0])), x * 0)[1], {})
+    assert np.array_equal(np.array(seen), golden["traj_bf16_model_t"])

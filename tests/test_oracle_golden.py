@@ -147,3 +147,24 @@ def test_bf16_noise_floor(golden, tiny_sd):
     yg = _fwd(tiny_sd, inp, torch.tensor([0.7]), O.Prec("bf16", "ref"))
     rb = torch.tensor(golden["flux_b1_ref_bf16"])
     assert ((yg - rb).norm() / rb.norm()).item() < 5e-2
+
+
+def test_bf16_state_sampler_model_times_and_trajectory(golden, tiny_sd):
+    """With the pipeline's bf16 state (visualcloze.py:399) torchdiffeq casts t to bf16 before the drift sees it:
+    the reference's own bf16 run records Flux timesteps 1 - bf16(t_i).  The oracle's bf16 sampler reproduces that
+    sequence exactly and tracks the reference's bf16 trajectory within bf16 noise."""
+    inp = tiny_inputs(B=1)
+    P = O.Prec("bf16", "ref")
+    seen = golden["traj_bf16_model_t"]
+    t = O.time_grid(5, inp["x"].shape[1], True, 1)
+    assert np.array_equal((1 - t[:-1].to(torch.bfloat16).float()).double().numpy(), seen)
+    assert not np.array_equal((1 - t[:-1]).double().numpy(), seen)        # the f32 grid would NOT match
+
+    def model_fn(xin, tm):
+        return O.flux_forward(tiny_sd, G, xin, inp["img_ids"], inp["txt"], inp["txt_ids"], tm, inp["y"], inp["txt_mask"],
+                              inp["img_mask"], inp["guidance"], P=P)
+    states, evals = O.sample_euler(model_fn, P.r(inp["x"]), P.r(inp["cond"]), t, P)
+    assert np.array_equal(np.array(evals, dtype=np.float64), seen)
+    ref = torch.tensor(golden["traj_bf16_states"])
+    for i in range(1, 5):
+        assert ((states[i] - ref[i]).norm() / ref[i].norm()).item() < 5e-2

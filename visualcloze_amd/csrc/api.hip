@@ -15,6 +15,9 @@ extern "C" {
 
 int vc_abi_version(void) { return VC_ABI_VERSION; }
 const char* vc_last_error(void) { return g_err; }
+void vc_struct_sizes(int32_t out[3]) {
+  out[0] = (int32_t)sizeof(VcGemmProblem); out[1] = (int32_t)sizeof(VcGemmArgs); out[2] = (int32_t)sizeof(VcLnStream);
+}
 
 int vc_device_count(void) {
   int n = 0;

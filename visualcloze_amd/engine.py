@@ -139,7 +139,7 @@ class FluxEngine:
 
     # ------------------------------------------------------------------ per-batch precompute
     def prepare_sample(self, ws: Workspace, txt, y, guidance, guidance_is_bf16: bool, img_ids, txt_ids,
-                       timesteps: torch.Tensor, kv_len: Sequence[int], s=None) -> None:
+                       timesteps: torch.Tensor, kv_len: Sequence[int], s=None, timesteps_is_bf16: bool = False) -> None:
         """Everything that does not depend on x: txt_in(txt), the vec path and all modulations for every
         (step, sample) (model.py:102-108 + layers.py:120-126 for all 57+1 modules), the RoPE tables.
         txt [B,T,ctx], y [B,vec], guidance [B] or None, img_ids [B,N,3], txt_ids [B,T,3], timesteps [S] (shared by
@@ -161,13 +161,18 @@ class FluxEngine:
         # txt_in
         self._lin("txt_in", txt.reshape(B * ws.T, -1), ws.TXT0, s=s)
         # vec path: rows s*B+b
-        hip.timestep_embedding(ws.TS, W.temb_freqs, ws.TEMB, stream=s)
+        # bf16 `timesteps` (not what the sampler passes: integrators.py:108 builds them in f32) make `1000 * t` a bf16
+        # product in layers.py:38, exactly as for the bf16 guidance below
+        hip.timestep_embedding(ws.TS, W.temb_freqs, ws.TEMB, round_t_bf16=timesteps_is_bf16, stream=s)
         self._lin("time_in.in_layer", ws.TEMB, ws.H1, epi=hip.EPI_SILU, s=s)
         self._lin("time_in.out_layer", ws.H1, ws.TVEC, s=s)
         if self.g.guidance_embed:
             if guidance is None:
                 raise ValueError("Didn't get guidance strength for guidance distilled model.")
-            g32 = guidance.reshape(B).to(self.dev, torch.float32)
+            g32 = guidance.reshape(-1)
+            if g32.numel() == 1:           # the pipeline's guidance is shape (1,) and broadcasts (visualcloze.py:413)
+                g32 = g32.expand(B)
+            g32 = g32.reshape(B).to(self.dev, torch.float32).contiguous()
             ge = torch.empty(B, 256, dtype=torch.bfloat16, device=self.dev)
             gh = torch.empty(B, D, dtype=torch.bfloat16, device=self.dev)
             hip.timestep_embedding(g32, W.temb_freqs, ge, round_t_bf16=guidance_is_bf16, stream=s)

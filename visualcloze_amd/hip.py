@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VC_HIP_LIB") or os.path.join(_HERE, "lib", "libvcloze_hip.so")   # VC_HIP_LIB: profiling build
 CSRC = os.path.join(_HERE, "csrc")
 
+ABI_VERSION = 2                # VC_ABI_VERSION of include/vcloze_hip.h
 GEMM_MAX_PROBLEMS = 4          # VC_GEMM_MAX_PROBLEMS: grouped problems per vc_gemm launch
 EPI_BIAS, EPI_GELU, EPI_GATE_RES, EPI_SILU = 0, 1, 2, 3
 
@@ -43,11 +44,18 @@ class GemmArgs(C.Structure):
     ]
 
 
+class LnStream(C.Structure):
+    """VcLnStream of include/vcloze_hip.h."""
+    _fields_ = [("x", C.c_void_p), ("ldx", C.c_int64), ("y", C.c_void_p), ("ldy", C.c_int64), ("shift", C.c_void_p),
+                ("scale", C.c_void_p), ("rows", C.c_int32), ("rows_per_batch", C.c_int32)]
+
+
 # every symbol include/vcloze_hip.h declares: name -> (restype, argtypes)
 _vp, _i32, _i64 = C.c_void_p, C.c_int32, C.c_int64
 SYMBOLS = {
     "vc_abi_version": (C.c_int, []),
     "vc_last_error": (C.c_char_p, []),
+    "vc_struct_sizes": (None, [C.POINTER(C.c_int32)]),
     "vc_device_count": (C.c_int, []),
     "vc_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "vc_gemm": (C.c_int, [C.POINTER(GemmArgs), C.c_int, _vp]),
@@ -97,14 +105,13 @@ _lib = None
 
 
 def build(force: bool = False) -> str:
-    """Compile csrc/*.hip for gfx950 into lib/libvcloze_hip.so (hipcc cross-compiles without a GPU)."""
-    if force or not os.path.exists(LIB_PATH) or any(
-        os.path.getmtime(os.path.join(CSRC, f)) > os.path.getmtime(LIB_PATH)
-        for f in os.listdir(CSRC) if f.endswith((".hip", ".h", "Makefile"))
-    ):
-        r = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
-        if r.returncode != 0:
-            raise VclozeHipError("building libvcloze_hip.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    """Compile csrc/*.hip for gfx950 into lib/libvcloze_hip.so (hipcc cross-compiles without a GPU).  `make` is
+    incremental and knows every dependency (the ABI header include/vcloze_hip.h included), so it is simply run."""
+    if force:
+        subprocess.run(["make", "-C", CSRC, "clean"], capture_output=True, text=True)
+    r = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise VclozeHipError("building libvcloze_hip.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
     return LIB_PATH
 
 
@@ -119,8 +126,12 @@ def lib() -> C.CDLL:
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(l, name)  # AttributeError if the ABI lost a symbol
             fn.restype, fn.argtypes = res, args
-        if l.vc_abi_version() != 1:
-            raise VclozeHipError("libvcloze_hip.so ABI version mismatch")
+        if l.vc_abi_version() != ABI_VERSION:
+            raise VclozeHipError(f"libvcloze_hip.so ABI version {l.vc_abi_version()} != {ABI_VERSION} expected by hip.py - rebuild")
+        sizes = (C.c_int32 * 3)()
+        l.vc_struct_sizes(sizes)          # a stale library whose structs disagree with these ctypes mirrors must not run
+        if list(sizes) != [C.sizeof(GemmProblem), C.sizeof(GemmArgs), C.sizeof(LnStream)]:
+            raise VclozeHipError(f"libvcloze_hip.so struct sizes {list(sizes)} differ from the ctypes mirrors - rebuild")
         _lib = l
     return _lib
 
@@ -215,12 +226,6 @@ def ln_modulate(x, shift, scale, out=None, step_ptr=None, mod_step_stride=0, str
                                 scale.data_ptr(), mod_bstride, rows, D, rows_per_batch or rows, _p(step_ptr), mod_step_stride,
                                 stream if stream is not None else cur_stream()), "vc_ln_modulate")
     return out
-
-
-class LnStream(C.Structure):
-    """VcLnStream of include/vcloze_hip.h."""
-    _fields_ = [("x", C.c_void_p), ("ldx", C.c_int64), ("y", C.c_void_p), ("ldy", C.c_int64), ("shift", C.c_void_p),
-                ("scale", C.c_void_p), ("rows", C.c_int32), ("rows_per_batch", C.c_int32)]
 
 
 def ln_modulate2(streams, step_ptr=None, mod_step_stride=0, stream=None, mod_bstride=0) -> None:

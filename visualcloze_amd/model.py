@@ -155,6 +155,19 @@ class LastLayer(_NoTorchForward):
         self.adaLN_modulation = _Seq(_Empty(), Linear(hidden_size, 2 * hidden_size))
 
 
+def per_sample(v: Optional[Tensor], B: int) -> Optional[Tensor]:
+    """A per-sample vector [B]; a single value (the pipeline's `guidance = torch.full((1,), cfg)`, visualcloze.py:413)
+    broadcasts over the batch as it does in the reference's `vec + guidance_in(...)`."""
+    if v is None:
+        return None
+    v = v.reshape(-1)
+    if v.numel() == 1 and B > 1:
+        v = v.expand(B)
+    if v.numel() != B:
+        raise ValueError(f"expected 1 or {B} per-sample values, got {v.numel()}")
+    return v
+
+
 class Flux(nn.Module):
     """Drop-in for models/model.py:35-151 (inference surface)."""
 
@@ -240,6 +253,12 @@ class Flux(nn.Module):
         self._fingerprint = self._weights_fingerprint()
         return self._engine
 
+    def invalidate_engine(self) -> None:
+        """Forget the prepared (merged, bf16) weights; the next forward / sample re-prepares.  Call after writing the
+        parameters through a path that does not bump `_version` (`.data`, dist.broadcast)."""
+        self._engine = None
+        self._fingerprint = None
+
     def engine(self) -> FluxEngine:
         if self._engine is None or self._fingerprint != self._weights_fingerprint():
             self.prepare()
@@ -270,13 +289,16 @@ class Flux(nn.Module):
         out = torch.empty(B, N, self.out_channels, dtype=torch.bfloat16, device=dev)
         bf = lambda t: t.to(dev, torch.bfloat16).contiguous()  # noqa: E731
         gbf16 = guidance is not None and guidance.dtype == torch.bfloat16
+        guidance = per_sample(guidance, B)
+        timesteps = per_sample(timesteps, B)
         for b0 in range(0, B, eng.MAX_BATCH):          # samples of a chunk run as ONE stacked launch sequence
             bs = min(eng.MAX_BATCH, B - b0)
             sl = slice(b0, b0 + bs)
             ws = eng.workspace(T, N, 1, bs)
             eng.prepare_sample(ws, bf(txt[sl]), bf(y[sl]), None if guidance is None else guidance[sl], gbf16, img_ids[sl],
                                txt_ids[sl], timesteps[sl].float().reshape(1, bs),
-                               [self._kv_len(txt_mask, img_mask, b, T, N) for b in range(b0, b0 + bs)])
+                               [self._kv_len(txt_mask, img_mask, b, T, N) for b in range(b0, b0 + bs)],
+                               timesteps_is_bf16=timesteps.dtype == torch.bfloat16)
             ws.XIN.copy_(bf(img[sl]).reshape(bs * N, -1))
             eng.eval_once(ws, None, euler=False, concat=False)
             out[sl].copy_(ws.V.reshape(bs, N, -1))

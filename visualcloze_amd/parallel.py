@@ -66,6 +66,12 @@ def broadcast_weights(module: torch.nn.Module, src: int = 0, bucket_bytes: int =
                 o += p.numel()
             del flat
         i = j
+    # dist.broadcast / copy_ through `.data` do not bump `Parameter._version`, which the engines' weight
+    # fingerprints key on: drop every prepared (LoRA-merged) copy explicitly so it is rebuilt from the new weights.
+    for m in module.modules():
+        inv = getattr(m, "invalidate_engine", None)
+        if callable(inv):
+            inv()
     if torch.cuda.is_available():
         torch.cuda.synchronize()
     return time.time() - t0

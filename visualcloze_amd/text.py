@@ -221,7 +221,10 @@ class T5EncoderModel(nn.Module, _Exec):
         to run them, so the launch sequence is captured once per (sequence length, weight storage) as a hipGraph on a
         side stream and replayed: ids in / hidden states out through persistent buffers."""
         dev, L = ids.device, ids.shape[0]
-        sig = (L, str(dev), tuple(p.data_ptr() for p in self.parameters()), all(p.dtype == torch.bfloat16 for p in self.parameters()))
+        # keyed on storage AND version: an in-place reload (load_state_dict) must rebuild the plan, because the gathered
+        # relative-position-bias table is baked into the capture (ADVICE r1)
+        sig = (L, str(dev), tuple((p.data_ptr(), p._version) for p in self.parameters()),
+               all(p.dtype == torch.bfloat16 for p in self.parameters()))
         plan = self.__dict__.get("_plan")
         if plan is None or plan["sig"] != sig:
             plan = {"sig": sig, "ids": torch.zeros(L, dtype=torch.int32, device=dev),

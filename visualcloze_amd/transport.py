@@ -89,12 +89,25 @@ class Sampler:
         return _sample
 
 
+def _solver_t_as_state(t: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """torchdiffeq hands the drift `t.to(y.dtype)` (`_PerturbFunc.forward`): with the bf16 state of
+    visualcloze.py:399 the time a model sees is bf16(t_i), while dt = t_{i+1} - t_i comes from the f32 grid."""
+    return t.to(x.dtype).to(torch.float32) if x.dtype.is_floating_point else t.to(torch.float32)
+
+
+def model_times(t: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """The `timesteps` of the S = len(t) - 1 Flux evaluations (f32): 1 - t_i with t_i rounded to the state dtype
+    (integrators.py:108-109 builds `ones(B) * t` in f32 from it; transport.py:384 forms 1 - t)."""
+    t32 = t.to(torch.float32)
+    return torch.ones(len(t) - 1) * (1 - _solver_t_as_state(t32[:-1], x))
+
+
 def _sample_foreign(model, x, kw, t, return_trajectory):
     """Any other callable: the same grid and update rule, one host-driven call per interval."""
     cond = kw.pop("cond", None)
     states = [x]
     for i in range(len(t) - 1):
-        tt = torch.ones(x.size(0), device=x.device) * t[i].to(x.device)
+        tt = torch.ones(x.size(0), device=x.device) * _solver_t_as_state(t[i], x).to(x.device)
         xin = torch.cat((x, cond), dim=-1) if cond is not None else x
         v = model(xin, timesteps=torch.ones_like(tt) * (1 - tt), **kw)
         assert v.shape == x.shape, "Output shape from ODE solver must match input shape"
@@ -120,12 +133,14 @@ def _sample_fused(flux, x, kw, t, return_trajectory):
     T = txt.shape[1]
     S = len(t) - 1
     t32 = t.to(torch.float32)
-    eval_t = torch.ones(S) * (1 - t32[:-1])        # Flux sees 1 - t (transport.py:384)
+    eval_t = model_times(t32, x)                   # Flux sees 1 - t (transport.py:384), t in the state's dtype
     dts = (t32[1:] - t32[:-1]).contiguous()        # torchdiffeq fixed grid: dt = t1 - t0
     bf = lambda a: a.to(dev, torch.bfloat16).contiguous()  # noqa: E731
     out = torch.empty(B, N, C, dtype=torch.bfloat16, device=dev)
     traj = []
     gbf16 = guidance is not None and guidance.dtype == torch.bfloat16
+    from .model import per_sample
+    guidance = per_sample(guidance, B)
     st = eng.stream
     st.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(st):

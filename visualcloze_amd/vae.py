@@ -159,7 +159,12 @@ class _HipExec(nn.Module):
 
     def _norm(self, gn: _GroupNorm, x, y, swish):
         sc = self._scratch(x.device, "gn", (hip.groupnorm_scratch_floats(x.shape[0]),), torch.float32)
-        hip.groupnorm(x, gn.weight.detach().to(torch.bfloat16), gn.bias.detach().to(torch.bfloat16), y, sc, swish=swish)
+        c = gn.__dict__.get("_bf16_affine")
+        key = (gn.weight.data_ptr(), gn.weight._version, gn.bias.data_ptr(), gn.bias._version)
+        if c is None or c[0] != key:        # converted once per weight load, not per call
+            c = (key, gn.weight.detach().to(torch.bfloat16).contiguous(), gn.bias.detach().to(torch.bfloat16).contiguous())
+            gn.__dict__["_bf16_affine"] = c
+        hip.groupnorm(x, c[1], c[2], y, sc, swish=swish)
 
     def _resnet(self, blk: ResnetBlock, x, H, W, tag):
         """x: `_act` map [HW+1, Cin]; returns an `_act` map [HW+1, Cout]."""

@@ -141,16 +141,18 @@ def sdpa(q: Tensor, k: Tensor, v: Tensor, P: Prec, kv_len: Optional[List[int]] =
     out = torch.zeros(B, L, H * D)
     for b in range(B):
         n = L if kv_len is None else int(kv_len[b])
-        s = (q[b, :, :n].float() @ k[b, :, :n].float().transpose(-1, -2)) * (D ** -0.5)
-        p = torch.softmax(s, dim=-1)
-        if P.mode == "bf16":
-            # flash-attn keeps the un-normalised P in bf16 for the PV matmul and divides by the f32 row sum last
-            m = s.max(dim=-1, keepdim=True).values
-            e = torch.exp(s - m)
-            o = (P.r(e) @ v[b, :, :n].float()) / e.sum(dim=-1, keepdim=True)
-        else:
-            o = p @ v[b, :, :n].float()
-        out[b, :n] = P.r(o.permute(1, 0, 2).reshape(n, H * D))
+        hc = max(1, min(H, (1 << 28) // max(1, n * n)))     # heads per chunk: score tensors stay <= 1 GiB (L = 7424 fits)
+        for h0 in range(0, H, hc):
+            hs = slice(h0, min(H, h0 + hc))
+            s = (q[b, hs, :n].float() @ k[b, hs, :n].float().transpose(-1, -2)) * (D ** -0.5)
+            if P.mode == "bf16":
+                # flash-attn keeps the un-normalised P in bf16 for the PV matmul and divides by the f32 row sum last
+                m = s.max(dim=-1, keepdim=True).values
+                e = torch.exp(s - m)
+                o = (P.r(e) @ v[b, hs, :n].float()) / e.sum(dim=-1, keepdim=True)
+            else:
+                o = torch.softmax(s, dim=-1) @ v[b, hs, :n].float()
+            out[b, :n, h0 * D:(h0 + o.shape[0]) * D] = P.r(o.permute(1, 0, 2).reshape(n, o.shape[0] * D))
     return out
 
 

@@ -152,6 +152,13 @@ def test_fused_sampler_vs_golden_trajectory(model, golden):
     for i in range(1, ref.shape[0]):
         assert rel_l2(tr[i], ref[i]) < 2 * TOL_GOLDEN
     assert torch.equal(tr[-1], out[-1])
+    # the reference's own bf16 run (bf16 state => Flux sees 1 - bf16(t_i); un-merged LoRA, CPU autocast): the guidance
+    # tensor is bf16 there (visualcloze.py:413), so 1000*g rounds to 29952
+    kwb = dict(kw, guidance=kw["guidance"].to(torch.bfloat16))
+    trb = fn_t(inp["x"].to("cuda", torch.bfloat16), m.forward, kwb)
+    refb = golden["traj_bf16_states"]
+    for i in range(1, refb.shape[0]):
+        assert rel_l2(trb[i], refb[i]) < 2 * TOL_GOLDEN
 
 
 def test_fused_sampler_sdedit_grid(model, golden):

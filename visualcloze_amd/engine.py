@@ -189,89 +189,118 @@ class FluxEngine:
         self._gemm(hip.make_problem(ws.H1, W.mod_w, W.mod_b, ws.MOD), s=s)
 
     # ------------------------------------------------------------------ one evaluation
+    class _Ctx:
+        """Per-evaluation launch context: buffer views and the step-indexed modulation addressing."""
+
+    def _ctx(self, ws: Workspace, step_ptr, s):
+        c = FluxEngine._Ctx()
+        D, T, N, L, B = self.D, ws.T, ws.N, ws.L, ws.B
+        c.ws, c.step_ptr, c.s = ws, step_ptr, s
+        c.nm = self.W.n_mod
+        c.mss = B * c.nm                  # MOD step stride (elements); sample stride is nm
+        c.XH_I, c.XH_T = ws.XH[:B * N], ws.XH[B * N:]
+        c.HID_I, c.HID_T = ws.HID[:B * N], ws.HID[B * N:]
+        c.ATT = ws.CAT[:, :D]
+        c.kvl = ws.KVLEN if ws.ragged else None
+        # joint-order views of the first sample's rows + batch strides (row m of a stream -> sample m // rows)
+        c.qkv_i = dict(M=B * N, c_rpb=N, c_bstride=L * ws.QKV.stride(0))
+        c.qkv_t = dict(M=B * T, c_rpb=T, c_bstride=L * ws.QKV.stride(0))
+        c.att_i = dict(M=B * N, a_rpb=N, a_bstride=L * ws.CAT.stride(0))
+        c.att_t = dict(M=B * T, a_rpb=T, a_bstride=L * ws.CAT.stride(0))
+        return c
+
+    def _ln(self, c, x, name, idx, out, rpb):
+        hip.ln_modulate(x, self._mod(c.ws, name, idx), self._mod(c.ws, name, idx + 1), out=out, step_ptr=c.step_ptr,
+                        mod_step_stride=c.mss, stream=c.s, rows_per_batch=rpb, mod_bstride=c.nm)
+
+    def _ln2(self, c, name_i, name_t, idx):    # img + txt streams in one launch
+        ws = c.ws
+        hip.ln_modulate2([(ws.XI, self._mod(ws, name_i, idx), self._mod(ws, name_i, idx + 1), c.XH_I, ws.N),
+                          (ws.XT, self._mod(ws, name_t, idx), self._mod(ws, name_t, idx + 1), c.XH_T, ws.T)],
+                         step_ptr=c.step_ptr, mod_step_stride=c.mss, stream=c.s, mod_bstride=c.nm)
+
+    def _gated(self, c, names, As, outs, gates, rpbs, a_views):
+        ps = []
+        for n_, a_, o_, g_, rpb, av in zip(names, As, outs, gates, rpbs, a_views):
+            ps.append(self._prob(n_, a_, o_, res=o_, gate=g_, rows_per_batch=rpb, gate_bstride=c.nm, **av))
+        self._gemm(ps, epi=hip.EPI_GATE_RES, step_ptr=c.step_ptr, gate_step_stride=c.mss, s=c.s)
+
+    def _attention(self, c, scales, split):
+        """QKNorm + RoPE (+ V^T) and the joint attention over ws.QKV -> CAT[:, :D] (layers.py:165-185 / 236-241)."""
+        ws, s = c.ws, c.s
+        q1, k1, q2, k2 = scales
+        hip.qknorm_rope_vt(ws.QKV, q1, k1, ws.ROPE, ws.VT, ws.L, self.H, stream=s, q_scale2=q2, k_scale2=k2, split=split, B=ws.B)
+        hip.attention(ws.QKV, ws.VT, c.ATT, ws.L, self.H, kv_len=c.kvl, variant=self.attn_variant, stream=s, B=ws.B)
+
+    def double_block(self, c, i: int) -> None:
+        """DoubleStreamBlock i (layers.py:158-196) on ws.XI / ws.XT, in place."""
+        ws, s, Wn = c.ws, c.s, self.W.w
+        T, N = ws.T, ws.N
+        pf = f"double_blocks.{i}"
+        im, tm = pf + ".img_mod.lin", pf + ".txt_mod.lin"
+        self._ln2(c, im, tm, 0)
+        self._gemm([self._prob(pf + ".img_attn.qkv", c.XH_I, ws.QKV[T:], **c.qkv_i),
+                    self._prob(pf + ".txt_attn.qkv", c.XH_T, ws.QKV[:T], **c.qkv_t)], s=s)
+        self._attention(c, (Wn[pf + ".txt_attn.norm.query_norm.scale"], Wn[pf + ".txt_attn.norm.key_norm.scale"],
+                            Wn[pf + ".img_attn.norm.query_norm.scale"], Wn[pf + ".img_attn.norm.key_norm.scale"]), T)
+        self._gated(c, (pf + ".img_attn.proj", pf + ".txt_attn.proj"), (c.ATT[T:], c.ATT[:T]), (ws.XI, ws.XT),
+                    (self._mod(ws, im, 2), self._mod(ws, tm, 2)), (N, T), (c.att_i, c.att_t))
+        self._ln2(c, im, tm, 3)
+        self._gemm([self._prob(pf + ".img_mlp.0", c.XH_I, c.HID_I), self._prob(pf + ".txt_mlp.0", c.XH_T, c.HID_T)],
+                   epi=hip.EPI_GELU, s=s)
+        self._gated(c, (pf + ".img_mlp.2", pf + ".txt_mlp.2"), (c.HID_I, c.HID_T), (ws.XI, ws.XT),
+                    (self._mod(ws, im, 5), self._mod(ws, tm, 5)), (N, T), ({}, {}))
+
+    def join_streams(self, c) -> None:
+        """cat((txt, img), 1) per sample (model.py:116): XT / XI -> X."""
+        ws, s = c.ws, c.s
+        T, N, L = ws.T, ws.N, ws.L
+        for b in range(ws.B):
+            hip.copy(ws.X[b * L:b * L + T], ws.XT[b * T:(b + 1) * T], stream=s)
+            hip.copy(ws.X[b * L + T:(b + 1) * L], ws.XI[b * N:(b + 1) * N], stream=s)
+
+    def single_block(self, c, i: int) -> None:
+        """SingleStreamBlock i (layers.py:232-245) on ws.X, in place."""
+        ws, s, Wn, D = c.ws, c.s, self.W.w, self.D
+        pf = f"single_blocks.{i}"
+        mn = pf + ".modulation.lin"
+        self._ln(c, ws.X, mn, 0, ws.XH, ws.L)
+        self._lin(pf + ".linear1.qkv", ws.XH, ws.QKV, s=s)
+        self._lin(pf + ".linear1.mlp", ws.XH, ws.CAT[:, D:], epi=hip.EPI_GELU, s=s)
+        self._attention(c, (Wn[pf + ".norm.query_norm.scale"], Wn[pf + ".norm.key_norm.scale"], None, None), 0)
+        self._gated(c, (pf + ".linear2",), (ws.CAT,), (ws.X,), (self._mod(ws, mn, 2),), (ws.L,), ({},))
+
+    def last_layer(self, c) -> None:
+        """LastLayer (layers.py:248-259) on the image rows of ws.X -> ws.V."""
+        ws, s = c.ws, c.s
+        fm = "final_layer.adaLN_modulation.1"
+        self._ln(c, ws.X, fm, 0, ws.XH, ws.L)   # text rows are normalised too (13 % of a 10 us kernel) and then skipped
+        self._lin("final_layer.linear", ws.XH[ws.T:], ws.V, s=s, M=ws.B * ws.N, a_rpb=ws.N, a_bstride=ws.L * ws.XH.stride(0))
+
     def eval_once(self, ws: Workspace, step_ptr, euler: bool, s=None, taps: Optional[dict] = None,
                   concat: bool = True) -> None:
         """Flux.forward on ws.XS || ws.COND (or a caller-filled ws.XIN when not `concat`) -> ws.V, plus the
         Euler update of ws.XS when `euler`."""
-        D, H, T, N, L, B = self.D, self.H, ws.T, ws.N, ws.L, ws.B
-        nm = self.W.n_mod
-        mss = B * nm                      # MOD step stride (elements); sample stride is nm
-        XI, XT, X, XH, QKV, CAT, HID = ws.XI, ws.XT, ws.X, ws.XH, ws.QKV, ws.CAT, ws.HID
-        XH_I, XH_T = XH[:B * N], XH[B * N:]
-        HID_I, HID_T = HID[:B * N], HID[B * N:]
-        ATT = CAT[:, :D]
-        kvl = ws.KVLEN if ws.ragged else None
-        Wn = self.W.w
+        c = self._ctx(ws, step_ptr, s)
 
         def tap(name, t):
             if taps is not None:
                 torch.cuda.synchronize()
                 taps[name] = t.float().cpu().clone()
 
-        def ln(x, name, idx, out, rpb):
-            hip.ln_modulate(x, self._mod(ws, name, idx), self._mod(ws, name, idx + 1), out=out, step_ptr=step_ptr,
-                            mod_step_stride=mss, stream=s, rows_per_batch=rpb, mod_bstride=nm)
-
-        def ln2(name_i, name_t, idx):    # img + txt streams in one launch
-            hip.ln_modulate2([(XI, self._mod(ws, name_i, idx), self._mod(ws, name_i, idx + 1), XH_I, N),
-                              (XT, self._mod(ws, name_t, idx), self._mod(ws, name_t, idx + 1), XH_T, T)],
-                             step_ptr=step_ptr, mod_step_stride=mss, stream=s, mod_bstride=nm)
-
-        def gated(names, As, outs, gates, rpbs, a_views):
-            ps = []
-            for n_, a_, o_, g_, rpb, av in zip(names, As, outs, gates, rpbs, a_views):
-                ps.append(self._prob(n_, a_, o_, res=o_, gate=g_, rows_per_batch=rpb, gate_bstride=nm, **av))
-            self._gemm(ps, epi=hip.EPI_GATE_RES, step_ptr=step_ptr, gate_step_stride=mss, s=s)
-
         if concat:
             hip.concat_cols(ws.XS, ws.COND, ws.XIN, stream=s)
-        hip.copy(XT, ws.TXT0, stream=s)
-        self._lin("img_in", ws.XIN, XI, s=s)
-        tap("img_in", XI); tap("txt_in", XT)
-
-        # joint-order views of the first sample's rows + batch strides (row m of a stream -> sample m // rows)
-        qkv_i = dict(M=B * N, c_rpb=N, c_bstride=L * QKV.stride(0))
-        qkv_t = dict(M=B * T, c_rpb=T, c_bstride=L * QKV.stride(0))
-        att_i = dict(M=B * N, a_rpb=N, a_bstride=L * CAT.stride(0))
-        att_t = dict(M=B * T, a_rpb=T, a_bstride=L * CAT.stride(0))
+        hip.copy(ws.XT, ws.TXT0, stream=s)
+        self._lin("img_in", ws.XIN, ws.XI, s=s)
+        tap("img_in", ws.XI); tap("txt_in", ws.XT)
         for i in range(self.g.depth):
-            pf = f"double_blocks.{i}"
-            im, tm = pf + ".img_mod.lin", pf + ".txt_mod.lin"
-            ln2(im, tm, 0)
-            self._gemm([self._prob(pf + ".img_attn.qkv", XH_I, QKV[T:], **qkv_i),
-                        self._prob(pf + ".txt_attn.qkv", XH_T, QKV[:T], **qkv_t)], s=s)
-            hip.qknorm_rope_vt(QKV, Wn[pf + ".txt_attn.norm.query_norm.scale"], Wn[pf + ".txt_attn.norm.key_norm.scale"],
-                               ws.ROPE, ws.VT, L, H, stream=s, q_scale2=Wn[pf + ".img_attn.norm.query_norm.scale"],
-                               k_scale2=Wn[pf + ".img_attn.norm.key_norm.scale"], split=T, B=B)
-            hip.attention(QKV, ws.VT, ATT, L, H, kv_len=kvl, variant=self.attn_variant, stream=s, B=B)
-            gated((pf + ".img_attn.proj", pf + ".txt_attn.proj"), (ATT[T:], ATT[:T]), (XI, XT),
-                  (self._mod(ws, im, 2), self._mod(ws, tm, 2)), (N, T), (att_i, att_t))
-            ln2(im, tm, 3)
-            self._gemm([self._prob(pf + ".img_mlp.0", XH_I, HID_I), self._prob(pf + ".txt_mlp.0", XH_T, HID_T)],
-                       epi=hip.EPI_GELU, s=s)
-            gated((pf + ".img_mlp.2", pf + ".txt_mlp.2"), (HID_I, HID_T), (XI, XT),
-                  (self._mod(ws, im, 5), self._mod(ws, tm, 5)), (N, T), ({}, {}))
-            tap(f"double.{i}.img", XI); tap(f"double.{i}.txt", XT)
-
-        for b in range(B):                # cat((txt, img), 1) per sample
-            hip.copy(X[b * L:b * L + T], XT[b * T:(b + 1) * T], stream=s)
-            hip.copy(X[b * L + T:(b + 1) * L], XI[b * N:(b + 1) * N], stream=s)
-
+            self.double_block(c, i)
+            tap(f"double.{i}.img", ws.XI); tap(f"double.{i}.txt", ws.XT)
+        self.join_streams(c)
         for i in range(self.g.depth_single_blocks):
-            pf = f"single_blocks.{i}"
-            mn = pf + ".modulation.lin"
-            ln(X, mn, 0, XH, L)
-            self._lin(pf + ".linear1.qkv", XH, QKV, s=s)
-            self._lin(pf + ".linear1.mlp", XH, CAT[:, D:], epi=hip.EPI_GELU, s=s)
-            hip.qknorm_rope_vt(QKV, Wn[pf + ".norm.query_norm.scale"], Wn[pf + ".norm.key_norm.scale"], ws.ROPE, ws.VT,
-                               L, H, stream=s, B=B)
-            hip.attention(QKV, ws.VT, ATT, L, H, kv_len=kvl, variant=self.attn_variant, stream=s, B=B)
-            gated((pf + ".linear2",), (CAT,), (X,), (self._mod(ws, mn, 2),), (L,), ({},))
-            tap(f"single.{i}", X)
-
-        fm = "final_layer.adaLN_modulation.1"
-        ln(X, fm, 0, XH, L)              # text rows are normalised too (13 % of a 10 us kernel) and then skipped
-        self._lin("final_layer.linear", XH[T:], ws.V, s=s, M=B * N, a_rpb=N, a_bstride=L * XH.stride(0))
+            self.single_block(c, i)
+            tap(f"single.{i}", ws.X)
+        self.last_layer(c)
         if euler:
             hip.euler_step(ws.XS, ws.V, ws.DTS, step_ptr, stream=s)
             hip.step_advance(step_ptr, stream=s)

@@ -208,24 +208,35 @@ class Flux(nn.Module):
         return tuple((p.data_ptr(), p._version) for p in self.parameters()) + tuple(
             m.scale for _, m in self._linears())
 
+    @staticmethod
     @torch.no_grad()
-    def prepare(self) -> FluxEngine:
+    def merged_linear(m: "Linear"):
+        """(W', b') of one Linear as the engine executes it: bf16(W + s*B@A), bf16(b + s*b_B) - LinearLora
+        (models/modules/lora.py:92-98) with its LoRA pair folded in, exact in f32 and rounded to bf16 once."""
+        W32 = m.weight.detach().float()
+        B32 = None if m.bias is None else m.bias.detach().float()
+        if m.rank:
+            W32 = W32 + m.scale * (m.lora_B.weight.detach().float() @ m.lora_A.weight.detach().float())
+            if m.lora_B.bias is not None:
+                B32 = (B32 if B32 is not None else 0) + m.scale * m.lora_B.bias.detach().float()
+        return W32.to(torch.bfloat16).contiguous(), None if B32 is None else B32.to(torch.bfloat16).contiguous()
+
+    @torch.no_grad()
+    def prepare(self, free_parameters: bool = False) -> FluxEngine:
         """(Re)build the engine's device weights: bf16, contiguous, LoRA merged as W + s*B@A, b + s*b_B
-        (exact in f32, rounded to bf16 once — DESIGN.md §numerics).  One-time preprocessing; uses torch ops."""
+        (exact in f32, rounded to bf16 once — DESIGN.md §numerics).  One-time preprocessing; uses torch ops.
+        `free_parameters`: release the module's own parameter storage afterwards (sampling-only ranks of a
+        data-parallel job: 23.8 GB of merged weights stay, the 26.3 GB of un-merged parameters go; the module can
+        then no longer be re-prepared or saved until weights are loaded again)."""
         hip.require_gpu()
         dev = next(self.parameters()).device
         if dev.type != "cuda":
             raise hip.VclozeHipError("Flux weights must live on the GPU (model.to('cuda')) — there is no CPU path")
+        if getattr(self, "_params_freed", False):
+            raise hip.VclozeHipError("parameters were released by prepare(free_parameters=True); load weights again first")
         w, b = {}, {}
         for name, m in self._linears():
-            W32 = m.weight.detach().float()
-            B32 = None if m.bias is None else m.bias.detach().float()
-            if m.rank:
-                W32 = W32 + m.scale * (m.lora_B.weight.detach().float() @ m.lora_A.weight.detach().float())
-                if m.lora_B.bias is not None:
-                    B32 = (B32 if B32 is not None else 0) + m.scale * m.lora_B.bias.detach().float()
-            w[name] = W32.to(torch.bfloat16).contiguous()
-            b[name] = None if B32 is None else B32.to(torch.bfloat16).contiguous()
+            w[name], b[name] = self.merged_linear(m)
         for name, p in self.named_parameters():
             if name.endswith("norm.scale"):
                 w[name] = p.detach().to(torch.bfloat16).contiguous()
@@ -250,6 +261,11 @@ class Flux(nn.Module):
         freqs = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half).to(dev)
         pw = PreparedWeights(w=w, b=b, mod_w=mod_w, mod_b=mod_b, mod_off=off, n_mod=o, temb_freqs=freqs)
         self._engine = FluxEngine(self.params, pw, dev)
+        if free_parameters:
+            for p in self.parameters():
+                p.data = torch.empty(0, dtype=p.dtype, device=p.device)
+            self._params_freed = True
+            torch.cuda.empty_cache()
         self._fingerprint = self._weights_fingerprint()
         return self._engine
 

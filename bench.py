@@ -5,8 +5,8 @@ A "step" is one solver step of the hot path for one grid: a full Flux evaluation
 blocks, L = 512 text + 3456 image tokens for the 384-grid 2x3 layout = BASELINE configs[1]) plus the Euler
 update, replayed as one hipGraph.  Every rank (one process per GPU) runs its own independent grid: weak
 scaling, no collective inside the step; the frozen weights are broadcast once over RCCL before timing.
-Per-sample precomputation (txt_in, vec path, all 29x1.06M modulation rows, RoPE table) is INSIDE the timed
-region whenever a new sample starts, inputs already resident in HBM.
+The timed region OPENS on a sample boundary, so the per-sample precomputation (txt_in, vec path, all 29x1.06M
+modulation rows, RoPE table; reported separately as `precompute_ms`) is inside it; inputs are resident in HBM.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -123,11 +123,23 @@ class Job:
         self.graph = eng.step_graph(ws, self.s)
         self.step_in_sample = 0
 
+    def restart_sample(self):
+        self.step_in_sample = self.S
+
     def step(self):
         if self.step_in_sample >= self.S:
             self.begin_sample()
         self.graph.launch(self.s)
         self.step_in_sample += 1
+
+    def precompute_ms(self, iters=3):
+        """wall time of one begin_sample() (host RoPE table + H2D, txt_in, vec path, the all-steps modulation GEMM)"""
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            self.begin_sample()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters * 1e3
 
 
 def flops_per_eval(T, N, D=3072, H=24, mlp=12288, depth=19, single=38, in_ch=384, out_ch=64):
@@ -137,18 +149,24 @@ def flops_per_eval(T, N, D=3072, H=24, mlp=12288, depth=19, single=38, in_ch=384
     return lin, attn
 
 
+PMC_FILE = "profiles/r02_pmc_summary.json"
+
+
 def pmc_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01h_pmc_summary.json: FETCH_SIZE and WRITE_SIZE in separate --pmc runs, KiB units; FETCH_SIZE x2 on
-    gfx950 for wide coalesced reads, MI355X_MICROARCH.md §HBM).  PMC cannot be sampled from inside bench.py itself."""
-    path = os.path.join(REPO, "profiles", "r01h_pmc_summary.json")
-    try:
-        k = json.load(open(path))[kernel]
-        fetch, write = 2.0 * k["FETCH_SIZE"] * 1024.0, k["WRITE_SIZE"] * 1024.0
-        return dict(fetch_bytes=round(fetch), write_bytes=round(write), total_bytes=round(fetch + write),
-                    unit="bytes/launch", source="profiles/r01h_pmc_summary.json (rocprofv3 --pmc, FETCH_SIZE x2 gfx950 correction)")
-    except Exception:
-        return None
+    """HBM-side bytes per launch of `kernel`, READ FROM THE COMMITTED rocprofv3 PMC passes of this same command
+    (FETCH_SIZE and WRITE_SIZE in separate --pmc runs, KiB units; FETCH_SIZE x2 on gfx950 for wide coalesced reads,
+    MI355X_MICROARCH.md §HBM) - hardware counters cannot be sampled from inside bench.py, so this field is a file
+    lookup (`measured_in_this_run: false`), null when the file does not hold the kernel."""
+    for rel in (PMC_FILE, "profiles/r01h_pmc_summary.json"):
+        try:
+            k = json.load(open(os.path.join(REPO, rel)))[kernel]
+            fetch, write = 2.0 * k["FETCH_SIZE"] * 1024.0, k["WRITE_SIZE"] * 1024.0
+            return dict(fetch_bytes=round(fetch), write_bytes=round(write), total_bytes=round(fetch + write),
+                        unit="bytes/launch", measured_in_this_run=False,
+                        source=f"{rel} (rocprofv3 --pmc passes of bench.py, FETCH_SIZE x2 gfx950 correction)")
+        except Exception:
+            continue
+    return None
 
 
 def roofline_gemm(job, iters=3):
@@ -207,11 +225,13 @@ def roofline_attention(job, iters=3):
     eng, ws = job.eng, job.ws
     s = job.s
     with torch.cuda.stream(eng.stream):
-        hip.attention(ws.QKV, ws.VT, ws.CAT[:, :eng.D], ws.L, eng.H, variant=eng.attn_variant, stream=s, B=ws.B)
+        hip.attention(ws.QKV, ws.VT, ws.CAT[:, :eng.D], ws.L, eng.H, variant=eng.attn_variant, stream=s, B=ws.B,
+                      scratch=eng.attn_scratch)
         e0, e1 = hip.Event(), hip.Event()
         e0.record(s)
         for _ in range(iters * 10):
-            hip.attention(ws.QKV, ws.VT, ws.CAT[:, :eng.D], ws.L, eng.H, variant=eng.attn_variant, stream=s, B=ws.B)
+            hip.attention(ws.QKV, ws.VT, ws.CAT[:, :eng.D], ws.L, eng.H, variant=eng.attn_variant, stream=s, B=ws.B,
+                      scratch=eng.attn_scratch)
         e1.record(s)
         ms = e0.elapsed_ms(e1) / (iters * 10)
     fl = 4.0 * ws.L * ws.L * eng.D * ws.B
@@ -220,8 +240,9 @@ def roofline_attention(job, iters=3):
 
 
 def cpu_baseline(T, N, wl):
-    """The CPU oracle (a port of the reference path) on the host cores: one DoubleStreamBlock + one
-    SingleStreamBlock at full width, fp32, extrapolated x(19, 38) to one evaluation."""
+    """The CPU oracle (a port of the reference path) on the host cores: one DoubleStreamBlock + one SingleStreamBlock
+    at full width, extrapolated x(19, 38) to one evaluation - in fp32 (`value`: exact reference semantics, the faster
+    of the two on a CPU) and in the bf16 mode that rounds where the reference's autocast run does."""
     import oracle.flux_oracle as O
     G = O.FluxGeometry()
     D, L = G.hidden_size, T + N
@@ -243,20 +264,24 @@ def cpu_baseline(T, N, wl):
     img, txt, vec = torch.randn(1, N, D, generator=g), torch.randn(1, T, D, generator=g), torch.randn(1, D, generator=g)
     ids = torch.cat((torch.zeros(T, 3), grid_img_ids(wl['rows'], *wl['row_latent'])))[None]
     cs = O.rope_cos_sin(ids, G.axes_dim, G.theta)
-    P = O.Prec("fp32")
-    with torch.no_grad():
-        t0 = time.time(); O.double_block(sd, "d", img, txt, vec, cs, G, P); td = time.time() - t0
-        t0 = time.time(); O.double_block(sd, "d", img, txt, vec, cs, G, P); td = min(td, time.time() - t0)
-        x = torch.cat((txt, img), 1)
-        t0 = time.time(); O.single_block(sd, "s", x, vec, cs, G, P); ts = time.time() - t0
-        t0 = time.time(); O.single_block(sd, "s", x, vec, cs, G, P); ts = min(ts, time.time() - t0)
-    per_eval = G.depth * td + G.depth_single_blocks * ts
-    return dict(value=round(1.0 / per_eval, 5), unit="denoising-steps/sec", cores=cores, kind="port",
-                sample=f"oracle fp32: 1 DoubleStreamBlock ({td:.2f}s) + 1 SingleStreamBlock ({ts:.2f}s) at L={L}, D={D}, "
-                       f"extrapolated x(19,38) to one evaluation; best of 2")
+    x = torch.cat((txt, img), 1)
+
+    def leg(P, reps):
+        td = ts = 1e30
+        with torch.no_grad():
+            for _ in range(reps):
+                t0 = time.time(); O.double_block(sd, "d", img, txt, vec, cs, G, P); td = min(td, time.time() - t0)
+                t0 = time.time(); O.single_block(sd, "s", x, vec, cs, G, P); ts = min(ts, time.time() - t0)
+        return td, ts, 1.0 / (G.depth * td + G.depth_single_blocks * ts)
+    td, ts, v32 = leg(O.Prec("fp32"), 2)
+    tdb, tsb, v16 = leg(O.Prec("bf16", "merged"), 1)
+    return dict(value=round(v32, 5), unit="denoising-steps/sec", cores=cores, kind="port", bf16_value=round(v16, 5),
+                sample=f"oracle: 1 DoubleStreamBlock + 1 SingleStreamBlock at L={L}, D={D}, extrapolated x(19,38) to one "
+                       f"evaluation; fp32 {td:.2f}s + {ts:.2f}s (best of 2) -> value; bf16 rounding mode {tdb:.2f}s + {tsb:.2f}s "
+                       f"-> bf16_value")
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=29)
@@ -268,46 +293,30 @@ def main():
     ap.add_argument("--per-gpu-batch", type=int, default=1,
                     help="independent grids advanced together by one graph replay on each GPU (throughput mode; "
                          "BASELINE's cfg 2 is 1)")
-    a = ap.parse_args()
+    return ap.parse_args(argv)
 
-    rank = int(os.environ.get("RANK", 0))
-    local = int(os.environ.get("LOCAL_RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    if world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
-    from visualcloze_amd import hip
-    hip.require_gpu()                       # fails loudly: there is no CPU path to fall back to
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+
+def timed_region(job, steps, warmup, barrier=None, max_over_ranks=None):
+    """The contract's timing: W untimed steps, barrier + synchronize, EXACTLY K steps, barrier + synchronize, max over
+    ranks.  The timed region opens on a sample boundary, so the per-sample precompute of a new grid (txt_in, the vec
+    path, all 29 x 1.06 M modulation rows in one GEMM, the RoPE table: `precompute_ms`) is inside it."""
     from visualcloze_amd import parallel as par
-    par.init_distributed("nccl", dev)
-    wl = WORKLOADS[a.workload]
-    model, bcast_s = build_model(dev, rank, world)
-    eng = model.engine()
-    if a.tile_cfg is not None:
-        eng.tile_cfg = a.tile_cfg
-    if a.attn_variant is not None:
-        eng.attn_variant = a.attn_variant
+    barrier = barrier or par.barrier
+    for _ in range(warmup):
+        job.step()
+    job.restart_sample()                            # the next step() starts a new grid
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        job.step()
+    barrier()                                       # synchronize + barrier + synchronize
+    elapsed = time.perf_counter() - t0
+    return (max_over_ranks or par.max_over_ranks)(elapsed)
+
+
+def result_record(a, wl, world, elapsed, T, N, bcast_s, weight_bytes):
+    """The ONE JSON line of the contract (rank 0 adds roofline / cpu_baseline)."""
     PB = a.per_gpu_batch
-    x, kw = make_inputs(dev, wl, seed=par.sample_seed(0, rank * PB), B=PB)   # seed from the global sample index
-    job = Job(model, x, kw, wl["steps"])
-
-    barrier = par.barrier
-
-    with torch.cuda.stream(eng.stream):
-        for _ in range(a.warmup):
-            job.step()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            job.step()
-        barrier()                                   # synchronize + barrier + synchronize
-        elapsed = time.perf_counter() - t0
-    elapsed = par.max_over_ranks(elapsed, dev)
-    final = job.ws.XS.float()
-    assert torch.isfinite(final).all(), "non-finite latent"
-
-    T, N = 512, x.shape[1]
     lin, attn = flops_per_eval(T, N)
     value = world * PB * a.steps / elapsed          # a replay advances PB grids by one solver step each
     rec = {
@@ -322,14 +331,56 @@ def main():
         "model_tflops_per_eval": round((lin + attn) / 1e12, 2),
         "achieved_model_tflops_per_gpu": round((lin + attn) / 1e12 * value / world, 1),
         "per_gpu_batch": PB,
+        "rccl_ranks": world,
         "weight_broadcast_s": round(bcast_s, 3),
+        "weight_broadcast_gbps": round(weight_bytes / bcast_s / 1e9, 1) if bcast_s > 0 else None,
     }
+    return rec
+
+
+def main(argv=None):
+    a = parse_args(argv)
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    from visualcloze_amd import hip
+    hip.require_gpu()                       # fails loudly: there is no CPU path to fall back to
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    from visualcloze_amd import parallel as par
+    numa = par.pin_to_gpu_numa(local) if world > 1 else None     # one rank per GPU, each on its GPU's socket
+    par.init_distributed("nccl", dev)
+    assert par.world() == world
+    wl = WORKLOADS[a.workload]
+    model, bcast_s = build_model(dev, rank, world)
+    weight_bytes = sum(p.numel() * p.element_size() for p in model.parameters())
+    eng = model.prepare(free_parameters=True)   # sampling-only process: keep the 23.8 GB of merged weights, drop the rest
+    if a.tile_cfg is not None:
+        eng.tile_cfg = a.tile_cfg
+    if a.attn_variant is not None:
+        eng.attn_variant = a.attn_variant
+    PB = a.per_gpu_batch
+    x, kw = make_inputs(dev, wl, seed=par.sample_seed(0, rank * PB), B=PB)   # seed from the global sample index
+    job = Job(model, x, kw, wl["steps"])
+
+    with torch.cuda.stream(eng.stream):
+        elapsed = timed_region(job, a.steps, a.warmup, max_over_ranks=lambda s: par.max_over_ranks(s, dev))
+    final = job.ws.XS.float()
+    assert torch.isfinite(final).all(), "non-finite latent"
+
+    T, N = 512, x.shape[1]
+    rec = result_record(a, wl, world, elapsed, T, N, bcast_s, weight_bytes)
+    rec["numa_node"] = numa
+    rec["hbm_allocated_gb"] = round(torch.cuda.max_memory_allocated(dev) / 1e9, 1)
     if rank == 0:
+        rec["precompute_ms"] = round(job.precompute_ms(), 3)
         rec["roofline"] = roofline_gemm(job)
         rec["attention_kernel"] = roofline_attention(job)
         if world == 1 and not a.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(T, N, wl)
-            rec["gpu_over_cpu"] = round(value / rec["cpu_baseline"]["value"], 1)
+            rec["gpu_over_cpu"] = round(rec["value"] / rec["cpu_baseline"]["value"], 1)
         print(json.dumps(rec), flush=True)
     if world > 1:
         torch.distributed.barrier()

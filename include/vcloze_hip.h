@@ -105,11 +105,17 @@ int vc_qknorm_rope_vt(void* qkv, int64_t ld, int64_t bstride, const void* q_scal
  * kv_len[b] (host-visible semantics: keys >= kv_len masked, query rows >= kv_len written as 0,
  * = pad_input of math.py:96); NULL = all L.  out: [B, L, H*128] bf16, row stride ldo.
  * variant: 0 = 8 waves x 32 queries per workgroup, 1 = 4 waves x 32 queries (two workgroups per CU); +2 = the same
- * kernel on a persistent grid (one workgroup per resident slot, work items assigned statically) - 3 is the default
- * of the host engine.  All variants produce bit-identical results. */
+ * kernel on a persistent grid (one workgroup per resident slot, work items assigned statically); variants 0-3 produce
+ * bit-identical results.  7 = 3 with the TAIL SPLIT, the default of the host engine: the items beyond the last full
+ * round of 2 x CUs workgroups (232 of 744 at L = 3968, H = 24) are cut along the keys into one equal chunk per
+ * workgroup; partial (O, m, l) go to `scratch` (>= vc_attention_scratch_bytes(), device memory, contents undefined
+ * afterwards) and a second kernel on the same stream merges them.  Same softmax, different f32 summation order for
+ * those rows.  The launcher falls back to variant 3 when scratch is NULL / too small, kv_len is given, or the split
+ * would not shorten the critical path. */
 int vc_attention(const void* qkv, int64_t ld, int64_t bstride, const void* vt, void* out, int64_t ldo,
                  int64_t out_bstride, const int32_t* kv_len, int32_t B, int32_t L, int32_t Lpad, int32_t H,
-                 int32_t variant, void* stream);
+                 int32_t variant, void* scratch, int64_t scratch_bytes, void* stream);
+int64_t vc_attention_scratch_bytes(void);
 
 /* timestep_embedding (layers.py:28-49): out[b, 0:half]=cos(1000*t*f), [half:]=sin, f host table. */
 int vc_timestep_embedding(const float* t, const float* freqs, void* out_bf16, int32_t n, int32_t half,

@@ -75,6 +75,75 @@ def test_data_parallel_path_world2_gloo(tmp_path):
         assert f"rank {r} ok" in o
 
 
+BENCH_WORKER = textwrap.dedent("""
+    import json, os, sys, time, torch
+    sys.path.insert(0, %r)
+    import bench
+    from visualcloze_amd import parallel as par
+    par.init_distributed("gloo")
+    r, w = par.rank(), par.world()
+    a = bench.parse_args(["--gpus", str(w), "--steps", "6", "--warmup", "2", "--workload", "384-grid-1x2"])
+    wl = bench.WORKLOADS[a.workload]
+    x, kw = bench.make_inputs("cpu", wl, seed=par.sample_seed(0, r * a.per_gpu_batch), B=a.per_gpu_batch)
+
+    class StubJob:                       # stands in for the engine-backed Job: same driver protocol, no GPU
+        def __init__(self): self.steps = self.restarts = 0; self.first_after_restart = None
+        def restart_sample(self): self.restarts += 1; self.pending = True
+        def step(self):
+            if getattr(self, "pending", False): self.first_after_restart = self.steps; self.pending = False
+            self.steps += 1; time.sleep(0.002 * (r + 1))      # rank w-1 is the slowest
+    job = StubJob()
+    elapsed = bench.timed_region(job, a.steps, a.warmup)
+    assert job.steps == a.steps + a.warmup and job.restarts == 1 and job.first_after_restart == a.warmup
+    assert elapsed >= 0.002 * w * a.steps                      # max over ranks: everyone reports the slowest rank's time
+    rec = bench.result_record(a, wl, w, elapsed, 512, x.shape[1], bcast_s=0.5, weight_bytes=26.3e9)
+    assert rec["n_gpus"] == w and rec["rccl_ranks"] == w and rec["scaling"] == "weak"
+    assert abs(rec["value"] - w * a.steps / elapsed) < 1e-3 and rec["config"]["parallelism"] == f"dp{w}"
+    assert rec["weight_broadcast_gbps"] == 52.6
+    # per-rank inputs come from the GLOBAL sample index: distinct across ranks, reproducible without the job
+    sums = [None] * w
+    torch.distributed.all_gather_object(sums, float(x.float().sum()))
+    assert len(set(sums)) == w, sums
+    x1, _ = bench.make_inputs("cpu", wl, seed=par.sample_seed(0, r), B=1)
+    assert torch.equal(x, x1)
+    lat = par.gather_latents([x[0, :4, :3].float()], w)
+    if r == 0:
+        assert len(lat) == w and all(abs(float(lat[i].sum()) - float(bench.make_inputs("cpu", wl, seed=i)[0][0, :4, :3].float().sum())) < 1e-6 for i in range(w))
+        print(json.dumps(rec))
+    par.barrier()
+    torch.distributed.destroy_process_group()
+    print("rank", r, "ok")
+""") % REPO
+
+
+def test_bench_driver_world8_gloo_stub_engine(tmp_path):
+    """bench.py's distributed driver (rank/seed mapping, barrier-bracketed timing, max over ranks, whole-job value, the
+    JSON record) with 8 ranks over gloo and a stub in place of the GPU engine: `torchrun --nproc-per-node 8 bench.py
+    --gpus 8` on RCCL is then the only link this container cannot exercise."""
+    import json
+    script = tmp_path / "bench_worker.py"
+    script.write_text(BENCH_WORKER)
+    port = _free_port()
+    procs = []
+    for r in range(8):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="8", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{o}"
+        assert f"rank {r} ok" in o
+    rec = json.loads([ln for ln in outs[0].splitlines() if ln.startswith("{")][0])
+    assert rec["n_gpus"] == 8 and rec["metric"] == "denoising-steps/sec" and rec["higher_is_better"] is True
+
+
+def test_cpulist_parser():
+    from visualcloze_amd import parallel as par
+    assert par.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    assert par.parse_cpulist("") == []
+
+
 def test_single_process_degenerates():
     from visualcloze_amd import parallel as par
     assert par.world() == 1 and par.rank() == 0

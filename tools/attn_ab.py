@@ -23,10 +23,12 @@ for L in (3968, 6656):
     vt = rnd(H, 128, Lpad)
     o = torch.empty(L, H * 128, dtype=torch.bfloat16, device=dev)
     stream = hip.cur_stream()
+    scr = hip.attention_scratch(dev)
     def run(l, var):
         # int vc_attention(qkv, ld, bstride, vt, out, ldo, out_bstride, kv_len, B, L, Lpad, H, variant, stream)
         rc = l.vc_attention(C.c_void_p(qkv.data_ptr()), C.c_int64(qkv.stride(0)), C.c_int64(0), C.c_void_p(vt.data_ptr()), C.c_void_p(o.data_ptr()),
-                            C.c_int64(o.stride(0)), C.c_int64(0), C.c_void_p(0), C.c_int32(1), C.c_int32(L), C.c_int32(Lpad), C.c_int32(H), C.c_int32(var), C.c_void_p(stream))
+                            C.c_int64(o.stride(0)), C.c_int64(0), C.c_void_p(0), C.c_int32(1), C.c_int32(L), C.c_int32(Lpad), C.c_int32(H), C.c_int32(var),
+                            C.c_void_p(scr.data_ptr()), C.c_int64(scr.numel()), C.c_void_p(stream))
         assert rc == 0, rc
     run(getlib("main"), 1); ref = o.clone()
     for v in variants:

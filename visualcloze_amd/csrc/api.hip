@@ -56,9 +56,11 @@ int vc_qknorm_rope_vt(void* qkv, int64_t ld, int64_t bstride, const void* q_scal
 }
 int vc_attention(const void* qkv, int64_t ld, int64_t bstride, const void* vt, void* out, int64_t ldo,
                  int64_t out_bstride, const int32_t* kv_len, int32_t B, int32_t L, int32_t Lpad, int32_t H,
-                 int32_t variant, void* stream) {
-  return vc_attention_launch(qkv, ld, bstride, vt, out, ldo, out_bstride, kv_len, B, L, Lpad, H, variant, S(stream), ERRBUF);
+                 int32_t variant, void* scratch, int64_t scratch_bytes, void* stream) {
+  return vc_attention_launch(qkv, ld, bstride, vt, out, ldo, out_bstride, kv_len, B, L, Lpad, H, variant, scratch, scratch_bytes,
+                             S(stream), ERRBUF);
 }
+int64_t vc_attention_scratch_bytes(void) { return vc_attention_scratch_bytes_impl(); }
 int vc_timestep_embedding(const float* t, const float* freqs, void* out_bf16, int32_t n, int32_t half,
                           int32_t round_t_bf16, void* stream) {
   return vc_temb_launch(t, freqs, out_bf16, n, half, round_t_bf16, S(stream), ERRBUF);

@@ -28,8 +28,19 @@ struct AttnArgs {
   const int32_t* kv_len;
   int64_t ld, bstride, ldo, out_bstride;
   int32_t B, L, Lpad, H, qblocks, items;
+  // tail split (variant +4): whole items for `full_rounds` rounds, then the remaining `tail_items` are cut into
+  // gridDim.x equal chunks of (item, KV tile) units; a chunk that covers only part of an item leaves (O, m, l)
+  // in `part` and attn_merge_kernel combines the pieces.  full_rounds < 0 = off.
+  int32_t full_rounds, tail_items, tail_units;
+  float* part;
   uint64_t* debug_ts;   // profiling builds only (-DVC_ATTN_TIMESTAMPS)
 };
+
+// one partial result: [wave 4][16 groups][lane 64][4] f32 accumulator fragments in register order, then [wave 4][lane 64]
+// (m, l) pairs; every store / load is 16 B (8 B) per lane, lane-contiguous
+constexpr int PART_O = 4 * 16 * 64 * 4;          // floats
+constexpr int PART_FLOATS = PART_O + 4 * 64 * 2;
+VC_DEV int chunk_begin(int c, int units, int chunks) { return (int)(((long)c * units) / chunks); }
 
 constexpr int KVB = 64;               // keys per tile
 constexpr int K_TILE = KVB * 256;     // bytes
@@ -53,7 +64,29 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs a) 
   // Persistent launch: gridDim.x = CUs x resident blocks; block p takes work items p, p + gridDim.x, ...  With 744
   // items on 512 slots (L=3968) the hardware dispatcher refills BOTH slots of the CUs that finish first (4 items on
   // some CUs, 2 on others); the static assignment gives every CU 3 (slot 0 runs a second item while slot 1 idles).
-  for (int item = blockIdx.x; item < a.items; item += gridDim.x) {
+  const int G = gridDim.x;
+  const int nkt_all = (a.L + KVB - 1) / KVB;                      // tail split runs without kv_len (uniform tile count)
+  const bool split = a.full_rounds >= 0;
+  const int chunk = split ? xcd_remap(blockIdx.x, G) : 0;         // neighbouring chunks (same head) share an XCD's L2
+  int tu = split ? chunk_begin(chunk, a.tail_units, G) : 0;
+  const int tu_end = split ? chunk_begin(chunk + 1, a.tail_units, G) : 0;
+  const int it_first = tu / nkt_all;
+  for (int seg = 0;; ++seg) {
+  int item, kt0 = 0, kt1 = -1, piece = -1;
+  if (!split) {
+    item = blockIdx.x + seg * G;
+    if (item >= a.items) break;
+  } else if (seg < a.full_rounds) {
+    item = blockIdx.x + seg * G;
+  } else {
+    if (tu >= tu_end) break;
+    const int it = tu / nkt_all;
+    kt0 = tu - it * nkt_all;
+    kt1 = min(nkt_all, kt0 + (tu_end - tu));
+    tu += kt1 - kt0;
+    item = a.full_rounds * G + it;
+    if (kt1 - kt0 != nkt_all) piece = chunk * 2 + (it - it_first);
+  }
   int id = xcd_remap(item, a.items);
   const int qb = id % a.qblocks;
   const int bh = id / a.qblocks;
@@ -104,7 +137,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs a) 
   };
 
   const int nkt = (kvlen + KVB - 1) / KVB;
-  stage(0, 0);
+  if (kt1 < 0) kt1 = nkt;
+  stage(0, kt0);
 
   // ---- Q fragments (B operand): lane = query lq, d = t*16 + hh*8 .. +7 ----
   const int q0 = qb * (NW * 32) + wave * 32;
@@ -144,14 +178,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs a) 
 #endif
   __syncthreads();
 
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int cur = kt & 1;
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int cur = (kt - kt0) & 1;
     stamp();
     // Tile kt+1's LDS-DMA pieces (8 per wave with 4 waves, 4 with 8) go out one behind every DMA_EVERY-th QK^T MFMA: an
     // LDS-DMA wave-instruction holds the issue slot for ~75 cycles, and issued back to back at the top of the tile
     // (600 cycles without an MFMA from this wave) they cost 5 % of the kernel.  The last tile re-stages itself into the idle buffer so the body stays free
     // of branches (sched_group_barrier pins issue order only inside one basic block).
-    const int ktn = min(kt + 1, nkt - 1);
+    const int ktn = min(kt + 1, kt1 - 1);
     const char* base = smem + cur * STAGE;
 
     // S^T = K . Q^T.  Fragment reads run one 8-deep batch AHEAD of the MFMAs that consume them (rotating register
@@ -261,7 +295,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs a) 
   // ---- epilogue ----
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const int q = q0 + lq;
-  if (q < L) {
+  if (piece >= 0) {          // part of an item's keys only: un-normalised O^T fragments + (m, l), merged by attn_merge_kernel
+    float* pp = a.part + (long)piece * PART_FLOATS;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 w = {o[dt][g * 4 + 0], o[dt][g * 4 + 1], o[dt][g * 4 + 2], o[dt][g * 4 + 3]};
+        *(f32x4*)(pp + ((wave * 16 + dt * 4 + g) * 64 + lane) * 4) = w;
+      }
+    f32x2 ml = {m_run, l_tot};
+    *(f32x2*)(pp + PART_O + (wave * 64 + lane) * 2) = ml;
+  } else if (q < L) {
     const float inv = (q < kvlen) ? 1.0f / l_tot : 0.0f;  // padded query rows -> 0 (pad_input, math.py:96)
     bf16_t* orow = a.out + (long)b * a.out_bstride + (long)q * a.ldo + h * 128;
 #pragma unroll
@@ -277,14 +322,75 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs a) 
   }  // work items
 }
 
+// Combines the pieces of the tail items that attn_fwd_kernel<4> cut along the keys: O = sum_p 2^(m_p - m) O_p,
+// l = sum_p 2^(m_p - m) l_p, out = bf16(O / l).  One workgroup per tail item, thread layout = the writer's.
+__global__ __launch_bounds__(256) void attn_merge_kernel(const AttnArgs a, int G) {
+  const int it = blockIdx.x;
+  const int nkt = (a.L + KVB - 1) / KVB;
+  const int u0 = it * nkt, u1 = u0 + nkt;
+  int c = (int)(((long)u0 * G) / a.tail_units);
+  while (c > 0 && chunk_begin(c, a.tail_units, G) > u0) --c;
+  while (c + 1 < G && chunk_begin(c + 1, a.tail_units, G) <= u0) ++c;
+  if (chunk_begin(c + 1, a.tail_units, G) >= u1) return;        // the whole item ran inside one chunk: already written
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane & 31, hh = lane >> 5;
+  float m = -INFINITY;
+  for (int cc = c; cc < G && chunk_begin(cc, a.tail_units, G) < u1; ++cc) {
+    if (chunk_begin(cc + 1, a.tail_units, G) == chunk_begin(cc, a.tail_units, G)) continue;   // empty chunk (fewer units than blocks)
+    const int piece = cc * 2 + (it - chunk_begin(cc, a.tail_units, G) / nkt);
+    m = fmaxf(m, a.part[(long)piece * PART_FLOATS + PART_O + (wave * 64 + lane) * 2]);
+  }
+  f32x4 acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float l = 0.f;
+  for (int cc = c; cc < G && chunk_begin(cc, a.tail_units, G) < u1; ++cc) {
+    if (chunk_begin(cc + 1, a.tail_units, G) == chunk_begin(cc, a.tail_units, G)) continue;
+    const int piece = cc * 2 + (it - chunk_begin(cc, a.tail_units, G) / nkt);
+    const float* pp = a.part + (long)piece * PART_FLOATS;
+    const f32x2 ml = *(const f32x2*)(pp + PART_O + (wave * 64 + lane) * 2);
+    const float sc = __builtin_amdgcn_exp2f(ml[0] - m);
+    l += ml[1] * sc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] += *(const f32x4*)(pp + ((wave * 16 + i) * 64 + lane) * 4) * sc;
+  }
+  const int item = a.full_rounds * G + it;
+  const int id = xcd_remap(item, a.items);
+  const int qb = id % a.qblocks, bh = id / a.qblocks;
+  const int h = bh % a.H, b = bh / a.H;
+  const int q = qb * 128 + wave * 32 + lq;
+  if (q < a.L) {
+    const float inv = 1.0f / l;
+    bf16_t* orow = a.out + (long)b * a.out_bstride + (long)q * a.ldo + h * 128;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      u32x2 w;
+      w[0] = pack2bf(acc[i][0] * inv, acc[i][1] * inv);
+      w[1] = pack2bf(acc[i][2] * inv, acc[i][3] * inv);
+      *(u32x2*)(orow + (i >> 2) * 32 + (i & 3) * 8 + hh * 4) = w;
+    }
+  }
+}
+
 }  // namespace
 
 static uint64_t* g_attn_debug_ts = nullptr;
 extern "C" void vc_debug_set_attn_ts(void* p) { g_attn_debug_ts = (uint64_t*)p; }   // tools/ only; not in the ABI header
 
+static int attn_cu_count() {
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+  }
+  return n_cu;
+}
+
+int64_t vc_attention_scratch_bytes_impl() { return (int64_t)2 * attn_cu_count() * 2 * PART_FLOATS * (int64_t)sizeof(float); }
+
 int vc_attention_launch(const void* qkv, int64_t ld, int64_t bstride, const void* vt, void* out, int64_t ldo,
                         int64_t out_bstride, const int32_t* kv_len, int32_t B, int32_t L, int32_t Lpad,
-                        int32_t H, int32_t variant, hipStream_t s, char* err, int errlen) {
+                        int32_t H, int32_t variant, void* scratch, int64_t scratch_bytes, hipStream_t s, char* err, int errlen) {
   if (!qkv || !vt || !out) { snprintf(err, errlen, "attention: null pointer"); return VC_ERR_ARG; }
   if (B <= 0 || L <= 0 || H <= 0) { snprintf(err, errlen, "attention: empty problem B=%d L=%d H=%d", B, L, H); return VC_ERR_ARG; }
   if (Lpad < L || Lpad % KVB) { snprintf(err, errlen, "attention: Lpad=%d must be a multiple of %d and >= L=%d", Lpad, KVB, L); return VC_ERR_ARG; }
@@ -296,21 +402,32 @@ int vc_attention_launch(const void* qkv, int64_t ld, int64_t bstride, const void
   a.ld = ld; a.bstride = bstride; a.ldo = ldo; a.out_bstride = out_bstride;
   a.B = B; a.L = L; a.Lpad = Lpad; a.H = H;
   a.debug_ts = g_attn_debug_ts;
+  a.full_rounds = -1; a.tail_items = 0; a.tail_units = 0; a.part = (float*)scratch;
   const int lds = 2 * STAGE;
   hipError_t e;
   const bool persist = (variant & 2) != 0;   // +2: persistent grid with static item assignment (variants 2, 3)
+  const bool tail_split = (variant & 4) != 0; // +4 (with 1 and 2 = variant 7): tail items cut along the keys
+  if (tail_split && (variant & 3) != 3) { snprintf(err, errlen, "attention: the tail split (+4) exists for variant 3 only"); return VC_ERR_ARG; }
   variant &= 1;
-  static int n_cu = 0;
-  if (persist && n_cu == 0) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
-  }
+  const int n_cu = attn_cu_count();
   if (variant == 1) {  // 4 waves x 32 queries
     a.qblocks = (L + 127) / 128;
     static bool done = false;
     if (!done) { e = hipFuncSetAttribute((const void*)attn_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) goto fail; done = true; }
     a.items = a.qblocks * H * B;
-    hipLaunchKernelGGL(attn_fwd_kernel<4>, dim3(std::min(a.items, persist ? 2 * n_cu : a.items)), dim3(256), lds, s, a);
+    const int G = 2 * n_cu;
+    const int nkt = (L + KVB - 1) / KVB;
+    const int rounds = a.items / G, tail = a.items - rounds * G;
+    // cut the tail only where it shortens the critical path by more than the merge costs (~3 tiles): plain = one more
+    // round of nkt tiles for the blocks that draw a tail item, split = ceil(tail * nkt / G) tiles for every block
+    const int split_tiles = (int)(((long)tail * nkt + G - 1) / G);
+    if (tail_split && !kv_len && tail > 0 && scratch && scratch_bytes >= vc_attention_scratch_bytes_impl() && split_tiles + 3 < nkt) {
+      a.full_rounds = rounds; a.tail_items = tail; a.tail_units = tail * nkt;
+      hipLaunchKernelGGL(attn_fwd_kernel<4>, dim3(G), dim3(256), lds, s, a);
+      hipLaunchKernelGGL(attn_merge_kernel, dim3(tail), dim3(256), 0, s, a, G);
+    } else {
+      hipLaunchKernelGGL(attn_fwd_kernel<4>, dim3(std::min(a.items, persist ? G : a.items)), dim3(256), lds, s, a);
+    }
   } else {  // 8 waves x 32 queries
     a.qblocks = (L + 255) / 256;
     static bool done8 = false;

@@ -91,7 +91,8 @@ class FluxEngine:
         self.H = geom.num_heads
         self.mlp = int(geom.hidden_size * geom.mlp_ratio)
         self._ws: Dict[tuple, Workspace] = {}
-        self.attn_variant = 3      # 4 waves x 32 queries, persistent grid (hip.attention variants: +2 = persistent)
+        self.attn_variant = 7      # 4 waves x 32 queries, persistent grid, tail items cut along the keys (hip.attention)
+        self.attn_scratch = hip.attention_scratch(dev)
         self.tile_cfg = 0
         self.stream = torch.cuda.Stream(device=dev)   # capture needs a non-default stream
 
@@ -230,7 +231,8 @@ class FluxEngine:
         ws, s = c.ws, c.s
         q1, k1, q2, k2 = scales
         hip.qknorm_rope_vt(ws.QKV, q1, k1, ws.ROPE, ws.VT, ws.L, self.H, stream=s, q_scale2=q2, k_scale2=k2, split=split, B=ws.B)
-        hip.attention(ws.QKV, ws.VT, c.ATT, ws.L, self.H, kv_len=c.kvl, variant=self.attn_variant, stream=s, B=ws.B)
+        hip.attention(ws.QKV, ws.VT, c.ATT, ws.L, self.H, kv_len=c.kvl, variant=self.attn_variant, stream=s, B=ws.B,
+                      scratch=self.attn_scratch)
 
     def double_block(self, c, i: int) -> None:
         """DoubleStreamBlock i (layers.py:158-196) on ws.XI / ws.XT, in place."""

@@ -62,7 +62,8 @@ SYMBOLS = {
     "vc_ln_modulate": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp]),
     "vc_ln_modulate2": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i64, _vp]),
     "vc_qknorm_rope_vt": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp]),
-    "vc_attention": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "vc_attention": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
+    "vc_attention_scratch_bytes": (_i64, []),
     "vc_timestep_embedding": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "vc_silu": (C.c_int, [_vp, _vp, _i64, _vp]),
     "vc_add3": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
@@ -258,12 +259,29 @@ def qknorm_rope_vt(qkv, q_scale, k_scale, rope, vt, L, H, stream=None, q_scale2=
                                    stream if stream is not None else cur_stream()), "vc_qknorm_rope_vt")
 
 
-def attention(qkv, vt, out, L, H, kv_len=None, variant=0, stream=None, B=1):
-    """out: [B*L, >=H*128] rows (B L (H D)), sample-major like qkv; kv_len: optional int32 device tensor [B]."""
+_attn_scratch = {}
+
+
+def attention_scratch(device) -> torch.Tensor:
+    """The partial-result buffer of the tail-split attention (variant 7), one per device; launches on one stream
+    serialise their use of it."""
+    key = str(device)
+    if key not in _attn_scratch:
+        _attn_scratch[key] = torch.empty(lib().vc_attention_scratch_bytes(), dtype=torch.uint8, device=device)
+    return _attn_scratch[key]
+
+
+def attention(qkv, vt, out, L, H, kv_len=None, variant=0, stream=None, B=1, scratch=None):
+    """out: [B*L, >=H*128] rows (B L (H D)), sample-major like qkv; kv_len: optional int32 device tensor [B];
+    scratch: uint8 device buffer of >= vc_attention_scratch_bytes() for variant 7 (taken from attention_scratch()
+    when omitted)."""
     _bf16(qkv, "qkv"); _bf16(vt, "vt"); _bf16(out, "out")
     Lpad = vt.shape[-1]
+    if scratch is None and variant & 4:
+        scratch = attention_scratch(qkv.device)
     _check(lib().vc_attention(qkv.data_ptr(), qkv.stride(0), L * qkv.stride(0), vt.data_ptr(), out.data_ptr(),
                               out.stride(0), L * out.stride(0), _p(kv_len), B, L, Lpad, H, variant,
+                              _p(scratch), scratch.numel() if scratch is not None else 0,
                               stream if stream is not None else cur_stream()), "vc_attention")
 
 

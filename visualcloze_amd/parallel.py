@@ -32,6 +32,39 @@ def init_distributed(backend: Optional[str] = None, device: Optional[torch.devic
     dist.init_process_group(backend, **kw)
 
 
+def pin_to_gpu_numa(local_rank: int) -> Optional[int]:
+    """Bind this process (and the threads it starts) to the CPUs of the NUMA node its GPU hangs off: eight ranks that
+    launch one graph per step each must not migrate across sockets or share the cores next to another rank's GPU
+    (SURVEY.md §8e hazard list).  PCI address from the device properties -> /sys/bus/pci/devices/<addr>/numa_node ->
+    /sys/devices/system/node/node<N>/cpulist.  Returns the node, or None when the platform does not say (single-node
+    hosts report -1) - then nothing is changed."""
+    try:
+        pr = torch.cuda.get_device_properties(local_rank)
+        addr = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        node = int(open(f"/sys/bus/pci/devices/{addr}/numa_node").read().strip())
+        if node < 0:
+            return None
+        cpus = parse_cpulist(open(f"/sys/devices/system/node/node{node}/cpulist").read())
+        allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))
+        if not allowed:
+            return None
+        os.sched_setaffinity(0, allowed)
+        return node
+    except Exception:
+        return None
+
+
+def parse_cpulist(text: str) -> List[int]:
+    """"0-3,8,10-11" -> [0,1,2,3,8,10,11] (the kernel's cpulist format)."""
+    out: List[int] = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
 def world() -> int:
     return dist.get_world_size() if dist.is_initialized() else 1
 
@@ -101,14 +134,34 @@ def gather_latents(local: Sequence[torch.Tensor], n_samples: int) -> Optional[Li
     """Collect the final latents (0.44 MB per sample at cfg 2) on rank 0 in global sample order."""
     if world() == 1:
         return list(local)
-    objs = [None] * world() if rank() == 0 else None
-    dist.gather_object([t.cpu() for t in local], objs, dst=0)
-    if rank() != 0:
+    # one tensor collective, no pickling: every rank contributes ceil(n / world) slots of the common latent shape
+    # (ranks with one sample fewer pad with zeros); NCCL/RCCL gathers device tensors, gloo host tensors
+    w, r = world(), rank()
+    slots = (n_samples + w - 1) // w
+    on_gpu = dist.get_backend() == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+    ref = local[0] if local else None
+    dtypes = [torch.float32, torch.bfloat16, torch.float16, torch.float64]
+    meta = torch.zeros(10, dtype=torch.int64)
+    if ref is not None:
+        meta[0] = ref.dim()
+        meta[1:1 + ref.dim()] = torch.tensor(ref.shape)
+        meta[9] = dtypes.index(ref.dtype)
+    meta = meta.to(dev)
+    dist.all_reduce(meta, op=dist.ReduceOp.MAX)         # ranks without a sample learn the shape
+    shp = [int(v) for v in meta[1:1 + int(meta[0])].tolist()]
+    dtype = dtypes[int(meta[9])]
+    buf = torch.zeros(slots, *shp, dtype=dtype, device=dev)
+    for i, t in enumerate(local):
+        buf[i].copy_(t)
+    parts = [torch.empty_like(buf) for _ in range(w)] if r == 0 else None
+    dist.gather(buf, parts, dst=0)
+    if r != 0:
         return None
     out: List[Optional[torch.Tensor]] = [None] * n_samples
-    for r, lst in enumerate(objs):
-        for k, t in zip(shard_indices(n_samples, r, world()), lst):
-            out[k] = t
+    for rr in range(w):
+        for i, k in enumerate(shard_indices(n_samples, rr, w)):
+            out[k] = parts[rr][i].cpu()
     return out  # type: ignore[return-value]
 
 

@@ -122,6 +122,14 @@ int vc_timestep_embedding(const float* t, const float* freqs, void* out_bf16, in
                           int32_t round_t_bf16, void* stream);
 /* elementwise helpers on bf16 vectors */
 int vc_silu(const void* x, void* y, int64_t n, void* stream);
+/* the two epilogues of vc_gemm as stand-alone passes, for the un-merged LoRA execution mode (LinearLora.forward,
+ * models/modules/lora.py:92-98: base_out + lora_B(lora_A(x)) * scale is only complete after a second GEMM):
+ * act2d: y[m,n] = bf16(act(x[m,n])) on row views, act 0 = GELU(tanh) (layers.py:141-145,229), 1 = SiLU (layers.py:55-60);
+ * gate_residual: out[m,n] = bf16(res[m,n] + bf16(gate[n] * y[m,n])), gate advanced by *step_ptr * gate_step_stride
+ * like VcGemmArgs (layers.py:190-195,245). */
+int vc_act2d(const void* x, int64_t ldx, void* y, int64_t ldy, int32_t rows, int32_t cols, int32_t act, void* stream);
+int vc_gate_residual(const void* y, int64_t ldy, const void* res, int64_t ldres, const void* gate, void* out, int64_t ldo,
+                     int32_t rows, int32_t cols, const int32_t* step_ptr, int64_t gate_step_stride, void* stream);
 /* y[i] = bf16(bf16(a[i] + b[i % bn]) + c[i % cn]); c may be NULL (model.py:102-107: vec = time + guidance + vector) */
 int vc_add3(const void* a, const void* b, const void* c, void* y, int64_t n, int64_t bn, int64_t cn, void* stream);
 /* device-to-device copy on `stream` (captured as a memcpy node): restores the step-invariant txt rows */

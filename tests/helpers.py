@@ -53,3 +53,13 @@ def smoke() -> None:
     err = rel_l2(got, want)
     print(f"smoke: tiny Flux.forward on {torch.cuda.get_device_name(0)}: rel-L2 vs bf16 oracle = {err:.3e}")
     assert torch.isfinite(got.float()).all() and err < 2e-2, f"HIP path deviates from the oracle: {err}"
+
+
+def parity_log(line: str) -> None:
+    """Print a measured deviation and, when VC_PARITY_LOG names a file, append it there (the numbers DESIGN.md quotes
+    come from these lines; pytest swallows stdout of passing tests)."""
+    print("\n" + line)
+    path = os.environ.get("VC_PARITY_LOG")
+    if path:
+        with open(path, "a") as f:
+            f.write(line + "\n")

@@ -119,7 +119,8 @@ def test_full_width_one_plus_one_blocks_vs_oracle(small_model, geom):
     want_bf16, want_fp32 = _oracle_pair(sd, O.FluxGeometry(depth=1, depth_single_blocks=1), inp, t)
     floor = rel_l2(want_bf16, want_fp32)          # what bf16 execution costs the oracle itself at this size
     e16, e32 = rel_l2(got, want_bf16), rel_l2(got, want_fp32)
-    print(f"\n[{geom}] L={T + inp['x'].shape[1]}: HIP vs bf16 oracle {e16:.3e}, vs fp32 oracle {e32:.3e}, oracle bf16-vs-fp32 floor {floor:.3e}")
+    from tests.helpers import parity_log
+    parity_log(f"[1+1 blocks, {geom}] L={T + inp['x'].shape[1]}: HIP vs bf16 oracle {e16:.3e}, vs fp32 oracle {e32:.3e}, oracle bf16-vs-fp32 floor {floor:.3e}")
     assert e16 < 1.5e-2
     assert e32 < max(3e-2, 4 * floor)
 
@@ -239,8 +240,9 @@ def test_full_depth_19_38_vs_oracle():
     want_bf16, want_fp32 = _oracle_pair(sd, O.FluxGeometry(), inp, t)
     floor = rel_l2(want_bf16, want_fp32)
     e16, e32 = rel_l2(got, want_bf16), rel_l2(got, want_fp32)
-    print(f"\n[full depth 19+38, cfg2] HIP vs bf16-merged oracle {e16:.3e}, vs fp32-ref oracle {e32:.3e}, "
-          f"oracle bf16-vs-fp32 floor {floor:.3e}  (oracle time {time.time() - t0:.0f} s on {torch.get_num_threads()} threads)")
+    from tests.helpers import parity_log
+    parity_log(f"[full depth 19+38, cfg2] HIP vs bf16-merged oracle {e16:.3e}, vs fp32-ref oracle {e32:.3e}, "
+               f"oracle bf16-vs-fp32 floor {floor:.3e}  (oracle time {time.time() - t0:.0f} s on {torch.get_num_threads()} threads)")
     assert torch.isfinite(got).all()
     assert e16 < 1.5 * floor
     assert e32 < 2.0 * floor

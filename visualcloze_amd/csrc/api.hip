@@ -66,6 +66,13 @@ int vc_timestep_embedding(const float* t, const float* freqs, void* out_bf16, in
   return vc_temb_launch(t, freqs, out_bf16, n, half, round_t_bf16, S(stream), ERRBUF);
 }
 int vc_silu(const void* x, void* y, int64_t n, void* stream) { return vc_silu_launch(x, y, n, S(stream), ERRBUF); }
+int vc_act2d(const void* x, int64_t ldx, void* y, int64_t ldy, int32_t rows, int32_t cols, int32_t act, void* stream) {
+  return vc_act2d_launch(x, ldx, y, ldy, rows, cols, act, S(stream), ERRBUF);
+}
+int vc_gate_residual(const void* y, int64_t ldy, const void* res, int64_t ldres, const void* gate, void* out, int64_t ldo,
+                     int32_t rows, int32_t cols, const int32_t* step_ptr, int64_t gate_step_stride, void* stream) {
+  return vc_gate_residual_launch(y, ldy, res, ldres, gate, out, ldo, rows, cols, step_ptr, gate_step_stride, S(stream), ERRBUF);
+}
 int vc_add3(const void* a, const void* b, const void* c, void* y, int64_t n, int64_t bn, int64_t cn, void* stream) {
   return vc_add3_launch(a, b, c, y, n, bn, cn, S(stream), ERRBUF);
 }

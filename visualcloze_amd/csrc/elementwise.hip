@@ -63,6 +63,27 @@ __global__ void sdedit_mix_kernel(const bf16_t* __restrict__ noise, const bf16_t
   out[i] = f2bf(rbf(bf2f(noise[i]) * (1.0f - s)) + rbf(bf2f(latent[i]) * s));
 }
 
+// y[m, n] = bf16(act(x[m, n])) on row views: act 0 = GELU(tanh), 1 = SiLU
+__global__ void act2d_kernel(const bf16_t* __restrict__ x, long ldx, bf16_t* __restrict__ y, long ldy, int rows, int cols, int act) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)rows * cols) return;
+  const int m = (int)(i / cols), n = (int)(i % cols);
+  const float v = bf2f(x[m * ldx + n]);
+  y[m * ldy + n] = f2bf(act == 0 ? gelu_tanh(v) : silu_f(v));
+}
+
+// out[m, n] = bf16(res[m, n] + bf16(gate[n] * y[m, n])): the gated residual of layers.py:190-195,245 as its own pass
+// (un-merged LoRA mode, where y = base + lora is only complete after a second GEMM)
+__global__ void gate_residual_kernel(const bf16_t* __restrict__ y, long ldy, const bf16_t* __restrict__ res, long ldres,
+                                     const bf16_t* __restrict__ gate, bf16_t* __restrict__ out, long ldo, int rows, int cols,
+                                     const int* __restrict__ step_ptr, long gate_step_stride) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)rows * cols) return;
+  const int m = (int)(i / cols), n = (int)(i % cols);
+  const bf16_t* g = gate + (step_ptr ? (long)(*step_ptr) * gate_step_stride : 0);
+  out[m * ldo + n] = f2bf(bf2f(res[m * ldres + n]) + rbf(bf2f(g[n]) * bf2f(y[m * ldy + n])));
+}
+
 __global__ void step_advance_kernel(int* step_ptr) { if (threadIdx.x == 0 && blockIdx.x == 0) *step_ptr += 1; }
 
 }  // namespace
@@ -83,6 +104,24 @@ int vc_silu_launch(const void* x, void* y, int64_t n, hipStream_t s, char* err, 
   if (!x || !y || n <= 0) { snprintf(err, errlen, "silu: bad args"); return VC_ERR_ARG; }
   hipLaunchKernelGGL(silu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, (long)n);
   VC_CHECK_LAUNCH("silu");
+}
+int vc_act2d_launch(const void* x, int64_t ldx, void* y, int64_t ldy, int32_t rows, int32_t cols, int32_t act, hipStream_t s,
+                    char* err, int errlen) {
+  if (!x || !y || rows <= 0 || cols <= 0 || act < 0 || act > 1) { snprintf(err, errlen, "act2d: bad args"); return VC_ERR_ARG; }
+  const long n = (long)rows * cols;
+  hipLaunchKernelGGL(act2d_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16_t*)x, (long)ldx, (bf16_t*)y,
+                     (long)ldy, rows, cols, act);
+  VC_CHECK_LAUNCH("act2d");
+}
+int vc_gate_residual_launch(const void* y, int64_t ldy, const void* res, int64_t ldres, const void* gate, void* out, int64_t ldo,
+                            int32_t rows, int32_t cols, const int32_t* step_ptr, int64_t gate_step_stride, hipStream_t s,
+                            char* err, int errlen) {
+  if (!y || !res || !gate || !out || rows <= 0 || cols <= 0) { snprintf(err, errlen, "gate_residual: bad args"); return VC_ERR_ARG; }
+  const long n = (long)rows * cols;
+  hipLaunchKernelGGL(gate_residual_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16_t*)y, (long)ldy,
+                     (const bf16_t*)res, (long)ldres, (const bf16_t*)gate, (bf16_t*)out, (long)ldo, rows, cols, step_ptr,
+                     (long)gate_step_stride);
+  VC_CHECK_LAUNCH("gate_residual");
 }
 int vc_add3_launch(const void* a, const void* b, const void* c, void* y, int64_t n, int64_t bn, int64_t cn, hipStream_t s, char* err, int errlen) {
   if (!a || !b || !y || n <= 0 || bn <= 0 || (c && cn <= 0)) { snprintf(err, errlen, "add3: bad args"); return VC_ERR_ARG; }

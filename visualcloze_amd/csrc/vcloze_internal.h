@@ -19,6 +19,11 @@ int vc_qknorm_rope_vt_launch(void* qkv, int64_t ld, int64_t bstride, const void*
                              int32_t H, hipStream_t s, char* err, int errlen);
 int vc_temb_launch(const float* t, const float* freqs, void* out, int n, int half, int round_t, hipStream_t s, char* err, int errlen);
 int vc_silu_launch(const void* x, void* y, int64_t n, hipStream_t s, char* err, int errlen);
+int vc_act2d_launch(const void* x, int64_t ldx, void* y, int64_t ldy, int32_t rows, int32_t cols, int32_t act, hipStream_t s,
+                    char* err, int errlen);
+int vc_gate_residual_launch(const void* y, int64_t ldy, const void* res, int64_t ldres, const void* gate, void* out, int64_t ldo,
+                            int32_t rows, int32_t cols, const int32_t* step_ptr, int64_t gate_step_stride, hipStream_t s,
+                            char* err, int errlen);
 int vc_add3_launch(const void* a, const void* b, const void* c, void* y, int64_t n, int64_t bn, int64_t cn, hipStream_t s, char* err, int errlen);
 int vc_concat_cols_launch(const void* x, int cx, const void* cond, int cc, void* out, int64_t rows, hipStream_t s, char* err, int errlen);
 int vc_euler_launch(void* x, const void* v, const float* dts, const int32_t* step_ptr, int64_t n, hipStream_t s, char* err, int errlen);

@@ -32,6 +32,28 @@ from . import hip
 
 
 @dataclass
+class RefLinear:
+    """One Linear of the UN-MERGED LoRA execution mode (LinearLora.forward, models/modules/lora.py:92-98):
+    y = bf16(x W^T + b);  h = bf16(x A^T);  u = bf16(h B^T + b_B);  out = bf16(y + bf16(u * scale)).
+    A / B are zero-padded along the rank to the GEMM's K granularity (64)."""
+    w: torch.Tensor
+    b: Optional[torch.Tensor]
+    A: Optional[torch.Tensor]          # [rK, in]   (None: no LoRA pair on this Linear)
+    B: Optional[torch.Tensor]          # [out, rK]
+    bB: Optional[torch.Tensor]
+    scale: Optional[torch.Tensor]      # [out] bf16, every element = lora scale
+
+
+@dataclass
+class LinCall:
+    """A Linear to run: module path + operand views (+ the batch-strided row description of hip.make_problem)."""
+    name: str
+    a: torch.Tensor
+    out: torch.Tensor
+    kw: dict
+
+
+@dataclass
 class PreparedWeights:
     """bf16, contiguous, LoRA-merged device tensors keyed by reference module path."""
     w: Dict[str, torch.Tensor]
@@ -41,6 +63,7 @@ class PreparedWeights:
     mod_off: Dict[str, int]      # module path -> column offset in MOD
     n_mod: int
     temb_freqs: torch.Tensor     # [128] f32
+    ref: Optional[Dict[str, RefLinear]] = None    # lora_mode="ref": un-merged factors of every Linear (incl. the modulation ones)
 
 
 class Workspace:
@@ -95,6 +118,9 @@ class FluxEngine:
         self.attn_scratch = hip.attention_scratch(dev)
         self.tile_cfg = 0
         self.stream = torch.cuda.Stream(device=dev)   # capture needs a non-default stream
+        self._ref_scratch: Dict[tuple, torch.Tensor] = {}
+        if weights.ref is not None:
+            self.MAX_BATCH = 1     # the un-merged mode addresses plain rows (no batch-strided views)
 
     # ------------------------------------------------------------------ helpers
     def workspace(self, T: int, N: int, steps: int, B: int = 1) -> Workspace:
@@ -108,11 +134,52 @@ class FluxEngine:
             self._ws[key] = ws
         return ws
 
-    def _gemm(self, probs, epi=hip.EPI_BIAS, step_ptr=None, gate_step_stride=0, s=None):
+    def _gemm(self, calls, epi=hip.EPI_BIAS, step_ptr=None, gate_step_stride=0, s=None):
+        """Run one or several Linears (grouped into ONE launch in the merged mode) with the fused epilogue `epi`."""
+        if isinstance(calls, LinCall):
+            calls = [calls]
+        if self.W.ref is not None:
+            for c in calls:
+                self._linear_ref(c, epi, step_ptr, gate_step_stride, s)
+            return
+        probs = [hip.make_problem(c.a, self.W.w[c.name], self.W.b[c.name], c.out, **c.kw) for c in calls]
         hip.gemm(probs, epi=epi, tile_cfg=self.tile_cfg, step_ptr=step_ptr, gate_step_stride=gate_step_stride, stream=s)
 
-    def _prob(self, name, a, out, **kw):
-        return hip.make_problem(a, self.W.w[name], self.W.b[name], out, **kw)
+    def _prob(self, name, a, out, **kw) -> LinCall:
+        return LinCall(name, a, out, kw)
+
+    def _scratch(self, tag, rows, cols):
+        key = (tag, rows, cols)
+        t = self._ref_scratch.get(key)
+        if t is None:
+            t = torch.empty(rows, cols, dtype=torch.bfloat16, device=self.dev)
+            self._ref_scratch[key] = t
+        return t
+
+    def _linear_ref(self, c: LinCall, epi, step_ptr, gate_step_stride, s) -> None:
+        """LinearLora.forward with the reference's three roundings (lora.py:92-98), then the epilogue as its own pass.
+        A parity / debugging mode (3 GEMMs + 1 pass per Linear, +8 % FLOPs); one sample per launch sequence."""
+        R = self.W.ref[c.name]
+        kw = c.kw
+        M = kw.get("M") or c.a.shape[0]
+        a, out = c.a[:M], c.out[:M]
+        N = R.w.shape[0]
+        plain = epi == hip.EPI_BIAS
+        y = out if (plain and R.A is None) else self._scratch("y", M, N)
+        hip.gemm(hip.make_problem(a, R.w, R.b, y), tile_cfg=self.tile_cfg, stream=s)                  # base_out
+        if R.A is not None:
+            h = self._scratch("h", M, R.A.shape[0])
+            hip.gemm(hip.make_problem(a, R.A, None, h), tile_cfg=self.tile_cfg, stream=s)              # lora_A(x)
+            y2 = out if plain else self._scratch("y2", M, N)
+            hip.gemm(hip.make_problem(h, R.B, R.bB, y2, res=y, gate=R.scale), epi=hip.EPI_GATE_RES,    # base_out + lora_B(.) * scale
+                     tile_cfg=self.tile_cfg, stream=s)
+            y = y2
+        if epi == hip.EPI_GELU:
+            hip.act2d(y, out, "gelu", stream=s)
+        elif epi == hip.EPI_SILU:
+            hip.act2d(y, out, "silu", stream=s)
+        elif epi == hip.EPI_GATE_RES:
+            hip.gate_residual(y, kw["res"][:M], kw["gate"], out, step_ptr=step_ptr, gate_step_stride=gate_step_stride, stream=s)
 
     def _lin(self, name, a, out, epi=hip.EPI_BIAS, s=None, **kw):
         self._gemm(self._prob(name, a, out, **kw), epi=epi, s=s)
@@ -187,7 +254,12 @@ class FluxEngine:
         else:
             hip.add3(ws.TVEC, ws.YVEC, None, out=ws.VEC, stream=s)
         hip.silu(ws.VEC, out=ws.H1, stream=s)
-        self._gemm(hip.make_problem(ws.H1, W.mod_w, W.mod_b, ws.MOD), s=s)
+        if W.ref is None:
+            hip.gemm(hip.make_problem(ws.H1, W.mod_w, W.mod_b, ws.MOD), tile_cfg=self.tile_cfg, stream=s)
+        else:                          # un-merged mode: every modulation Linear on its own column range of MOD
+            for name, off in W.mod_off.items():
+                n = W.ref[name].w.shape[0]
+                self._gemm(self._prob(name, ws.H1, ws.MOD[:, off:off + n]), s=s)
 
     # ------------------------------------------------------------------ one evaluation
     class _Ctx:

@@ -66,6 +66,8 @@ SYMBOLS = {
     "vc_attention_scratch_bytes": (_i64, []),
     "vc_timestep_embedding": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "vc_silu": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "vc_act2d": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "vc_gate_residual": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp]),
     "vc_add3": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     "vc_copy": (C.c_int, [_vp, _vp, _i64, _vp]),
     "vc_concat_cols": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i64, _vp]),
@@ -296,6 +298,28 @@ def silu(x, out=None, stream=None):
     out = torch.empty_like(x) if out is None else out
     _check(lib().vc_silu(x.data_ptr(), out.data_ptr(), x.numel(), stream if stream is not None else cur_stream()), "vc_silu")
     return out
+
+
+def act2d(x, out, act, stream=None):
+    """out = bf16(act(x)) on 2-D row views; act: "gelu" (tanh) or "silu"."""
+    for t in (x, out):
+        _bf16(t, "act2d")
+        if t.dim() != 2 or t.stride(1) != 1 or t.shape != x.shape:
+            raise VclozeHipError("act2d: 2-D views of one shape with contiguous rows expected")
+    _check(lib().vc_act2d(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), x.shape[0], x.shape[1],
+                          {"gelu": 0, "silu": 1}[act], stream if stream is not None else cur_stream()), "vc_act2d")
+    return out
+
+
+def gate_residual(y, res, gate, out, step_ptr=None, gate_step_stride=0, stream=None):
+    """out = bf16(res + bf16(gate * y)) on 2-D row views (last dim contiguous); out may alias res."""
+    for t in (y, res, out):
+        _bf16(t, "gate_residual")
+        if t.dim() != 2 or t.stride(1) != 1 or t.shape != y.shape:
+            raise VclozeHipError("gate_residual: 2-D views of one shape with contiguous rows expected")
+    _check(lib().vc_gate_residual(y.data_ptr(), y.stride(0), res.data_ptr(), res.stride(0), gate.data_ptr(), out.data_ptr(),
+                                  out.stride(0), y.shape[0], y.shape[1], _p(step_ptr), gate_step_stride,
+                                  stream if stream is not None else cur_stream()), "vc_gate_residual")
 
 
 def add3(a, b, c=None, out=None, stream=None):

@@ -197,6 +197,10 @@ class Flux(nn.Module):
         self.final_layer = LastLayer(self.hidden_size, 1, self.out_channels)
         self._engine: Optional[FluxEngine] = None
         self._fingerprint = None
+        # "merged": W + s*B@A folded once (the product mode).  "ref": LinearLora.forward executed as the
+        # reference does - base GEMM, two skinny GEMMs, three bf16 roundings (models/modules/lora.py:92-98) - so that
+        # the merge's one-rounding deviation is a choice, not a necessity; slower (+8 % FLOPs, unfused epilogues).
+        self.lora_mode = "merged"
 
     # ------------------------------------------------------------------ weights -> engine
     def _linears(self):
@@ -206,7 +210,7 @@ class Flux(nn.Module):
 
     def _weights_fingerprint(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters()) + tuple(
-            m.scale for _, m in self._linears())
+            m.scale for _, m in self._linears()) + (self.lora_mode,)
 
     @staticmethod
     @torch.no_grad()
@@ -234,9 +238,25 @@ class Flux(nn.Module):
             raise hip.VclozeHipError("Flux weights must live on the GPU (model.to('cuda')) — there is no CPU path")
         if getattr(self, "_params_freed", False):
             raise hip.VclozeHipError("parameters were released by prepare(free_parameters=True); load weights again first")
-        w, b = {}, {}
+        if self.lora_mode not in ("merged", "ref"):
+            raise ValueError(f"lora_mode must be 'merged' or 'ref', got {self.lora_mode!r}")
+        w, b, ref = {}, {}, ({} if self.lora_mode == "ref" else None)
+        bf = lambda t: None if t is None else t.detach().to(torch.bfloat16).contiguous()  # noqa: E731
         for name, m in self._linears():
-            w[name], b[name] = self.merged_linear(m)
+            if ref is None:
+                w[name], b[name] = self.merged_linear(m)
+                continue
+            w[name], b[name] = bf(m.weight), bf(m.bias)
+            A = B = bB = sc = None
+            if m.rank:
+                rk = (m.rank + 63) // 64 * 64            # zero-pad the rank to the GEMM's K granularity
+                A = torch.zeros(rk, m.in_features, dtype=torch.bfloat16, device=dev)
+                B = torch.zeros(m.out_features, rk, dtype=torch.bfloat16, device=dev)
+                A[:m.rank], B[:, :m.rank] = bf(m.lora_A.weight), bf(m.lora_B.weight)
+                bB = bf(m.lora_B.bias)
+                sc = torch.full((m.out_features,), m.scale, dtype=torch.bfloat16, device=dev)
+            from .engine import RefLinear
+            ref[name] = RefLinear(w[name], b[name], A, B, bB, sc)
         for name, p in self.named_parameters():
             if name.endswith("norm.scale"):
                 w[name] = p.detach().to(torch.bfloat16).contiguous()
@@ -245,6 +265,12 @@ class Flux(nn.Module):
             n = f"single_blocks.{i}.linear1"
             w[n + ".qkv"], w[n + ".mlp"] = w[n][: 3 * D], w[n][3 * D:]
             b[n + ".qkv"], b[n + ".mlp"] = b[n][: 3 * D], b[n][3 * D:]
+            if ref is not None:         # linear1's two column ranges share lora_A
+                from .engine import RefLinear
+                r = ref[n]
+                for sfx, sl in ((".qkv", slice(0, 3 * D)), (".mlp", slice(3 * D, None))):
+                    ref[n + sfx] = RefLinear(r.w[sl], r.b[sl], r.A, None if r.B is None else r.B[sl],
+                                             None if r.bB is None else r.bB[sl], None if r.scale is None else r.scale[sl])
         # all modulation projections stacked: one GEMM yields every shift/scale/gate of a step
         mods: List[str] = []
         for i in range(self.params.depth):
@@ -259,7 +285,7 @@ class Flux(nn.Module):
         mod_b = torch.cat([b.pop(n) for n in mods], dim=0).contiguous()
         half = 128
         freqs = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half).to(dev)
-        pw = PreparedWeights(w=w, b=b, mod_w=mod_w, mod_b=mod_b, mod_off=off, n_mod=o, temb_freqs=freqs)
+        pw = PreparedWeights(w=w, b=b, mod_w=mod_w, mod_b=mod_b, mod_off=off, n_mod=o, temb_freqs=freqs, ref=ref)
         self._engine = FluxEngine(self.params, pw, dev)
         if free_parameters:
             for p in self.parameters():

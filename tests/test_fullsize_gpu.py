@@ -137,7 +137,7 @@ def test_attention_properties(geom):
     # V = 1  =>  every output element is a convex combination of ones
     vt = torch.zeros(H, 128, Lp, dtype=torch.bfloat16, device=DEV)
     vt[..., :L] = 1
-    for variant in (0, 1, 2, 3, 7):
+    for variant in (0, 1, 2, 3, 7, 8, 12):
         out.fill_(float("nan"))
         hip.attention(qkv, vt, out, L, H, variant=variant)
         torch.cuda.synchronize()
@@ -164,6 +164,13 @@ def test_attention_properties(geom):
         assert torch.equal(o3, o1)
     assert rel_l2(out, o1) < 2e-3
     assert (out.float() - o1.float()).abs().max().item() <= 2 ** -7 * o1.float().abs().max().item()
+    # the one-wave-per-SIMD kernel (8; 12 with the tail split): same arithmetic, its own summation order
+    for variant in (8, 12):
+        o8 = torch.full_like(out, float("nan"))
+        hip.attention(qkv, vt, o8, L, H, variant=variant)
+        torch.cuda.synchronize()
+        assert rel_l2(o8, o1) < 2e-3
+        assert (o8.float() - o1.float()).abs().max().item() <= 2 ** -7 * o1.float().abs().max().item()
 
 
 def _kw(inp):
@@ -300,7 +307,7 @@ def test_race_screen_repeated_launches_are_bit_identical():
             assert torch.equal(first, x), f"GATE_RES cfg 36: launch {it} differs"
     qkv = torch.randn(L2, 3 * D, generator=g).to(torch.bfloat16).to(DEV)
     vt = qkv[:, 2 * D:].reshape(L2, H, 128).permute(1, 2, 0).contiguous()
-    for variant in (0, 1, 2, 3, 7):
+    for variant in (0, 1, 2, 3, 7, 8, 12):
         o0 = torch.empty(L2, D, dtype=torch.bfloat16, device=DEV)
         o1 = torch.empty(L2, D, dtype=torch.bfloat16, device=DEV)
         hip.attention(qkv, vt, o0, L2, H, variant=variant)

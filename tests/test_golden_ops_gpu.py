@@ -123,7 +123,7 @@ def test_modulation_vs_reference(hip, golden, model):
     check(out, golden["mod_out"][0])        # (shift1, scale1, gate1, shift2, scale2, gate2): chunk order included
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 7])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 7, 8, 12])
 @pytest.mark.parametrize("case", ["attn_full", "attn_ragged"])
 def test_attention_vs_reference(hip, golden, variant, case):
     """models/math.py:63-99 `attention(q, k, v, pe, attn_mask)` = apply_rope + flash_attn_varlen_func + pad_input.

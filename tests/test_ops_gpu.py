@@ -157,7 +157,7 @@ def rope_table(L):
     return torch.stack([torch.cos(pos), torch.sin(pos)], -1).float().to(DEV).contiguous()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 7])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 7, 8, 12])
 @pytest.mark.parametrize("L,H,extra,kv_len,split", [(64, 2, 0, None, 0), (40, 2, 0, None, 16), (200, 3, 256, None, 0),
                                                     (333, 2, 0, 301, 128), (1, 1, 0, None, 0), (1664, 4, 0, None, 512)])
 def test_qknorm_rope_vt_and_attention(hip, variant, L, H, extra, kv_len, split):
@@ -189,7 +189,7 @@ def test_qknorm_rope_vt_and_attention(hip, variant, L, H, extra, kv_len, split):
         assert float(out[kv_len:].float().abs().sum()) == 0.0           # pad_input semantics (math.py:96)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 7])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 7, 8, 12])
 def test_attention_softmax_rescale_branch(hip, variant):
     """Force the online-softmax running max to jump late (a spiked key in the LAST tile) and early."""
     L, H = 256, 1

@@ -6,7 +6,7 @@ from visualcloze_amd import hip
 dev = "cuda:0"
 variants = [int(v) for v in sys.argv[1:]] or [3]
 H = 24
-for L in (1664, 2688, 3968, 4608, 5376, 6656, 7424, 8064):
+for L in [int(x) for x in os.environ.get("VC_ATTN_L", "1664,2688,3968,4608,5376,6656,7424,8064").split(",")]:
     Lpad = (L + 63) // 64 * 64
     qkv = torch.randn(L, 3 * H * 128, device=dev).to(torch.bfloat16)
     vt = torch.randn(H, 128, Lpad, device=dev).to(torch.bfloat16)

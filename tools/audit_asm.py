@@ -1,0 +1,53 @@
+"""Audit of a hipcc .s for a kernel whose inline asm owns registers by name (attention64.hip): the kernel must have
+no spills and no scratch, and every v_accvgpr_* must sit inside an ;;#ASMSTART / ;;#ASMEND block.  Also prints the
+instruction mix of the kernel's largest loop.     python tools/audit_asm.py file.s kernel_substring"""
+import re, sys
+path, name = sys.argv[1], sys.argv[2]
+txt = open(path).read()
+m = re.search(r"^(_Z\w*%s\w*):[^\n]*\n(.*?)\n\s*s_endpgm" % name, txt, re.S | re.M)
+if not m:
+    sys.exit(f"kernel *{name}* not found")
+sym, body = m.group(1), m.group(2)
+meta = txt[txt.index(".amdhsa_kernel " + sym):]
+meta = meta[:meta.index(".end_amdhsa_kernel")]
+def field(k):
+    mm = re.search(r"\.amdhsa_%s\s+(\S+)" % k, meta)
+    return mm.group(1) if mm else None
+yaml = txt[txt.rindex("amdhsa.kernels"):]
+ky = yaml[yaml.index(sym):]
+def yfield(k):
+    mm = re.search(r"\.%s:\s+(\S+)" % k, ky)
+    return mm.group(1) if mm else None
+print(f"{sym}: next_free_vgpr={field('next_free_vgpr')} accum_offset={field('accum_offset')} vgpr_count={yfield('vgpr_count')} "
+      f"agpr_count={yfield('agpr_count')} sgpr_count={yfield('sgpr_count')} spill_vgpr={yfield('vgpr_spill_count')} "
+      f"spill_sgpr={yfield('sgpr_spill_count')} scratch={yfield('private_segment_fixed_size')} lds={yfield('group_segment_fixed_size')}")
+bad = []
+inasm = False
+n_insn = 0
+for ln in body.splitlines():
+    s = ln.strip()
+    if s.startswith(";;#ASMSTART"): inasm = True
+    elif s.startswith(";;#ASMEND"): inasm = False
+    elif s and not s.startswith((";", ".", "s_nop")) and not s.endswith(":"):
+        n_insn += 1
+        if not inasm and ("v_accvgpr" in s or "scratch_" in s or "buffer_store" in s and "offen" in s):
+            bad.append(s)
+print(f"{n_insn} instructions; compiler-generated accvgpr / scratch instructions outside asm blocks: {len(bad)}")
+for b in bad[:20]:
+    print("   ", b)
+ok = not bad and yfield('vgpr_spill_count') == '0' and yfield('private_segment_fixed_size') == '0'
+# per-gap histogram of the main loop: instructions between consecutive MFMAs
+gaps, cur = [], None
+for ln in body.splitlines():
+    s = ln.strip()
+    if not s or s.startswith((";", ".")) or s.endswith(":"):
+        continue
+    if s.startswith("v_mfma"):
+        if cur is not None: gaps.append(cur)
+        cur = 0
+    elif cur is not None:
+        cur += 1
+import collections
+h = collections.Counter(min(g, 12) for g in gaps)
+print("instructions between consecutive MFMAs (12 = 12 or more):", dict(sorted(h.items())))
+sys.exit(0 if ok else 1)

@@ -386,7 +386,9 @@ static int attn_cu_count() {
   return n_cu;
 }
 
-int64_t vc_attention_scratch_bytes_impl() { return (int64_t)2 * attn_cu_count() * 2 * PART_FLOATS * (int64_t)sizeof(float); }
+int64_t vc_attention_scratch_bytes_impl() {
+  return std::max((int64_t)2 * attn_cu_count() * 2 * PART_FLOATS * (int64_t)sizeof(float), vc_attention64_scratch_bytes_impl(attn_cu_count()));
+}
 
 int vc_attention_launch(const void* qkv, int64_t ld, int64_t bstride, const void* vt, void* out, int64_t ldo,
                         int64_t out_bstride, const int32_t* kv_len, int32_t B, int32_t L, int32_t Lpad,
@@ -401,6 +403,9 @@ int vc_attention_launch(const void* qkv, int64_t ld, int64_t bstride, const void
   a.qkv = (const bf16_t*)qkv; a.vt = (const bf16_t*)vt; a.out = (bf16_t*)out; a.kv_len = kv_len;
   a.ld = ld; a.bstride = bstride; a.ldo = ldo; a.out_bstride = out_bstride;
   a.B = B; a.L = L; a.Lpad = Lpad; a.H = H;
+  if (variant & 8)    // one wave per SIMD, 64 queries per wave (attention64.hip); +4 = tail split
+    return vc_attention64_launch(qkv, ld, bstride, vt, out, ldo, out_bstride, kv_len, B, L, Lpad, H, (variant & 4) != 0, scratch,
+                                 scratch_bytes, attn_cu_count(), s, err, errlen);
   a.debug_ts = g_attn_debug_ts;
   a.full_rounds = -1; a.tail_items = 0; a.tail_units = 0; a.part = (float*)scratch;
   const int lds = 2 * STAGE;

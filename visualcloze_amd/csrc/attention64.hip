@@ -1,0 +1,536 @@
+// Joint text+image flash attention for gfx950, ONE WAVE PER SIMD form (vc_attention variants 8 / 12).
+//
+// Same arithmetic and the same LDS images as attention.hip (models/math.py:63-99: softmax(q k^T / sqrt(128)) v over the
+// stitched grid sequence, f32 online softmax in the log2 domain, bf16 P, padded keys masked, padded query rows zero),
+// restructured around what bounds that kernel: at 32 queries per wave and two waves per SIMD its loop is issue-bound
+// (49 % matrix-pipe busy; every K / V^T fragment read and every LDS-DMA piece serves only 32 queries, and the two
+// waves of a SIMD contend for one VALU port).  Here a workgroup is 4 waves = one per SIMD, each wave owns 64 queries
+// (two 32-query blocks) and the WHOLE 512-entry register file:
+//
+//   AGPR a[0:127]    O^T accumulators, 2 query blocks x 4 d-tiles x 16          (written only by the P.V MFMAs)
+//   AGPR a[128:191]  Q fragments (MFMA B operands), 2 x 8 k-steps x 4           (loaded once per work item)
+//   AGPR a[192:255]  K fragments of the NEXT tile (MFMA A operands), 2 x 8 x 4  (ds_read straight into AGPRs)
+//   VGPR             S^T of two tiles (2 x 64), P (32), V^T fragment ring (32), softmax state, addresses
+//
+// Every K / V^T fragment feeds two MFMAs (both query blocks): half the LDS reads and half the LDS-DMA issues per FLOP.
+// The tile loop is software-pipelined inside the wave, two phases of 32 MFMAs per 64-key tile:
+//
+//   phase A(t):  S(t+1) = K(t+1) . Q^T          ||  P(t) = 2^(S(t)), row sums, bf16 pack; V^T(t) fragments 0..7
+//   phase B(t):  O += V^T(t) . P(t)^T            ||  row max of S(t+1), rescale decision, S(t+1) <- c*S(t+1) - m;
+//                                                    K(t+2) fragments -> AGPRs; V^T(t) fragments 8..15; LDS-DMA
+//   one s_barrier per tile.
+//
+// The MFMAs, LDS reads and waits are inline asm with literal AGPR names (hipcc cannot be told which accumulators live
+// in which half of the register file: with builtins it parks S in AGPRs and moves it through v_accvgpr_read by the
+// hundred per tile - DESIGN.md 3.2); the softmax VALU code between them is ordinary C++ on compiler-allocated
+// VGPRs, and the issue order is pinned slot by slot with sched_barrier(0) (<= 5-6 fillers per MFMA gap:
+// MI355X_MICROARCH.md 'one wave per SIMD').  K and V^T tiles stream through 4-deep LDS rings by LDS-DMA; tile t issues
+// V^T(t+2) and K(t+4) and waits with a COUNTED vmcnt(8), so every piece has a full tile of flight time.
+//
+// Audit after every change (Makefile target `audit64`): no spills, no scratch, no compiler-generated v_accvgpr_*.
+#include <algorithm>
+#include <type_traits>
+#include "common.h"
+#include "vcloze_internal.h"
+
+namespace {
+
+struct Attn64Args {
+  const bf16_t* qkv;
+  const bf16_t* vt;
+  bf16_t* out;
+  const int32_t* kv_len;
+  int64_t ld, bstride, ldo, out_bstride;
+  int32_t B, L, Lpad, H, qblocks, items;
+  int32_t full_rounds, tail_items, tail_units;   // tail split, as attention.hip (full_rounds < 0 = off)
+  float* part;
+};
+
+constexpr int KVB = 64;
+constexpr int K_TILE = KVB * 256, V_TILE = 128 * KVB * 2;
+constexpr int RING = 4;
+constexpr int V_RING0 = RING * K_TILE;              // 64 KB of K ring, then 64 KB of V^T ring
+constexpr int LDS64 = RING * (K_TILE + V_TILE);     // 128 KB
+constexpr int QW = 64;                              // queries per wave
+constexpr int QB = 4 * QW;                          // queries per work item
+
+constexpr int A_O = 0, A_Q = 128, A_K = 192;        // AGPR map
+
+// one partial result of the tail split: [wave 4][32 groups][lane 64][4] f32 + [wave 4][qb 2][lane 64] (m, l)
+constexpr int PART64_O = 4 * 32 * 64 * 4;
+constexpr int PART64_FLOATS = PART64_O + 4 * 2 * 64 * 2;
+VC_DEV int chunk_begin64(int c, int units, int chunks) { return (int)(((long)c * units) / chunks); }
+
+VC_DEV int swap23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
+
+template <int I, int N, class F>
+VC_DEV void sfor(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    sfor<I + 1, N>(f);
+  }
+}
+#define SB() __builtin_amdgcn_sched_barrier(0)
+
+// ---- asm-owned instructions ----
+template <int KA, int QA, bool ZERO>
+VC_DEV void mfma_qk(f32x16& s) {      // S^T[u] (+)= K_frag . Q_frag   (A = K rows, B = Q rows: a lane owns ONE query column)
+  if constexpr (ZERO)
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], 0" : "=v"(s) : "n"(KA), "n"(KA + 3), "n"(QA), "n"(QA + 3));
+  else
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], %0" : "+v"(s) : "n"(KA), "n"(KA + 3), "n"(QA), "n"(QA + 3));
+}
+template <int OA>
+VC_DEV void mfma_pv(const u32x4& v, const u32x4& p) {   // O^T[dt] += Vt_frag . P_frag
+  asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(v), "v"(p), "n"(OA), "n"(OA + 15));
+}
+template <int A0, int OFF>
+VC_DEV void lds_k(uint32_t addr) {    // K fragment -> AGPRs
+  asm volatile("ds_read_b128 a[%c1:%c2], %0 offset:%c3" ::"v"(addr), "n"(A0), "n"(A0 + 3), "n"(OFF));
+}
+template <int OFF>
+VC_DEV void lds_v(u32x4& f, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(f) : "v"(addr), "n"(OFF));
+}
+template <int A0, int OFF>
+VC_DEV void load_q(const bf16_t* p) {   // 16 B of a query row -> AGPRs (waited for with vmcnt)
+  asm volatile("global_load_dwordx4 a[%c1:%c2], %0, off offset:%c3" ::"v"(p), "n"(A0), "n"(A0 + 3), "n"(OFF) : "memory");
+}
+template <int N> VC_DEV void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%c0)" ::"n"(N)); }
+template <int N> VC_DEV void wait_vm() { asm volatile("s_waitcnt vmcnt(%c0)" ::"n"(N)); }
+VC_DEV float v_max3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+VC_DEV float v_max(float a, float b) {      // (fmaxf would canonicalise both MFMA-written inputs first: two extra v_max per call)
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+#define PIN(x) asm volatile("" : "+v"(x))     /* the value is materialised HERE: IR-level sinking cannot move its producers later */
+VC_DEV uint32_t v_cvt_pk(float lo, float hi) {
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+template <int A> VC_DEV float agpr_read() {
+  float r;
+  asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(r) : "n"(A));
+  return r;
+}
+template <int A> VC_DEV void agpr_write(float v) { asm volatile("v_accvgpr_write_b32 a[%c1], %0" ::"v"(v), "n"(A)); }
+// max over the two half-waves (lanes l and l ^ 32): v_permlane32_swap exchanges the upper half of one operand with the
+// lower half of the other, so swapping two copies of x leaves [x_lo, x_lo] and [x_hi, x_hi]
+VC_DEV float xmax32(float x) {
+  uint32_t a = __builtin_bit_cast(uint32_t, x), b = a;
+  auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  return v_max(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+}
+VC_DEV float xsum32(float x) {
+  uint32_t a = __builtin_bit_cast(uint32_t, x), b = a;
+  auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+}
+
+__global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // the whole accumulator file belongs to the asm statements of this kernel
+  asm volatile("" ::: "a0", "a15", "a31", "a47", "a63", "a79", "a95", "a111", "a127", "a143", "a159", "a175", "a191", "a207",
+               "a223", "a239", "a255");
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lq = lane & 31, hh = lane >> 5;
+  const float c_scale = 0.08838834764831845f * 1.4426950408889634f;   // 128^-0.5 * log2(e)
+
+  // ---- lane constants ----
+  uint32_t k_rd[8], v_rd[4];
+  {
+    const int row = swap23(lq);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) k_rd[t] = row * 256 + (((2 * t + hh) ^ (row & 15)) << 4);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) v_rd[s] = V_RING0 + lq * 128 + (((2 * s + hh) ^ ((lq >> 1) & 7)) << 4);
+  }
+  uint32_t k_off[4], v_off[4];      // LDS-DMA source byte offsets of this lane's 4 K and 4 V^T pieces (tile 0)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = i * 256 + tid;
+    const int row = c >> 4;
+    k_off[i] = (uint32_t)row * (uint32_t)a.ld * 2u + (uint32_t)(((c & 15) ^ (row & 15)) << 4);
+    const int d = c >> 3;
+    v_off[i] = ((uint32_t)d * (uint32_t)a.Lpad + (uint32_t)((((c & 7) ^ ((d >> 1) & 7))) << 3)) * 2u;
+  }
+  const uint32_t k_step = (uint32_t)KVB * (uint32_t)a.ld * 2u;
+  // keys past row L - 1 re-read row L - 1 (they are masked later); the 16-B column of a piece is the same for all 4
+  const uint32_t k_max = (uint32_t)(a.L - 1) * (uint32_t)a.ld * 2u + (uint32_t)(((tid & 15) ^ ((tid >> 4) & 15)) << 4);
+
+  const int G = gridDim.x;
+  const int nkt_all = (a.L + KVB - 1) / KVB;
+  const bool split = a.full_rounds >= 0;
+  const int chunk = split ? xcd_remap(blockIdx.x, G) : 0;
+  int tu = split ? chunk_begin64(chunk, a.tail_units, G) : 0;
+  const int tu_end = split ? chunk_begin64(chunk + 1, a.tail_units, G) : 0;
+  const int it_first = tu / nkt_all;
+
+  for (int seg = 0;; ++seg) {
+    int item, kt0 = 0, kt1 = -1, piece = -1;
+    if (!split) {
+      item = blockIdx.x + seg * G;
+      if (item >= a.items) break;
+    } else if (seg < a.full_rounds) {
+      item = blockIdx.x + seg * G;
+    } else {
+      if (tu >= tu_end) break;
+      const int it = tu / nkt_all;
+      kt0 = tu - it * nkt_all;
+      kt1 = min(nkt_all, kt0 + (tu_end - tu));
+      tu += kt1 - kt0;
+      item = a.full_rounds * G + it;
+      if (kt1 - kt0 != nkt_all) piece = chunk * 2 + (it - it_first);
+    }
+    const int id = xcd_remap(item, a.items);
+    const int qb_i = id % a.qblocks;
+    const int bh = id / a.qblocks;
+    const int h = bh % a.H, b = bh / a.H;
+    const int L = a.L;
+    const int kvlen = a.kv_len ? __builtin_amdgcn_readfirstlane(a.kv_len[b]) : L;
+    const int nkt = (kvlen + KVB - 1) / KVB;
+    if (kt1 < 0) kt1 = nkt;
+
+    const bf16_t* __restrict__ qbase = a.qkv + (long)b * a.bstride + h * 128;
+    const char* kbytes = (const char*)(qbase + a.H * 128);
+    const char* vbytes = (const char*)(a.vt + ((long)(b * a.H + h) * 128) * a.Lpad);
+
+    // LDS-DMA of source tile min(n, kt1 - 1) into ring slot SLOT (4 K + 4 V^T pieces per wave and tile)
+    // (the wave's LDS destination base is re-derived from one SGPR per use: hoisted out of the 4-tile loop body the 32
+    // distinct M0 values - and their spills - cost more than one s_add each)
+    int wave_lds = wave * 1024;
+    auto dma_k = [&](auto SLOT, int n, int i) {
+      const int kt = min(n, kt1 - 1);
+      const uint32_t off = min(k_off[i] + (uint32_t)kt * k_step, k_max);
+      asm volatile("" : "+s"(wave_lds));
+      glds16(kbytes + off, smem + wave_lds + (decltype(SLOT)::value * K_TILE + i * 4096));
+    };
+    auto dma_v = [&](auto SLOT, int n, int i) {
+      const int kt = min(n, kt1 - 1);
+      asm volatile("" : "+s"(wave_lds));
+      glds16(vbytes + (v_off[i] + (uint32_t)kt * (KVB * 2)), smem + wave_lds + (V_RING0 + decltype(SLOT)::value * V_TILE + i * 4096));
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+
+    // ---- prologue: K(0..3), V(0..1) in flight, Q -> AGPRs, O = 0 ----
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { dma_k(I0{}, kt0, i); dma_v(I0{}, kt0, i); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { dma_k(I1{}, kt0 + 1, i); dma_v(I1{}, kt0 + 1, i); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_k(I2{}, kt0 + 2, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_k(I3{}, kt0 + 3, i);
+    const int q0 = qb_i * QB + wave * QW;
+    {
+      const bf16_t* qp0 = qbase + (long)min(q0 + lq, L - 1) * a.ld + hh * 8;
+      const bf16_t* qp1 = qbase + (long)min(q0 + 32 + lq, L - 1) * a.ld + hh * 8;
+      sfor<0, 8>([&](auto T) { load_q<A_Q + decltype(T)::value * 4, decltype(T)::value * 32>(qp0); });
+      sfor<0, 8>([&](auto T) { load_q<A_Q + 32 + decltype(T)::value * 4, decltype(T)::value * 32>(qp1); });
+    }
+    sfor<0, 128>([&](auto I) { agpr_write<A_O + decltype(I)::value>(0.f); });
+    wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    SB();
+
+    f32x16 S[2][2][2];                 // [tile parity][query block][key block]
+    u32x4 P[2][4];                     // [query block][16-key step]
+    u32x4 vf[8];                       // V^T fragment ring
+    float m_run[2] = {-INFINITY, -INFINITY}, negm[2], l_acc[2] = {0.f, 0.f}, alpha[2] = {1.f, 1.f};
+    bool resc = false;
+
+    // K fragments of ring slot SLOT -> a[192:255]
+    auto read_k = [&](auto SLOT, auto UT) {
+      constexpr int ut = decltype(UT)::value, u = ut >> 3, t = ut & 7;
+      lds_k<A_K + ut * 4, decltype(SLOT)::value * K_TILE + u * 8192>(k_rd[t]);
+    };
+    // start-softmax of the tile in Sx (ops [0, 44)), tile index n: row max, rescale decision, Sx <- c*Sx - m
+    auto mask_tail = [&](f32x16 (&Sx)[2][2], int n) {
+      if (n * KVB + KVB > kvlen) {     // only the last tile of a sample can hold keys beyond kv_len
+        asm volatile("s_nop 15" ::: "memory");     // (the MFMAs that wrote Sx may be only a few issue slots back)
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int key = n * KVB + u * 32 + ((r >> 3) << 4) + hh * 8 + (r & 7);
+              if (key >= kvlen) Sx[qb][u][r] = -INFINITY;
+            }
+      }
+    };
+    float mxp[2][2];
+    auto max_step = [&](f32x16 (&Sx)[2][2], auto QBU, auto J) {     // 8 steps per (qb, u): 16 values -> one
+      constexpr int qb = decltype(QBU)::value >> 1, u = decltype(QBU)::value & 1, j = decltype(J)::value;
+      if constexpr (j == 0) mxp[qb][u] = v_max3(Sx[qb][u][0], Sx[qb][u][1], Sx[qb][u][2]);
+      else if constexpr (j < 7) mxp[qb][u] = v_max3(mxp[qb][u], Sx[qb][u][2 * j + 1], Sx[qb][u][2 * j + 2]);
+      else mxp[qb][u] = v_max(mxp[qb][u], Sx[qb][u][15]);
+    };
+    auto decide = [&]() {
+      float m_cand[2];
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) m_cand[qb] = v_max(m_run[qb], xmax32(v_max(mxp[qb][0], mxp[qb][1])) * c_scale);
+      // deferred rescale (as attention.hip): keep the running max while no row of this wave grows by more than 2^8
+      resc = !__all((m_cand[0] - m_run[0] <= 8.0f) && (m_cand[1] - m_run[1] <= 8.0f));
+      if (resc) {
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+          alpha[qb] = __builtin_amdgcn_exp2f(m_run[qb] - m_cand[qb]);
+          m_run[qb] = m_cand[qb];
+        }
+      }
+      negm[0] = -m_run[0];
+      negm[1] = -m_run[1];
+    };
+    auto scale_step = [&](f32x16 (&Sx)[2][2], auto E) {             // 64 steps
+      constexpr int e = decltype(E)::value, qb = e >> 5, u = (e >> 4) & 1, r = e & 15;
+      Sx[qb][u][r] = __builtin_fmaf(Sx[qb][u][r], c_scale, negm[qb]);
+    };
+    // the rare path: O *= alpha, l *= alpha (runs between two P.V phases)
+    auto rescale_o = [&]() {
+      if (resc) {
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // the last P.V MFMAs retire before a[0:127] is read
+        sfor<0, 128>([&](auto I) {
+          constexpr int i = decltype(I)::value;
+          agpr_write<A_O + i>(agpr_read<A_O + i>() * alpha[i >> 6]);
+        });
+        l_acc[0] *= alpha[0];
+        l_acc[1] *= alpha[1];
+        asm volatile("s_nop 7" ::: "memory");
+        resc = false;
+      }
+    };
+
+    // ---- first tile, not overlapped: S(kt0) = K(kt0) . Q^T, its start-softmax, K(kt0+1) fragments ----
+    sfor<0, 16>([&](auto UT) { read_k(I0{}, UT); });
+    wait_lgkm<0>();
+    SB();
+    sfor<0, 32>([&](auto Gp) {
+      constexpr int g = decltype(Gp)::value, t = g >> 2, u = (g >> 1) & 1, qb = g & 1;
+      mfma_qk<A_K + (u * 8 + t) * 4, A_Q + (qb * 8 + t) * 4, t == 0>(S[0][qb][u]);
+    });
+    SB();
+    sfor<0, 16>([&](auto UT) { read_k(I1{}, UT); });
+    asm volatile("s_nop 15" ::: "memory");                          // S(kt0) complete before the VALU reads it
+    SB();
+    mask_tail(S[0], kt0);
+    sfor<0, 4>([&](auto QBU) { sfor<0, 8>([&](auto J) { max_step(S[0], QBU, J); }); });
+    decide();
+    resc = false;                                                   // O = 0, l = 0: nothing to rescale on the first tile
+    sfor<0, 64>([&](auto E) { scale_step(S[0], E); });
+    wait_lgkm<0>();
+    SB();
+
+    // ---- one tile of the steady state; J = (tile - kt0) & 3 selects ring slots and the S parity ----
+    auto tile = [&](auto Jc, int kt) {
+      constexpr int J = decltype(Jc)::value;
+      auto& Sc = S[J & 1];
+      auto& Sn = S[(J + 1) & 1];
+      using SLOT_V = std::integral_constant<int, J>;              // V^T(kt)
+      using SLOT_K2 = std::integral_constant<int, (J + 2) & 3>;    // K(kt+2) fragments / V^T(kt+2) DMA
+      using SLOT_K4 = std::integral_constant<int, J>;              // K(kt+4) DMA
+      rescale_o();
+      SB();
+      // ---------------- phase A: S(kt+1) = K(kt+1) . Q^T  ||  P(kt), l  ||  V^T(kt) fragments 0..7 ----------------
+      float pe0 = 0.f, pe1 = 0.f;
+      sfor<0, 32>([&](auto Gp) {
+        constexpr int g = decltype(Gp)::value, t = g >> 2, u = (g >> 1) & 1, qb = g & 1;
+        mfma_qk<A_K + (u * 8 + t) * 4, A_Q + (qb * 8 + t) * 4, t == 0>(Sn[qb][u]);
+        if constexpr (g > 0) {       // pair g-1: row sum and bf16 pack of the two probabilities exponentiated one gap earlier
+          constexpr int k = g - 1, pq = k >> 4, idx = k & 15, pu = idx >> 3, r0 = (idx & 7) * 2;
+          l_acc[pq] += pe0;
+          l_acc[pq] += pe1;
+          PIN(l_acc[pq]);
+          P[pq][pu * 2 + (r0 >> 3)][(r0 & 7) >> 1] = v_cvt_pk(pe0, pe1);
+        }
+        {
+          constexpr int k = g, pq = k >> 4, idx = k & 15, pu = idx >> 3, r0 = (idx & 7) * 2;
+          pe0 = __builtin_amdgcn_exp2f(Sc[pq][pu][r0]);
+          pe1 = __builtin_amdgcn_exp2f(Sc[pq][pu][r0 + 1]);
+        }
+        if constexpr (g >= 16 && g < 24) {
+          constexpr int f = g - 16;     // fragment (dt = f >> 2, s = f & 3)
+          lds_v<SLOT_V::value * V_TILE + (f >> 2) * 4096>(vf[f], v_rd[f & 3]);
+        }
+        if constexpr (g == 31) wait_lgkm<0>();
+        SB();
+      });
+      // ---------------- phase B: O += V^T(kt) . P(kt)^T  ||  start-softmax(kt+1), K(kt+2) -> AGPRs, DMA ----------------
+      mask_tail(Sn, kt + 1);
+      sfor<0, 32>([&](auto Gp) {
+        constexpr int g = decltype(Gp)::value, dt = g >> 3, s = (g >> 1) & 3, qb = g & 1;
+        if constexpr (g == 16) wait_lgkm<0>();      // V^T fragments 8..15 (and the K fragments issued so far)
+        mfma_pv<A_O + (qb * 4 + dt) * 16>(vf[(dt & 1) * 4 + s], P[qb][s]);
+        if constexpr (g == 0) {
+          constexpr int k = 31, pq = k >> 4, idx = k & 15, pu = idx >> 3, r0 = (idx & 7) * 2;
+          l_acc[pq] += pe0;
+          l_acc[pq] += pe1;
+          PIN(l_acc[pq]);
+          P[pq][pu * 2 + (r0 >> 3)][(r0 & 7) >> 1] = v_cvt_pk(pe0, pe1);
+        }
+        // S(kt+1) was completed by the last MFMAs of phase A: its first VALU read comes two MFMA gaps later
+        if constexpr (g >= 2 && g <= 9) sfor<0, 4>([&](auto QBU) { max_step(Sn, QBU, std::integral_constant<int, g - 2>{}); });
+        if constexpr (g == 10) decide();
+        if constexpr (g >= 11) {
+          constexpr int e0 = (g - 11) * 3;
+          sfor<e0, (g == 31 ? 64 : e0 + 3)>([&](auto E) { scale_step(Sn, E); });
+        }
+        if constexpr ((g & 1) && g < 16) {          // V^T fragment (dt + 2, s) into the register (dt, s) just retired
+          lds_v<SLOT_V::value * V_TILE + (dt + 2) * 4096>(vf[(dt & 1) * 4 + s], v_rd[s]);
+        }
+        if constexpr (g >= 2 && g < 18) read_k(SLOT_K2{}, std::integral_constant<int, g - 2>{});
+        if constexpr (g >= 18 && g < 26) {
+          constexpr int i = g - 18;
+          if constexpr (i < 4) dma_v(SLOT_K2{}, kt + 2, i);
+          else dma_k(SLOT_K4{}, kt + 4, i - 4);
+        }
+        SB();
+      });
+      wait_vm<8>();
+      wait_lgkm<0>();
+      __builtin_amdgcn_s_barrier();
+      SB();
+    };
+
+    for (int kt = kt0;;) {
+      tile(I0{}, kt); if (++kt >= kt1) break;
+      tile(I1{}, kt); if (++kt >= kt1) break;
+      tile(I2{}, kt); if (++kt >= kt1) break;
+      tile(I3{}, kt); if (++kt >= kt1) break;
+    }
+
+    // ---- epilogue ----
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");     // ring quiet, last P.V MFMAs retired
+    if (piece >= 0) {          // part of an item's keys only: un-normalised O^T fragments + (m, l), merged by attn64_merge_kernel
+      float* pp = a.part + (long)piece * PART64_FLOATS;
+      sfor<0, 32>([&](auto Gq) {
+        constexpr int g = decltype(Gq)::value;
+        f32x4 w = {agpr_read<A_O + g * 4 + 0>(), agpr_read<A_O + g * 4 + 1>(), agpr_read<A_O + g * 4 + 2>(), agpr_read<A_O + g * 4 + 3>()};
+        *(f32x4*)(pp + ((wave * 32 + g) * 64 + lane) * 4) = w;
+      });
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        f32x2 ml = {m_run[qb], xsum32(l_acc[qb])};
+        *(f32x2*)(pp + PART64_O + ((wave * 2 + qb) * 64 + lane) * 2) = ml;
+      }
+    } else {
+      sfor<0, 2>([&](auto QBc) {
+        constexpr int qb = decltype(QBc)::value;
+        const float l_tot = xsum32(l_acc[qb]);
+        const int q = q0 + qb * 32 + lq;
+        const float inv = (q < kvlen) ? 1.0f / l_tot : 0.0f;     // padded query rows -> 0 (pad_input, math.py:96)
+        bf16_t* orow = a.out + (long)b * a.out_bstride + (long)min(q, L - 1) * a.ldo + h * 128;
+        sfor<0, 16>([&](auto Gq) {
+          constexpr int g = decltype(Gq)::value, dt = g >> 2, gg = g & 3, A0 = A_O + (qb * 4 + dt) * 16 + gg * 4;
+          u32x2 w;
+          w[0] = pack2bf(agpr_read<A0 + 0>() * inv, agpr_read<A0 + 1>() * inv);
+          w[1] = pack2bf(agpr_read<A0 + 2>() * inv, agpr_read<A0 + 3>() * inv);
+          if (q < L) *(u32x2*)(orow + dt * 32 + gg * 8 + hh * 4) = w;
+        });
+      });
+    }
+    // no barrier here: every wave passed the last tile's s_barrier after its final LDS reads, and a wave's own
+    // vmcnt(0) above orders its in-flight pieces before the next item's prologue DMA into the same slots
+  }  // work items
+}
+
+// Combines the pieces of the tail items (see attention.hip::attn_merge_kernel); thread layout = the writer's.
+__global__ __launch_bounds__(256) void attn64_merge_kernel(const Attn64Args a, int G) {
+  const int it = blockIdx.x;
+  const int nkt = (a.L + KVB - 1) / KVB;
+  const int u0 = it * nkt, u1 = u0 + nkt;
+  int c = (int)(((long)u0 * G) / a.tail_units);
+  while (c > 0 && chunk_begin64(c, a.tail_units, G) > u0) --c;
+  while (c + 1 < G && chunk_begin64(c + 1, a.tail_units, G) <= u0) ++c;
+  if (chunk_begin64(c + 1, a.tail_units, G) >= u1) return;        // the whole item ran inside one chunk: already written
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane & 31, hh = lane >> 5;
+  const int item = a.full_rounds * G + it;
+  const int id = xcd_remap(item, a.items);
+  const int qb_i = id % a.qblocks, bh = id / a.qblocks;
+  const int h = bh % a.H, b = bh / a.H;
+  for (int qb = 0; qb < 2; ++qb) {
+    float m = -INFINITY;
+    for (int cc = c; cc < G && chunk_begin64(cc, a.tail_units, G) < u1; ++cc) {
+      if (chunk_begin64(cc + 1, a.tail_units, G) == chunk_begin64(cc, a.tail_units, G)) continue;
+      const int piece = cc * 2 + (it - chunk_begin64(cc, a.tail_units, G) / nkt);
+      m = fmaxf(m, a.part[(long)piece * PART64_FLOATS + PART64_O + ((wave * 2 + qb) * 64 + lane) * 2]);
+    }
+    f32x4 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float l = 0.f;
+    for (int cc = c; cc < G && chunk_begin64(cc, a.tail_units, G) < u1; ++cc) {
+      if (chunk_begin64(cc + 1, a.tail_units, G) == chunk_begin64(cc, a.tail_units, G)) continue;
+      const int piece = cc * 2 + (it - chunk_begin64(cc, a.tail_units, G) / nkt);
+      const float* pp = a.part + (long)piece * PART64_FLOATS;
+      const f32x2 ml = *(const f32x2*)(pp + PART64_O + ((wave * 2 + qb) * 64 + lane) * 2);
+      const float sc = __builtin_amdgcn_exp2f(ml[0] - m);
+      l += ml[1] * sc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] += *(const f32x4*)(pp + ((wave * 32 + qb * 16 + i) * 64 + lane) * 4) * sc;
+    }
+    const int q = qb_i * QB + wave * QW + qb * 32 + lq;
+    if (q < a.L) {
+      const float inv = 1.0f / l;
+      bf16_t* orow = a.out + (long)b * a.out_bstride + (long)q * a.ldo + h * 128;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        u32x2 w;
+        w[0] = pack2bf(acc[i][0] * inv, acc[i][1] * inv);
+        w[1] = pack2bf(acc[i][2] * inv, acc[i][3] * inv);
+        *(u32x2*)(orow + (i >> 2) * 32 + (i & 3) * 8 + hh * 4) = w;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+int64_t vc_attention64_scratch_bytes_impl(int n_cu) { return (int64_t)n_cu * 2 * PART64_FLOATS * (int64_t)sizeof(float); }
+
+int vc_attention64_launch(const void* qkv, int64_t ld, int64_t bstride, const void* vt, void* out, int64_t ldo,
+                          int64_t out_bstride, const int32_t* kv_len, int32_t B, int32_t L, int32_t Lpad, int32_t H,
+                          bool tail_split, void* scratch, int64_t scratch_bytes, int n_cu, hipStream_t s, char* err, int errlen) {
+  Attn64Args a;
+  a.qkv = (const bf16_t*)qkv; a.vt = (const bf16_t*)vt; a.out = (bf16_t*)out; a.kv_len = kv_len;
+  a.ld = ld; a.bstride = bstride; a.ldo = ldo; a.out_bstride = out_bstride;
+  a.B = B; a.L = L; a.Lpad = Lpad; a.H = H;
+  a.qblocks = (L + QB - 1) / QB;
+  a.items = a.qblocks * H * B;
+  a.full_rounds = -1; a.tail_items = 0; a.tail_units = 0; a.part = (float*)scratch;
+  static bool done = false;
+  hipError_t e;
+  if (!done) {
+    e = hipFuncSetAttribute((const void*)attn64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
+    if (e != hipSuccess) { snprintf(err, errlen, "attention64 attribute: %s", hipGetErrorString(e)); return VC_ERR_HIP; }
+    done = true;
+  }
+  const int G = n_cu;
+  const int nkt = (L + KVB - 1) / KVB;
+  const int rounds = a.items / G, tail = a.items - rounds * G;
+  const int split_tiles = (int)(((long)tail * nkt + G - 1) / G);
+  if (tail_split && !kv_len && tail > 0 && scratch && scratch_bytes >= vc_attention64_scratch_bytes_impl(n_cu) && split_tiles + 4 < nkt) {
+    a.full_rounds = rounds; a.tail_items = tail; a.tail_units = tail * nkt;
+    hipLaunchKernelGGL(attn64_kernel, dim3(G), dim3(256), LDS64, s, a);
+    hipLaunchKernelGGL(attn64_merge_kernel, dim3(tail), dim3(256), 0, s, a, G);
+  } else {
+    hipLaunchKernelGGL(attn64_kernel, dim3(std::min(a.items, G)), dim3(256), LDS64, s, a);
+  }
+  e = hipGetLastError();
+  if (e == hipSuccess) return VC_OK;
+  snprintf(err, errlen, "attention64 launch: %s", hipGetErrorString(e));
+  return VC_ERR_HIP;
+}

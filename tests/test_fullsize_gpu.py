@@ -162,14 +162,14 @@ def test_attention_properties(geom):
         hip.attention(qkv, vt, o3, L, H, variant=variant)
         torch.cuda.synchronize()
         assert torch.equal(o3, o1)
-    assert rel_l2(out, o1) < 2e-3
+    assert rel_l2(out, o1) < 4e-3            # (rows that differ do so by one bf16 ulp = 2^-8 relative)
     assert (out.float() - o1.float()).abs().max().item() <= 2 ** -7 * o1.float().abs().max().item()
     # the one-wave-per-SIMD kernel (8; 12 with the tail split): same arithmetic, its own summation order
     for variant in (8, 12):
         o8 = torch.full_like(out, float("nan"))
         hip.attention(qkv, vt, o8, L, H, variant=variant)
         torch.cuda.synchronize()
-        assert rel_l2(o8, o1) < 2e-3
+        assert rel_l2(o8, o1) < 4e-3
         assert (o8.float() - o1.float()).abs().max().item() <= 2 ** -7 * o1.float().abs().max().item()
 
 

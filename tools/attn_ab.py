@@ -32,6 +32,7 @@ for L in (3968, 6656):
         assert rc == 0, rc
     run(getlib("main"), 1); ref = o.clone()
     for v in variants:
+        print("  check", v, flush=True)
         o.zero_(); run(getlib(v[0]), v[1]); torch.cuda.synchronize()
         if not torch.equal(o, ref):
             d = (o.float() - ref.float()).abs().max().item()

@@ -120,17 +120,22 @@ template <int A> VC_DEV float agpr_read() {
   return r;
 }
 template <int A> VC_DEV void agpr_write(float v) { asm volatile("v_accvgpr_write_b32 a[%c1], %0" ::"v"(v), "n"(A)); }
-// max over the two half-waves (lanes l and l ^ 32): v_permlane32_swap exchanges the upper half of one operand with the
-// lower half of the other, so swapping two copies of x leaves [x_lo, x_lo] and [x_hi, x_hi]
+// Exchange with the other half-wave (lanes l and l ^ 32).  v_permlane32_swap swaps the upper half of its first operand
+// with the lower half of its second: two copies of x become [x_lo, x_lo] and [x_hi, x_hi].  In asm, because hipcc
+// (ROCm 7.2) folds the two results of the builtin into ONE register when both inputs are the same value; the s_nop is
+// the VALU-write -> permlane-read hazard (2 wait states), which nothing pads inside an asm string.
+VC_DEV void half_swap(float x, float& lo, float& hi) {
+  asm volatile("v_mov_b32 %1, %2\n\tv_mov_b32 %0, %2\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "=&v"(lo), "=&v"(hi) : "v"(x));
+}
 VC_DEV float xmax32(float x) {
-  uint32_t a = __builtin_bit_cast(uint32_t, x), b = a;
-  auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
-  return v_max(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+  float lo, hi;
+  half_swap(x, lo, hi);
+  return v_max(lo, hi);
 }
 VC_DEV float xsum32(float x) {
-  uint32_t a = __builtin_bit_cast(uint32_t, x), b = a;
-  auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
-  return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+  float lo, hi;
+  half_swap(x, lo, hi);
+  return lo + hi;
 }
 
 __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
@@ -247,6 +252,10 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
 
     f32x16 S[2][2][2];                 // [tile parity][query block][key block]
     u32x4 P[2][4];                     // [query block][16-key step]
+#ifdef VC_A64_NO_SOFTMAX
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("" : "=v"(P[i >> 2][i & 3]));
+#endif
     u32x4 vf[8];                       // V^T fragment ring
     float m_run[2] = {-INFINITY, -INFINITY}, negm[2], l_acc[2] = {0.f, 0.f}, alpha[2] = {1.f, 1.f};
     bool resc = false;
@@ -278,25 +287,39 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
       else if constexpr (j < 7) mxp[qb][u] = v_max3(mxp[qb][u], Sx[qb][u][2 * j + 1], Sx[qb][u][2 * j + 2]);
       else mxp[qb][u] = v_max(mxp[qb][u], Sx[qb][u][15]);
     };
-    auto decide = [&]() {
-      float m_cand[2];
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb) m_cand[qb] = v_max(m_run[qb], xmax32(v_max(mxp[qb][0], mxp[qb][1])) * c_scale);
+    float mq[2];
+    auto decide0 = [&]() {              // max over the two key blocks
+      mq[0] = v_max(mxp[0][0], mxp[0][1]);
+      mq[1] = v_max(mxp[1][0], mxp[1][1]);
+    };
+    auto decide1 = [&](auto QBc) {      // ... and over the two half-waves; candidate running max
+      constexpr int qb = decltype(QBc)::value;
+      mq[qb] = v_max(m_run[qb], xmax32(mq[qb]) * c_scale);
+    };
+    auto decide2 = [&]() {
       // deferred rescale (as attention.hip): keep the running max while no row of this wave grows by more than 2^8
-      resc = !__all((m_cand[0] - m_run[0] <= 8.0f) && (m_cand[1] - m_run[1] <= 8.0f));
+      resc = !__all((mq[0] - m_run[0] <= 8.0f) && (mq[1] - m_run[1] <= 8.0f));
       if (resc) {
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
-          alpha[qb] = __builtin_amdgcn_exp2f(m_run[qb] - m_cand[qb]);
-          m_run[qb] = m_cand[qb];
+          alpha[qb] = __builtin_amdgcn_exp2f(m_run[qb] - mq[qb]);
+          m_run[qb] = mq[qb];
         }
       }
       negm[0] = -m_run[0];
       negm[1] = -m_run[1];
     };
+    auto decide = [&]() {
+      decide0();
+      decide1(std::integral_constant<int, 0>{});
+      decide1(std::integral_constant<int, 1>{});
+      decide2();
+    };
     auto scale_step = [&](f32x16 (&Sx)[2][2], auto E) {             // 64 steps
       constexpr int e = decltype(E)::value, qb = e >> 5, u = (e >> 4) & 1, r = e & 15;
-      Sx[qb][u][r] = __builtin_fmaf(Sx[qb][u][r], c_scale, negm[qb]);
+      float v = __builtin_fmaf(Sx[qb][u][r], c_scale, negm[qb]);
+      PIN(v);                         // (computed in THIS gap: left alone, the fmas sink to their exps in the next tile)
+      Sx[qb][u][r] = v;
     };
     // the rare path: O *= alpha, l *= alpha (runs between two P.V phases)
     auto rescale_o = [&]() {
@@ -347,7 +370,12 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
       float pe0 = 0.f, pe1 = 0.f;
       sfor<0, 32>([&](auto Gp) {
         constexpr int g = decltype(Gp)::value, t = g >> 2, u = (g >> 1) & 1, qb = g & 1;
+#ifndef VC_A64_NO_MFMA
         mfma_qk<A_K + (u * 8 + t) * 4, A_Q + (qb * 8 + t) * 4, t == 0>(Sn[qb][u]);
+#else
+        if constexpr (t == 0) asm volatile("" : "=v"(Sn[qb][u]));
+#endif
+#ifndef VC_A64_NO_SOFTMAX
         if constexpr (g > 0) {       // pair g-1: row sum and bf16 pack of the two probabilities exponentiated one gap earlier
           constexpr int k = g - 1, pq = k >> 4, idx = k & 15, pu = idx >> 3, r0 = (idx & 7) * 2;
           l_acc[pq] += pe0;
@@ -360,10 +388,15 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
           pe0 = __builtin_amdgcn_exp2f(Sc[pq][pu][r0]);
           pe1 = __builtin_amdgcn_exp2f(Sc[pq][pu][r0 + 1]);
         }
+#endif
+#ifndef VC_A64_NO_LDS
         if constexpr (g >= 16 && g < 24) {
           constexpr int f = g - 16;     // fragment (dt = f >> 2, s = f & 3)
           lds_v<SLOT_V::value * V_TILE + (f >> 2) * 4096>(vf[f], v_rd[f & 3]);
         }
+#else
+        if constexpr (g >= 16 && g < 24) asm volatile("" : "=v"(vf[g - 16]));
+#endif
         if constexpr (g == 31) wait_lgkm<0>();
         SB();
       });
@@ -372,7 +405,10 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
       sfor<0, 32>([&](auto Gp) {
         constexpr int g = decltype(Gp)::value, dt = g >> 3, s = (g >> 1) & 3, qb = g & 1;
         if constexpr (g == 16) wait_lgkm<0>();      // V^T fragments 8..15 (and the K fragments issued so far)
+#ifndef VC_A64_NO_MFMA
         mfma_pv<A_O + (qb * 4 + dt) * 16>(vf[(dt & 1) * 4 + s], P[qb][s]);
+#endif
+#ifndef VC_A64_NO_SOFTMAX
         if constexpr (g == 0) {
           constexpr int k = 31, pq = k >> 4, idx = k & 15, pu = idx >> 3, r0 = (idx & 7) * 2;
           l_acc[pq] += pe0;
@@ -382,25 +418,37 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
         }
         // S(kt+1) was completed by the last MFMAs of phase A: its first VALU read comes two MFMA gaps later
         if constexpr (g >= 2 && g <= 9) sfor<0, 4>([&](auto QBU) { max_step(Sn, QBU, std::integral_constant<int, g - 2>{}); });
-        if constexpr (g == 10) decide();
-        if constexpr (g >= 11) {
-          constexpr int e0 = (g - 11) * 3;
-          sfor<e0, (g == 31 ? 64 : e0 + 3)>([&](auto E) { scale_step(Sn, E); });
+        if constexpr (g == 10) decide0();
+        if constexpr (g == 11) decide1(std::integral_constant<int, 0>{});
+        if constexpr (g == 12) decide1(std::integral_constant<int, 1>{});
+        if constexpr (g == 13) decide2();
+        if constexpr (g >= 14) {        // 64 scale steps over 18 gaps: 4 in gaps 14..23, 3 in gaps 24..31
+          constexpr int e0 = g < 24 ? (g - 14) * 4 : 40 + (g - 24) * 3;
+          sfor<e0, e0 + (g < 24 ? 4 : 3)>([&](auto E) { scale_step(Sn, E); });
         }
+#endif
+#ifndef VC_A64_NO_LDS
         if constexpr ((g & 1) && g < 16) {          // V^T fragment (dt + 2, s) into the register (dt, s) just retired
           lds_v<SLOT_V::value * V_TILE + (dt + 2) * 4096>(vf[(dt & 1) * 4 + s], v_rd[s]);
         }
         if constexpr (g >= 2 && g < 18) read_k(SLOT_K2{}, std::integral_constant<int, g - 2>{});
-        if constexpr (g >= 18 && g < 26) {
-          constexpr int i = g - 18;
+#endif
+#ifndef VC_A64_NO_DMA     // analysis builds only (wrong results): the loop without one of its ingredients
+        if constexpr (g < 2 || g >= 26) {        // LDS-DMA pieces in the thinnest gaps
+          constexpr int i = g < 2 ? g : g - 24;
           if constexpr (i < 4) dma_v(SLOT_K2{}, kt + 2, i);
           else dma_k(SLOT_K4{}, kt + 4, i - 4);
         }
+#endif
         SB();
       });
+#ifndef VC_A64_NO_DMA
       wait_vm<8>();
+#endif
       wait_lgkm<0>();
+#ifndef VC_A64_NO_BARRIER
       __builtin_amdgcn_s_barrier();
+#endif
       SB();
     };
 

@@ -169,8 +169,21 @@ def test_attention_properties(geom):
         o8 = torch.full_like(out, float("nan"))
         hip.attention(qkv, vt, o8, L, H, variant=variant)
         torch.cuda.synchronize()
-        assert rel_l2(o8, o1) < 4e-3
-        assert (o8.float() - o1.float()).abs().max().item() <= 2 ** -7 * o1.float().abs().max().item()
+        assert rel_l2(o8, o1) < 6e-3        # (q * 128^-0.5 log2 e is rounded to bf16 once more in this kernel)
+        assert (o8.float() - o1.float()).abs().max().item() <= 2 ** -6 * o1.float().abs().max().item()
+    # every variant against the function itself (f32 torch softmax(q k^T / sqrt d) v on two heads)
+    for hd in (0, H - 1):
+        q = qkv[:, hd * 128:(hd + 1) * 128].float()
+        k = qkv[:, D + hd * 128:D + (hd + 1) * 128].float()
+        v = qkv[:, 2 * D + hd * 128:2 * D + (hd + 1) * 128].float()
+        ref = torch.softmax(q @ k.t() * 128 ** -0.5, dim=-1) @ v
+        for variant in (1, 7, 8, 12):
+            o = torch.empty_like(out)
+            hip.attention(qkv, vt, o, L, H, variant=variant)
+            torch.cuda.synchronize()
+            got = o[:, hd * 128:(hd + 1) * 128]
+            assert rel_l2(got, ref) < 1e-2, (variant, hd)
+            assert (got.float() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item(), (variant, hd)
 
 
 def _kw(inp):

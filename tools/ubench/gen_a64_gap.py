@@ -19,6 +19,14 @@ def mfma(kind, g):
         a = 128 + ((dt & 1) * 4 + s) * 4
         b = 160 + (qb * 4 + s) * 4
         return f"v_mfma_f32_32x32x16_bf16 a[{d}:{d+15}], v[{a}:{a+3}], v[{b}:{b+3}], a[{d}:{d+15}]"
+    if kind == "qkchain":   # chain-major: 9 consecutive MFMAs on ONE accumulator (8 k-steps + the row-max step), 4 chains
+        c = (g // 9) & 3
+        t = g % 9
+        d = 64 + 16 * c
+        a = 192 + ((c & 1) * 8 + min(t, 7)) * 4
+        b = 128 + ((c >> 1) * 8 + min(t, 7)) * 4
+        cin = f"v[{d}:{d+15}]" if t else "0"
+        return f"v_mfma_f32_32x32x16_bf16 v[{d}:{d+15}], a[{a}:{a+3}], a[{b}:{b+3}], {cin}"
     if kind == "vv":    # everything in VGPRs, 4 chains
         d = 64 + 16 * (g & 3)
         a = 128 + (g & 7) * 4
@@ -29,8 +37,11 @@ def mfma(kind, g):
 def fillers(recipe, g):
     out = []
     r = 200 + (g % 8) * 4        # rotating scratch registers v200..v231
+    rp = 200 + ((g - 1) % 8) * 4   # registers written one gap earlier
     for op in recipe:
-        if op == "fma": out.append(f"v_fma_f32 v{r}, v{r}, v232, v233"); r += 1
+        if op == "addp": out.append(f"v_add_f32 v234, v{rp}, v234"); rp += 1      # consumes the PREVIOUS gap's exp
+        elif op == "cvtp": out.append(f"v_cvt_pk_bf16_f32 v235, v{rp-1}, v{rp-2}")
+        elif op == "fma": out.append(f"v_fma_f32 v{r}, v{r}, v232, v233"); r += 1
         elif op == "exp": out.append(f"v_exp_f32 v{r}, v{r}"); r += 1
         elif op == "add": out.append(f"v_add_f32 v234, v{r-1}, v234")
         elif op == "cvt": out.append(f"v_cvt_pk_bf16_f32 v235, v{r-1}, v{r-2}")
@@ -66,6 +77,18 @@ VARIANTS = [
     ("pv + 4 fma + K read (AGPR) + nop", "pv", ["nop"] + ["fma"] * 4 + ["ldsa"]),
     ("pv + 1 K read (AGPR)", "pv", ["ldsa"]),
     ("pv + 1 V read (VGPR)", "pv", ["ldsv"]),
+    ("qkchain (9 dependent MFMAs per chain), no fillers", "qkchain", []),
+    ("qkchain + exp addp exp addp cvtp", "qkchain", ["exp", "addp", "exp", "addp", "cvtp"]),
+    ("qk + exp addp exp addp cvtp", "qk", ["exp", "addp", "exp", "addp", "cvtp"]),
+    ("qk + exp exp addp addp cvtp", "qk", ["exp", "exp", "addp", "addp", "cvtp"]),
+    ("qk + exp addp exp addp cvtp + V read", "qk", ["exp", "addp", "exp", "addp", "cvtp", "ldsv"]),
+    ("qk + exp addp exp addp cvtp + fma", "qk", ["exp", "addp", "exp", "addp", "cvtp", "fma"]),
+    ("qk + exp addp exp addp cvtp + 2 fma", "qk", ["exp", "addp", "exp", "addp", "cvtp", "fma", "fma"]),
+    ("pv + 5 fma + K read (AGPR)", "pv", ["fma"] * 5 + ["ldsa"]),
+    ("pv + 4 fma + K read (AGPR)", "pv", ["fma"] * 4 + ["ldsa"]),
+    ("pv + 3 fma + K read (AGPR)", "pv", ["fma"] * 3 + ["ldsa"]),
+    ("pv + 2 fma + K read + V read", "pv", ["fma"] * 2 + ["ldsa", "ldsv"]),
+    ("pv + 2 max3 + K read", "pv", ["max3"] * 2 + ["ldsa"]),
     ("qk + 4 s_nop", "qk", ["nop"] * 4),
     ("qk + 4 salu", "qk", ["salu"] * 4),
 ]
@@ -76,7 +99,7 @@ src = ['// GENERATED by tools/ubench/gen_a64_gap.py - do not edit.',
 clob = ", ".join(f'"v{i}"' for i in range(64, 241)) + ', "s20", "a0", "a255"'
 for vi, (name, kind, recipe) in enumerate(VARIANTS):
     body = []
-    for g in range(32):
+    for g in range(36 if kind == "qkchain" else 32):
         body.append(mfma(kind, g))
         body += fillers(recipe, g)
     if any(op.startswith("lds") for op in recipe):
@@ -99,7 +122,7 @@ for vi, (name, kind, recipe) in enumerate(VARIANTS):
     hipLaunchKernelGGL(k{vi}, dim3(256), dim3(256), 65536, 0, out, 10);
     hipEventRecord(e0); hipLaunchKernelGGL(k{vi}, dim3(256), dim3(256), 65536, 0, out, iters); hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); unsigned long long cyc; hipMemcpy(&cyc, out, 8, hipMemcpyDeviceToHost);
-    printf("%-44s %6.1f ticks/MFMA  %7.1f ns/MFMA (event)  %2d fillers/gap\\n", "{name}", (double)cyc / (iters * 32.0), ms * 1e6 / (iters * 32.0), {len(recipe)}); }}''')
+    printf("%-44s %6.1f ticks/MFMA  %7.1f ns/MFMA (event)  %2d fillers/gap\\n", "{name}", (double)cyc / (iters * {36.0 if kind == "qkchain" else 32.0}), ms * 1e6 / (iters * {36.0 if kind == "qkchain" else 32.0}), {len(recipe)}); }}''')
 src.append('  return 0;\n}')
 open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "a64_gap.hip"), "w").write("\n".join(src) + "\n")
 print("wrote a64_gap.hip with", len(VARIANTS), "variants")

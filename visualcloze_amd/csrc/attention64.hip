@@ -15,16 +15,28 @@
 // Every K / V^T fragment feeds two MFMAs (both query blocks): half the LDS reads and half the LDS-DMA issues per FLOP.
 // The tile loop is software-pipelined inside the wave, two phases of 32 MFMAs per 64-key tile:
 //
-//   phase A(t):  S(t+1) = K(t+1) . Q^T          ||  P(t) = 2^(S(t)), row sums, bf16 pack; V^T(t) fragments 0..7
-//   phase B(t):  O += V^T(t) . P(t)^T            ||  row max of S(t+1), rescale decision, S(t+1) <- c*S(t+1) - m;
-//                                                    K(t+2) fragments -> AGPRs; V^T(t) fragments 8..15; LDS-DMA
+//   phase A(t):  S(t+1) = K(t+1) . Q^T - m      ||  P(t) = 2^(S(t)), row sums, bf16 pack; V^T(t) fragments 0..7
+//   phase B(t):  O += V^T(t) . P(t)^T            ||  row max of S(t+1), rescale decision; K(t+2) fragments -> AGPRs;
+//                                                    V^T(t) fragments 8..15; LDS-DMA
 //   one s_barrier per tile.
+//
+// No per-element scale / subtract in the loop: Q is multiplied by 128^-0.5 * log2(e) when it is loaded (once per work
+// item), and the running row max m is subtracted BY THE MATRIX PIPE - every S chain runs a 9th k-step over two extra
+// "dimensions", q_aug = (-m, -29952), k_aug = (1, key is masked ? 1 : 0), with m kept bf16-representable (any reference
+// point works for a softmax), so the accumulators come out as c*q.k - m, masked keys at -29952, ready for v_exp.  With
+// the deferred rescale (m moves only when a row grows by more than 2^8) the per-element VALU work is exp, add and half
+// a convert and half a max3 - what fits beside 68 MFMAs per tile; the measured prices per 32-cycle MFMA gap (one
+// wave per SIMD, tools/ubench/a64_gap.hip) are 7 issue slots, MFMA 1, plain VALU 1, v_exp 2, ds_read_b128 3.2.
+//
+// S^T lives in SIX 16-register blocks: phase A runs its four chains one after the other, and the blocks of S(t) whose
+// probabilities are already exponentiated take the last two chains of S(t+1); the block roles rotate with period 3,
+// as do the 3-deep K and V^T LDS rings, so the loop body is three tiles.
 //
 // The MFMAs, LDS reads and waits are inline asm with literal AGPR names (hipcc cannot be told which accumulators live
 // in which half of the register file: with builtins it parks S in AGPRs and moves it through v_accvgpr_read by the
 // hundred per tile - DESIGN.md 3.2); the softmax VALU code between them is ordinary C++ on compiler-allocated
 // VGPRs, and the issue order is pinned slot by slot with sched_barrier(0) (<= 5-6 fillers per MFMA gap:
-// MI355X_MICROARCH.md 'one wave per SIMD').  K and V^T tiles stream through 4-deep LDS rings by LDS-DMA; tile t issues
+// MI355X_MICROARCH.md 'one wave per SIMD').  K and V^T tiles stream through 3-deep LDS rings by LDS-DMA; tile t issues
 // V^T(t+2) and K(t+4) and waits with a COUNTED vmcnt(8), so every piece has a full tile of flight time.
 //
 // Audit after every change (Makefile target `audit64`): no spills, no scratch, no compiler-generated v_accvgpr_*.
@@ -48,9 +60,9 @@ struct Attn64Args {
 
 constexpr int KVB = 64;
 constexpr int K_TILE = KVB * 256, V_TILE = 128 * KVB * 2;
-constexpr int RING = 4;
-constexpr int V_RING0 = RING * K_TILE;              // 64 KB of K ring, then 64 KB of V^T ring
-constexpr int LDS64 = RING * (K_TILE + V_TILE);     // 128 KB
+constexpr int RING = 3;
+constexpr int V_RING0 = RING * K_TILE;              // 48 KB of K ring, then 48 KB of V^T ring
+constexpr int LDS64 = RING * (K_TILE + V_TILE);     // 96 KB
 constexpr int QW = 64;                              // queries per wave
 constexpr int QB = 4 * QW;                          // queries per work item
 
@@ -79,6 +91,9 @@ VC_DEV void mfma_qk(f32x16& s) {      // S^T[u] (+)= K_frag . Q_frag   (A = K ro
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], 0" : "=v"(s) : "n"(KA), "n"(KA + 3), "n"(QA), "n"(QA + 3));
   else
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], %0" : "+v"(s) : "n"(KA), "n"(KA + 3), "n"(QA), "n"(QA + 3));
+}
+VC_DEV void mfma_aug(f32x16& s, const u32x4& k, const u32x4& q) {   // the 9th k-step: S^T += k_aug . q_aug  (= -m, or -29952 - m on masked keys)
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s) : "v"(k), "v"(q));
 }
 template <int OA>
 VC_DEV void mfma_pv(const u32x4& v, const u32x4& p) {   // O^T[dt] += Vt_frag . P_frag
@@ -149,13 +164,14 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lq = lane & 31, hh = lane >> 5;
   const float c_scale = 0.08838834764831845f * 1.4426950408889634f;   // 128^-0.5 * log2(e)
+  const float MASKED = -29952.0f;                                      // bf16-exact; 2^(MASKED - m) == 0
 
   // ---- lane constants ----
   uint32_t k_rd[8], v_rd[4];
+  const int krow = swap23(lq);          // key row (within a 32-key block) whose fragment this lane feeds to the MFMA
   {
-    const int row = swap23(lq);
 #pragma unroll
-    for (int t = 0; t < 8; ++t) k_rd[t] = row * 256 + (((2 * t + hh) ^ (row & 15)) << 4);
+    for (int t = 0; t < 8; ++t) k_rd[t] = krow * 256 + (((2 * t + hh) ^ (krow & 15)) << 4);
 #pragma unroll
     for (int s = 0; s < 4; ++s) v_rd[s] = V_RING0 + lq * 128 + (((2 * s + hh) ^ ((lq >> 1) & 7)) << 4);
   }
@@ -171,6 +187,10 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
   const uint32_t k_step = (uint32_t)KVB * (uint32_t)a.ld * 2u;
   // keys past row L - 1 re-read row L - 1 (they are masked later); the 16-B column of a piece is the same for all 4
   const uint32_t k_max = (uint32_t)(a.L - 1) * (uint32_t)a.ld * 2u + (uint32_t)(((tid & 15) ^ ((tid >> 4) & 15)) << 4);
+  // k_aug / q_aug fragments (d = 128 + hh*8 + e): only elements 0, 1 of the hh = 0 lanes are ever non-zero
+  const uint32_t aug_on = hh == 0 ? 0xffffffffu : 0u;
+  const uint32_t kaug_one = 0x3f80u & aug_on;                                   // k_aug[128] = 1
+  const uint32_t qaug_mask = ((uint32_t)f2bf(MASKED) << 16) & aug_on;           // q_aug[129] = -29952
 
   const int G = gridDim.x;
   const int nkt_all = (a.L + KVB - 1) / KVB;
@@ -210,8 +230,8 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
     const char* vbytes = (const char*)(a.vt + ((long)(b * a.H + h) * 128) * a.Lpad);
 
     // LDS-DMA of source tile min(n, kt1 - 1) into ring slot SLOT (4 K + 4 V^T pieces per wave and tile)
-    // (the wave's LDS destination base is re-derived from one SGPR per use: hoisted out of the 4-tile loop body the 32
-    // distinct M0 values - and their spills - cost more than one s_add each)
+    // (the wave's LDS destination base is re-derived from one SGPR per use: hoisted out of the loop body the distinct
+    // M0 values - and their spills - cost more than one s_add each)
     int wave_lds = wave * 1024;
     auto dma_k = [&](auto SLOT, int n, int i) {
       const int kt = min(n, kt1 - 1);
@@ -227,37 +247,45 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>;
-    using I3 = std::integral_constant<int, 3>;
 
-    // ---- prologue: K(0..3), V(0..1) in flight, Q -> AGPRs, O = 0 ----
+    // ---- prologue: K(0..2), V(0..1) in flight; Q * c -> AGPRs; O = 0 ----
 #pragma unroll
     for (int i = 0; i < 4; ++i) { dma_k(I0{}, kt0, i); dma_v(I0{}, kt0, i); }
 #pragma unroll
     for (int i = 0; i < 4; ++i) { dma_k(I1{}, kt0 + 1, i); dma_v(I1{}, kt0 + 1, i); }
 #pragma unroll
     for (int i = 0; i < 4; ++i) dma_k(I2{}, kt0 + 2, i);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) dma_k(I3{}, kt0 + 3, i);
     const int q0 = qb_i * QB + wave * QW;
-    {
-      const bf16_t* qp0 = qbase + (long)min(q0 + lq, L - 1) * a.ld + hh * 8;
-      const bf16_t* qp1 = qbase + (long)min(q0 + 32 + lq, L - 1) * a.ld + hh * 8;
-      sfor<0, 8>([&](auto T) { load_q<A_Q + decltype(T)::value * 4, decltype(T)::value * 32>(qp0); });
-      sfor<0, 8>([&](auto T) { load_q<A_Q + 32 + decltype(T)::value * 4, decltype(T)::value * 32>(qp1); });
-    }
+    sfor<0, 2>([&](auto QBc) {
+      constexpr int qb = decltype(QBc)::value;
+      const bf16_t* qp = qbase + (long)min(q0 + qb * 32 + lq, L - 1) * a.ld + hh * 8;
+      u32x4 raw[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) raw[t] = *(const u32x4*)(qp + t * 16);
+      sfor<0, 8>([&](auto T) {
+        constexpr int t = decltype(T)::value;
+        sfor<0, 4>([&](auto E) {        // q * (128^-0.5 * log2 e), rounded to bf16 once more: S comes out in the log2 domain
+          constexpr int e = decltype(E)::value;
+          const uint32_t w = raw[t][e];
+          agpr_write<A_Q + (qb * 8 + t) * 4 + e>(__builtin_bit_cast(float, pack2bf(lo_bf(w) * c_scale, hi_bf(w) * c_scale)));
+        });
+      });
+    });
     sfor<0, 128>([&](auto I) { agpr_write<A_O + decltype(I)::value>(0.f); });
     wait_vm<0>();
     __builtin_amdgcn_s_barrier();
     SB();
 
-    f32x16 S[2][2][2];                 // [tile parity][query block][key block]
+    f32x16 SBk[6];                     // S^T blocks; roles rotate with the tile (see tile())
     u32x4 P[2][4];                     // [query block][16-key step]
 #ifdef VC_A64_NO_SOFTMAX
 #pragma unroll
     for (int i = 0; i < 8; ++i) asm volatile("" : "=v"(P[i >> 2][i & 3]));
 #endif
     u32x4 vf[8];                       // V^T fragment ring
-    float m_run[2] = {-INFINITY, -INFINITY}, negm[2], l_acc[2] = {0.f, 0.f}, alpha[2] = {1.f, 1.f};
+    float m_run[2] = {0.f, 0.f};       // running row max (log2 domain), always bf16-representable: -m_run sits in q_aug
+    float l_acc[2] = {0.f, 0.f}, alpha[2] = {1.f, 1.f};
+    u32x4 qaug[2] = {{qaug_mask, 0u, 0u, 0u}, {qaug_mask, 0u, 0u, 0u}};
     bool resc = false;
 
     // K fragments of ring slot SLOT -> a[192:255]
@@ -265,61 +293,48 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
       constexpr int ut = decltype(UT)::value, u = ut >> 3, t = ut & 7;
       lds_k<A_K + ut * 4, decltype(SLOT)::value * K_TILE + u * 8192>(k_rd[t]);
     };
-    // start-softmax of the tile in Sx (ops [0, 44)), tile index n: row max, rescale decision, Sx <- c*Sx - m
-    auto mask_tail = [&](f32x16 (&Sx)[2][2], int n) {
-      if (n * KVB + KVB > kvlen) {     // only the last tile of a sample can hold keys beyond kv_len
-        asm volatile("s_nop 15" ::: "memory");     // (the MFMAs that wrote Sx may be only a few issue slots back)
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-          for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int key = n * KVB + u * 32 + ((r >> 3) << 4) + hh * 8 + (r & 7);
-              if (key >= kvlen) Sx[qb][u][r] = -INFINITY;
-            }
-      }
+    // k_aug fragment of key block u of tile n: dimension 128 = 1, dimension 129 = (key >= kv_len)
+    auto make_kaug = [&](int n, int u) -> u32x4 {
+      const uint32_t m = (n * KVB + u * 32 + krow >= kvlen) ? (0x3f800000u & aug_on) : 0u;
+      return u32x4{kaug_one | m, 0u, 0u, 0u};
     };
-    float mxp[2][2];
-    auto max_step = [&](f32x16 (&Sx)[2][2], auto QBU, auto J) {     // 8 steps per (qb, u): 16 values -> one
-      constexpr int qb = decltype(QBU)::value >> 1, u = decltype(QBU)::value & 1, j = decltype(J)::value;
-      if constexpr (j == 0) mxp[qb][u] = v_max3(Sx[qb][u][0], Sx[qb][u][1], Sx[qb][u][2]);
-      else if constexpr (j < 7) mxp[qb][u] = v_max3(mxp[qb][u], Sx[qb][u][2 * j + 1], Sx[qb][u][2 * j + 2]);
-      else mxp[qb][u] = v_max(mxp[qb][u], Sx[qb][u][15]);
+    float mxp[4];
+    auto max_step = [&](f32x16& Sx, auto Cc, auto Jc) {     // 8 steps per chain: 16 values -> one
+      constexpr int c = decltype(Cc)::value, j = decltype(Jc)::value;
+      if constexpr (j == 0) mxp[c] = v_max3(Sx[0], Sx[1], Sx[2]);
+      else if constexpr (j < 7) mxp[c] = v_max3(mxp[c], Sx[2 * j + 1], Sx[2 * j + 2]);
+      else mxp[c] = v_max(mxp[c], Sx[15]);
     };
     float mq[2];
-    auto decide0 = [&]() {              // max over the two key blocks
-      mq[0] = v_max(mxp[0][0], mxp[0][1]);
-      mq[1] = v_max(mxp[1][0], mxp[1][1]);
+    // S holds c*q.k - m_run: mq = how far a row's max lies ABOVE the running max
+    auto decide0 = [&]() {
+      mq[0] = v_max(mxp[0], mxp[1]);
+      mq[1] = v_max(mxp[2], mxp[3]);
     };
-    auto decide1 = [&](auto QBc) {      // ... and over the two half-waves; candidate running max
-      constexpr int qb = decltype(QBc)::value;
-      mq[qb] = v_max(m_run[qb], xmax32(mq[qb]) * c_scale);
-    };
-    auto decide2 = [&]() {
-      // deferred rescale (as attention.hip): keep the running max while no row of this wave grows by more than 2^8
-      resc = !__all((mq[0] - m_run[0] <= 8.0f) && (mq[1] - m_run[1] <= 8.0f));
+    auto decide1 = [&](auto QBc) { mq[decltype(QBc)::value] = xmax32(mq[decltype(QBc)::value]); };
+    // deferred rescale (as attention.hip): m moves only when some row of the wave grew by more than 2^8, or on the
+    // first tile.  The new max is rounded to bf16 (it must sit in q_aug exactly); S(kt+1), already accumulated against
+    // the old max, is corrected in place, O and l at the start of the next tile.
+    auto decide2 = [&](auto B0, bool first) {       // B0: index of the first block of the tile's S in SBk
+      constexpr int b0 = decltype(B0)::value;
+      resc = first || !__all((mq[0] <= 8.0f) && (mq[1] <= 8.0f));
       if (resc) {
+        sfor<0, 2>([&](auto QBc) {
+          constexpr int qb = decltype(QBc)::value;
+          const float want = first ? mq[qb] : m_run[qb] + fmaxf(mq[qb], 0.f);
+          const bf16_t nb = f2bf(-want);
+          const float m_new = -bf2f(nb);
+          const float delta = m_new - m_run[qb];
+          alpha[qb] = __builtin_amdgcn_exp2f(-delta);
+          m_run[qb] = m_new;
+          qaug[qb][0] = ((uint32_t)nb & aug_on) | qaug_mask;
+          sfor<0, 2>([&](auto Uc) {
+            constexpr int blk = (b0 + qb * 2 + decltype(Uc)::value) % 6;
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-          alpha[qb] = __builtin_amdgcn_exp2f(m_run[qb] - mq[qb]);
-          m_run[qb] = mq[qb];
-        }
+            for (int r = 0; r < 16; ++r) SBk[blk][r] -= delta;
+          });
+        });
       }
-      negm[0] = -m_run[0];
-      negm[1] = -m_run[1];
-    };
-    auto decide = [&]() {
-      decide0();
-      decide1(std::integral_constant<int, 0>{});
-      decide1(std::integral_constant<int, 1>{});
-      decide2();
-    };
-    auto scale_step = [&](f32x16 (&Sx)[2][2], auto E) {             // 64 steps
-      constexpr int e = decltype(E)::value, qb = e >> 5, u = (e >> 4) & 1, r = e & 15;
-      float v = __builtin_fmaf(Sx[qb][u][r], c_scale, negm[qb]);
-      PIN(v);                         // (computed in THIS gap: left alone, the fmas sink to their exps in the next tile)
-      Sx[qb][u][r] = v;
     };
     // the rare path: O *= alpha, l *= alpha (runs between two P.V phases)
     auto rescale_o = [&]() {
@@ -335,73 +350,89 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
         resc = false;
       }
     };
+    // one S chain: 8 k-steps over the head dimension + the (-m, mask) step
+    auto qk_step = [&](f32x16& Sx, auto Cc, auto Tc, const u32x4& kaug) {
+      constexpr int c = decltype(Cc)::value, qb = c >> 1, u = c & 1, t = decltype(Tc)::value;
+      if constexpr (t < 8) mfma_qk<A_K + (u * 8 + t) * 4, A_Q + (qb * 8 + t) * 4, t == 0>(Sx);
+      else mfma_aug(Sx, kaug, qaug[qb]);
+    };
 
-    // ---- first tile, not overlapped: S(kt0) = K(kt0) . Q^T, its start-softmax, K(kt0+1) fragments ----
+    // ---- first tile, not overlapped: S(kt0) = K(kt0) . Q^T (m = 0), its row max, K(kt0+1) fragments ----
     sfor<0, 16>([&](auto UT) { read_k(I0{}, UT); });
     wait_lgkm<0>();
+    __builtin_amdgcn_s_barrier();      // every wave holds its K(kt0) fragments: slot 0 may take K(kt0+3)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_k(I0{}, kt0 + 3, i);
     SB();
-    sfor<0, 32>([&](auto Gp) {
-      constexpr int g = decltype(Gp)::value, t = g >> 2, u = (g >> 1) & 1, qb = g & 1;
-      mfma_qk<A_K + (u * 8 + t) * 4, A_Q + (qb * 8 + t) * 4, t == 0>(S[0][qb][u]);
-    });
+    {
+      u32x4 ka[2] = {make_kaug(kt0, 0), make_kaug(kt0, 1)};
+      sfor<0, 36>([&](auto Gp) {
+        constexpr int g = decltype(Gp)::value, c = g / 9, t = g % 9;
+        qk_step(SBk[c], std::integral_constant<int, c>{}, std::integral_constant<int, t>{}, ka[c & 1]);
+      });
+    }
     SB();
     sfor<0, 16>([&](auto UT) { read_k(I1{}, UT); });
     asm volatile("s_nop 15" ::: "memory");                          // S(kt0) complete before the VALU reads it
     SB();
-    mask_tail(S[0], kt0);
-    sfor<0, 4>([&](auto QBU) { sfor<0, 8>([&](auto J) { max_step(S[0], QBU, J); }); });
-    decide();
+    sfor<0, 4>([&](auto Cc) { sfor<0, 8>([&](auto Jc) { max_step(SBk[decltype(Cc)::value], Cc, Jc); }); });
+    decide0();
+    decide1(I0{});
+    decide1(I1{});
+    decide2(I0{}, true);
     resc = false;                                                   // O = 0, l = 0: nothing to rescale on the first tile
-    sfor<0, 64>([&](auto E) { scale_step(S[0], E); });
     wait_lgkm<0>();
+    __builtin_amdgcn_s_barrier();      // every wave holds its K(kt0+1) fragments before tile kt0 sends K(kt0+4) into that slot
     SB();
 
-    // ---- one tile of the steady state; J = (tile - kt0) & 3 selects ring slots and the S parity ----
+    // ---- one tile of the steady state; J = (tile - kt0) % 3 selects ring slots and the S block roles:
+    //      S(kt) = blocks (4J + i) % 6, S(kt+1) = blocks (4J + 4 + i) % 6, i = chain = 2*qb + u  (the last two chains of
+    //      S(kt+1) take the blocks of S(kt) that phase A has finished exponentiating by then) ----
     auto tile = [&](auto Jc, int kt) {
       constexpr int J = decltype(Jc)::value;
-      auto& Sc = S[J & 1];
-      auto& Sn = S[(J + 1) & 1];
-      using SLOT_V = std::integral_constant<int, J>;              // V^T(kt)
-      using SLOT_K2 = std::integral_constant<int, (J + 2) & 3>;    // K(kt+2) fragments / V^T(kt+2) DMA
-      using SLOT_K4 = std::integral_constant<int, J>;              // K(kt+4) DMA
+      constexpr int BASE = (4 * J) % 6;
+      using SLOT_V = std::integral_constant<int, J>;                 // V^T(kt)
+      using SLOT_K2 = std::integral_constant<int, (J + 2) % 3>;      // K(kt+2) fragments / V^T(kt+2) DMA
+      using SLOT_K4 = std::integral_constant<int, (J + 1) % 3>;      // K(kt+4) DMA
       rescale_o();
+      u32x4 ka[2] = {make_kaug(kt + 1, 0), make_kaug(kt + 1, 1)};
       SB();
-      // ---------------- phase A: S(kt+1) = K(kt+1) . Q^T  ||  P(kt), l  ||  V^T(kt) fragments 0..7 ----------------
+      // ---------------- phase A: S(kt+1) = K(kt+1) . Q^T - m  ||  P(kt), l  ||  V^T(kt) fragments 0..7 ----------------
       float pe0 = 0.f, pe1 = 0.f;
-      sfor<0, 32>([&](auto Gp) {
-        constexpr int g = decltype(Gp)::value, t = g >> 2, u = (g >> 1) & 1, qb = g & 1;
+      sfor<0, 36>([&](auto Gp) {
+        constexpr int g = decltype(Gp)::value, c = g / 9, t = g % 9;
 #ifndef VC_A64_NO_MFMA
-        mfma_qk<A_K + (u * 8 + t) * 4, A_Q + (qb * 8 + t) * 4, t == 0>(Sn[qb][u]);
+        qk_step(SBk[(BASE + 4 + c) % 6], std::integral_constant<int, c>{}, std::integral_constant<int, t>{}, ka[c & 1]);
 #else
-        if constexpr (t == 0) asm volatile("" : "=v"(Sn[qb][u]));
+        if constexpr (t == 0) asm volatile("" : "=v"(SBk[(BASE + 4 + c) % 6]));
 #endif
 #ifndef VC_A64_NO_SOFTMAX
-        if constexpr (g > 0) {       // pair g-1: row sum and bf16 pack of the two probabilities exponentiated one gap earlier
+        if constexpr (g > 0 && g <= 32) {   // pair g-1: row sum and bf16 pack of the two probabilities exponentiated one gap earlier
           constexpr int k = g - 1, pq = k >> 4, idx = k & 15, pu = idx >> 3, r0 = (idx & 7) * 2;
           l_acc[pq] += pe0;
           l_acc[pq] += pe1;
           PIN(l_acc[pq]);
           P[pq][pu * 2 + (r0 >> 3)][(r0 & 7) >> 1] = v_cvt_pk(pe0, pe1);
         }
-        {
+        if constexpr (g < 32) {
           constexpr int k = g, pq = k >> 4, idx = k & 15, pu = idx >> 3, r0 = (idx & 7) * 2;
-          pe0 = __builtin_amdgcn_exp2f(Sc[pq][pu][r0]);
-          pe1 = __builtin_amdgcn_exp2f(Sc[pq][pu][r0 + 1]);
+          pe0 = __builtin_amdgcn_exp2f(SBk[(BASE + pq * 2 + pu) % 6][r0]);
+          pe1 = __builtin_amdgcn_exp2f(SBk[(BASE + pq * 2 + pu) % 6][r0 + 1]);
         }
 #endif
 #ifndef VC_A64_NO_LDS
-        if constexpr (g >= 16 && g < 24) {
-          constexpr int f = g - 16;     // fragment (dt = f >> 2, s = f & 3)
+        if constexpr (g >= 32) {          // the four thin gaps at the end take the first eight V^T fragments
+          constexpr int f = (g - 32) * 2;   // fragment (dt = f >> 2, s = f & 3)
           lds_v<SLOT_V::value * V_TILE + (f >> 2) * 4096>(vf[f], v_rd[f & 3]);
+          lds_v<SLOT_V::value * V_TILE + ((f + 1) >> 2) * 4096>(vf[f + 1], v_rd[(f + 1) & 3]);
         }
 #else
-        if constexpr (g >= 16 && g < 24) asm volatile("" : "=v"(vf[g - 16]));
+        if constexpr (g >= 32) { asm volatile("" : "=v"(vf[(g - 32) * 2])); asm volatile("" : "=v"(vf[(g - 32) * 2 + 1])); }
 #endif
-        if constexpr (g == 31) wait_lgkm<0>();
+        if constexpr (g == 35) wait_lgkm<0>();
         SB();
       });
-      // ---------------- phase B: O += V^T(kt) . P(kt)^T  ||  start-softmax(kt+1), K(kt+2) -> AGPRs, DMA ----------------
-      mask_tail(Sn, kt + 1);
+      // ---------------- phase B: O += V^T(kt) . P(kt)^T  ||  row max of S(kt+1), K(kt+2) -> AGPRs, DMA ----------------
       sfor<0, 32>([&](auto Gp) {
         constexpr int g = decltype(Gp)::value, dt = g >> 3, s = (g >> 1) & 3, qb = g & 1;
         if constexpr (g == 16) wait_lgkm<0>();      // V^T fragments 8..15 (and the K fragments issued so far)
@@ -409,33 +440,23 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
         mfma_pv<A_O + (qb * 4 + dt) * 16>(vf[(dt & 1) * 4 + s], P[qb][s]);
 #endif
 #ifndef VC_A64_NO_SOFTMAX
-        if constexpr (g == 0) {
-          constexpr int k = 31, pq = k >> 4, idx = k & 15, pu = idx >> 3, r0 = (idx & 7) * 2;
-          l_acc[pq] += pe0;
-          l_acc[pq] += pe1;
-          PIN(l_acc[pq]);
-          P[pq][pu * 2 + (r0 >> 3)][(r0 & 7) >> 1] = v_cvt_pk(pe0, pe1);
-        }
         // S(kt+1) was completed by the last MFMAs of phase A: its first VALU read comes two MFMA gaps later
-        if constexpr (g >= 2 && g <= 9) sfor<0, 4>([&](auto QBU) { max_step(Sn, QBU, std::integral_constant<int, g - 2>{}); });
+        if constexpr (g >= 2 && g <= 9)
+          sfor<0, 4>([&](auto Cc) { max_step(SBk[(BASE + 4 + decltype(Cc)::value) % 6], Cc, std::integral_constant<int, g - 2>{}); });
         if constexpr (g == 10) decide0();
-        if constexpr (g == 11) decide1(std::integral_constant<int, 0>{});
-        if constexpr (g == 12) decide1(std::integral_constant<int, 1>{});
-        if constexpr (g == 13) decide2();
-        if constexpr (g >= 14) {        // 64 scale steps over 18 gaps: 4 in gaps 14..23, 3 in gaps 24..31
-          constexpr int e0 = g < 24 ? (g - 14) * 4 : 40 + (g - 24) * 3;
-          sfor<e0, e0 + (g < 24 ? 4 : 3)>([&](auto E) { scale_step(Sn, E); });
-        }
+        if constexpr (g == 11) decide1(I0{});
+        if constexpr (g == 12) decide1(I1{});
+        if constexpr (g == 13) decide2(std::integral_constant<int, (BASE + 4) % 6>{}, false);
 #endif
 #ifndef VC_A64_NO_LDS
         if constexpr ((g & 1) && g < 16) {          // V^T fragment (dt + 2, s) into the register (dt, s) just retired
           lds_v<SLOT_V::value * V_TILE + (dt + 2) * 4096>(vf[(dt & 1) * 4 + s], v_rd[s]);
         }
-        if constexpr (g >= 2 && g < 18) read_k(SLOT_K2{}, std::integral_constant<int, g - 2>{});
+        if constexpr (g >= 14 && g < 30) read_k(SLOT_K2{}, std::integral_constant<int, g - 14>{});
 #endif
 #ifndef VC_A64_NO_DMA     // analysis builds only (wrong results): the loop without one of its ingredients
-        if constexpr (g < 2 || g >= 26) {        // LDS-DMA pieces in the thinnest gaps
-          constexpr int i = g < 2 ? g : g - 24;
+        if constexpr (g < 2 || (g >= 18 && g < 30 && (g & 1) == 0)) {    // LDS-DMA pieces: gaps 0, 1, 18, 20, ... 28
+          constexpr int i = g < 2 ? g : (g - 18) / 2 + 2;
           if constexpr (i < 4) dma_v(SLOT_K2{}, kt + 2, i);
           else dma_k(SLOT_K4{}, kt + 4, i - 4);
         }
@@ -456,7 +477,6 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
       tile(I0{}, kt); if (++kt >= kt1) break;
       tile(I1{}, kt); if (++kt >= kt1) break;
       tile(I2{}, kt); if (++kt >= kt1) break;
-      tile(I3{}, kt); if (++kt >= kt1) break;
     }
 
     // ---- epilogue ----

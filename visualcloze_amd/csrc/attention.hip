@@ -374,6 +374,7 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const AttnArgs a, int G
 
 }  // namespace
 
+
 static uint64_t* g_attn_debug_ts = nullptr;
 extern "C" void vc_debug_set_attn_ts(void* p) { g_attn_debug_ts = (uint64_t*)p; }   // tools/ only; not in the ABI header
 
@@ -405,7 +406,7 @@ int vc_attention_launch(const void* qkv, int64_t ld, int64_t bstride, const void
   a.B = B; a.L = L; a.Lpad = Lpad; a.H = H;
   if (variant & 8)    // one wave per SIMD, 64 queries per wave (attention64.hip); +4 = tail split
     return vc_attention64_launch(qkv, ld, bstride, vt, out, ldo, out_bstride, kv_len, B, L, Lpad, H, (variant & 4) != 0, scratch,
-                                 scratch_bytes, attn_cu_count(), s, err, errlen);
+                                 scratch_bytes, attn_cu_count(), g_attn_debug_ts, s, err, errlen);
   a.debug_ts = g_attn_debug_ts;
   a.full_rounds = -1; a.tail_items = 0; a.tail_units = 0; a.part = (float*)scratch;
   const int lds = 2 * STAGE;

@@ -56,6 +56,7 @@ struct Attn64Args {
   int32_t B, L, Lpad, H, qblocks, items;
   int32_t full_rounds, tail_items, tail_units;   // tail split, as attention.hip (full_rounds < 0 = off)
   float* part;
+  uint64_t* debug_ts;   // profiling builds only (-DVC_ATTN_TIMESTAMPS): per workgroup (start, end, tiles)
 };
 
 constexpr int KVB = 64;
@@ -192,6 +193,10 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
   const uint32_t kaug_one = 0x3f80u & aug_on;                                   // k_aug[128] = 1
   const uint32_t qaug_mask = ((uint32_t)f2bf(MASKED) << 16) & aug_on;           // q_aug[129] = -29952
 
+#ifdef VC_ATTN_TIMESTAMPS
+  const uint64_t ts0 = __builtin_amdgcn_s_memtime();
+  int ts_tiles = 0;
+#endif
   const int G = gridDim.x;
   const int nkt_all = (a.L + KVB - 1) / KVB;
   const bool split = a.full_rounds >= 0;
@@ -224,6 +229,9 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
     const int kvlen = a.kv_len ? __builtin_amdgcn_readfirstlane(a.kv_len[b]) : L;
     const int nkt = (kvlen + KVB - 1) / KVB;
     if (kt1 < 0) kt1 = nkt;
+#ifdef VC_ATTN_TIMESTAMPS
+    ts_tiles += kt1 - kt0;
+#endif
 
     const bf16_t* __restrict__ qbase = a.qkv + (long)b * a.bstride + h * 128;
     const char* kbytes = (const char*)(qbase + a.H * 128);
@@ -512,6 +520,13 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
     // no barrier here: every wave passed the last tile's s_barrier after its final LDS reads, and a wave's own
     // vmcnt(0) above orders its in-flight pieces before the next item's prologue DMA into the same slots
   }  // work items
+#ifdef VC_ATTN_TIMESTAMPS
+  if (a.debug_ts && tid == 0) {
+    a.debug_ts[blockIdx.x * 4 + 0] = ts0;
+    a.debug_ts[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime();
+    a.debug_ts[blockIdx.x * 4 + 2] = ts_tiles;
+  }
+#endif
 }
 
 // Combines the pieces of the tail items (see attention.hip::attn_merge_kernel); thread layout = the writer's.
@@ -571,8 +586,10 @@ int64_t vc_attention64_scratch_bytes_impl(int n_cu) { return (int64_t)n_cu * 2 *
 
 int vc_attention64_launch(const void* qkv, int64_t ld, int64_t bstride, const void* vt, void* out, int64_t ldo,
                           int64_t out_bstride, const int32_t* kv_len, int32_t B, int32_t L, int32_t Lpad, int32_t H,
-                          bool tail_split, void* scratch, int64_t scratch_bytes, int n_cu, hipStream_t s, char* err, int errlen) {
+                          bool tail_split, void* scratch, int64_t scratch_bytes, int n_cu, uint64_t* debug_ts, hipStream_t s,
+                          char* err, int errlen) {
   Attn64Args a;
+  a.debug_ts = debug_ts;
   a.qkv = (const bf16_t*)qkv; a.vt = (const bf16_t*)vt; a.out = (bf16_t*)out; a.kv_len = kv_len;
   a.ld = ld; a.bstride = bstride; a.ldo = ldo; a.out_bstride = out_bstride;
   a.B = B; a.L = L; a.Lpad = Lpad; a.H = H;

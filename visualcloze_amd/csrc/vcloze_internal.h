@@ -11,7 +11,8 @@ int vc_attention_launch(const void* qkv, int64_t ld, int64_t bstride, const void
 int64_t vc_attention_scratch_bytes_impl();
 int vc_attention64_launch(const void* qkv, int64_t ld, int64_t bstride, const void* vt, void* out, int64_t ldo,
                           int64_t out_bstride, const int32_t* kv_len, int32_t B, int32_t L, int32_t Lpad, int32_t H,
-                          bool tail_split, void* scratch, int64_t scratch_bytes, int n_cu, hipStream_t s, char* err, int errlen);
+                          bool tail_split, void* scratch, int64_t scratch_bytes, int n_cu, uint64_t* debug_ts, hipStream_t s,
+                          char* err, int errlen);
 int64_t vc_attention64_scratch_bytes_impl(int n_cu);
 int vc_ln_modulate2_launch(const VcLnStream* a, const VcLnStream* b, int64_t mod_bstride, int32_t D, const int32_t* step_ptr,
                            int64_t mod_step_stride, hipStream_t s, char* err, int errlen);

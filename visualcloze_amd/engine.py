@@ -114,7 +114,7 @@ class FluxEngine:
         self.H = geom.num_heads
         self.mlp = int(geom.hidden_size * geom.mlp_ratio)
         self._ws: Dict[tuple, Workspace] = {}
-        self.attn_variant = 7      # 4 waves x 32 queries, persistent grid, tail items cut along the keys (hip.attention)
+        self.attn_variant = 12     # one wave per SIMD x 64 queries, tail items cut along the keys (hip.attention; 3 = round-1 kernel)
         self.attn_scratch = hip.attention_scratch(dev)
         self.tile_cfg = 0
         self.stream = torch.cuda.Stream(device=dev)   # capture needs a non-default stream

@@ -24,9 +24,9 @@ extern "C" {
 #define VC_ABI_VERSION 2
 int vc_abi_version(void);
 const char* vc_last_error(void);
-/* sizeof(VcGemmProblem), sizeof(VcGemmArgs), sizeof(VcLnStream) as this library was compiled: a binding checks them
- * against its own mirrors at load time, so a stale .so cannot silently disagree with the caller's structs. */
-void vc_struct_sizes(int32_t out[3]);
+/* sizeof(VcGemmProblem), sizeof(VcGemmArgs), sizeof(VcLnStream), sizeof(VcAttention) as this library was compiled: a
+ * binding checks them against its own mirrors at load time, so a stale .so cannot silently disagree with the caller. */
+void vc_struct_sizes(int32_t out[4]);
 /* number of visible devices / name of device 0 ("" when none) — fails loudly, never falls back */
 int vc_device_count(void);
 int vc_device_info(int dev, char* name, int namelen, int* cu_count, int64_t* hbm_bytes);
@@ -95,10 +95,16 @@ int vc_ln_modulate2(const VcLnStream* a, const VcLnStream* b, int64_t mod_bstrid
  * q | k | v at column offsets 0, H*128, 2*H*128 ("B L (K H D)", layers.py:166).
  * rope: [B?][L][64][2] f32 (cos, sin) per pair; rope_bstride 0 = shared by the batch.
  * Token rows < split use (q_scale, k_scale), rows >= split use (q_scale2, k_scale2): the text and image
- * streams of a DoubleStreamBlock own separate QKNorm scales (layers.py:167,174); NULL scale2 = one set. */
+ * streams of a DoubleStreamBlock own separate QKNorm scales (layers.py:167,174); NULL scale2 = one set.
+ * parts: bit 0 = the q rows, bit 1 = the k rows, bit 2 = V -> vt; 7 = everything.  6 when the attention call
+ * normalises the queries itself (VcAttention.q_scale). */
+#define VC_QKN_Q 1
+#define VC_QKN_K 2
+#define VC_QKN_VT 4
 int vc_qknorm_rope_vt(void* qkv, int64_t ld, int64_t bstride, const void* q_scale, const void* k_scale,
                       const void* q_scale2, const void* k_scale2, int32_t split, const float* rope,
-                      int64_t rope_bstride, void* vt, int32_t B, int32_t L, int32_t Lpad, int32_t H, void* stream);
+                      int64_t rope_bstride, void* vt, int32_t B, int32_t L, int32_t Lpad, int32_t H, int32_t parts,
+                      void* stream);
 
 /* Joint text+image attention, non-causal, D=128, softmax scale 128^-0.5 (math.py:63-99 /
  * flash_attn_varlen_func).  q,k from the qkv rows above; vt from vc_qknorm_rope_vt.
@@ -106,15 +112,25 @@ int vc_qknorm_rope_vt(void* qkv, int64_t ld, int64_t bstride, const void* q_scal
  * = pad_input of math.py:96); NULL = all L.  out: [B, L, H*128] bf16, row stride ldo.
  * variant: 0 = 8 waves x 32 queries per workgroup, 1 = 4 waves x 32 queries (two workgroups per CU); +2 = the same
  * kernel on a persistent grid (one workgroup per resident slot, work items assigned statically); variants 0-3 produce
- * bit-identical results.  7 = 3 with the TAIL SPLIT, the default of the host engine: the items beyond the last full
- * round of 2 x CUs workgroups (232 of 744 at L = 3968, H = 24) are cut along the keys into one equal chunk per
- * workgroup; partial (O, m, l) go to `scratch` (>= vc_attention_scratch_bytes(), device memory, contents undefined
- * afterwards) and a second kernel on the same stream merges them.  Same softmax, different f32 summation order for
- * those rows.  The launcher falls back to variant 3 when scratch is NULL / too small, kv_len is given, or the split
- * would not shorten the critical path. */
-int vc_attention(const void* qkv, int64_t ld, int64_t bstride, const void* vt, void* out, int64_t ldo,
-                 int64_t out_bstride, const int32_t* kv_len, int32_t B, int32_t L, int32_t Lpad, int32_t H,
-                 int32_t variant, void* scratch, int64_t scratch_bytes, void* stream);
+ * bit-identical results.  8 = ONE WAVE PER SIMD, 4 waves x 64 queries, software-pipelined inside the wave
+ * (attention64.hip), persistent; q * 128^-0.5 log2(e) is rounded to bf16 when the queries are loaded.
+ * +4 (7, 12) = TAIL SPLIT: the items beyond the last full round of resident workgroups are cut along the keys into one
+ * equal chunk per workgroup; partial (O, m, l) go to `scratch` (>= vc_attention_scratch_bytes(), device memory,
+ * contents undefined afterwards) and a second kernel on the same stream merges them.  Same softmax, different f32
+ * summation order for those rows.  The launcher drops the split when scratch is NULL / too small, kv_len is given, or
+ * it would not shorten the critical path.  12 is the default of the host engine.
+ * q_scale != NULL (variants 8, 12 only): the q columns of qkv hold the RAW projection output and QKNorm + RoPE
+ * (layers.py:75-84, math.py:112-117) are applied to the 64 query rows a wave loads, with q_scale / q_scale2 / split /
+ * rope / rope_bstride as in vc_qknorm_rope_vt (which is then called with parts = VC_QKN_K | VC_QKN_VT). */
+typedef struct VcAttention {
+  const void* qkv; int64_t ld, bstride;
+  const void* vt; void* out; int64_t ldo, out_bstride;
+  const int32_t* kv_len;
+  int32_t B, L, Lpad, H, variant, split;
+  void* scratch; int64_t scratch_bytes;
+  const void* q_scale; const void* q_scale2; const float* rope; int64_t rope_bstride;
+} VcAttention;
+int vc_attention(const VcAttention* a, void* stream);
 int64_t vc_attention_scratch_bytes(void);
 
 /* timestep_embedding (layers.py:28-49): out[b, 0:half]=cos(1000*t*f), [half:]=sin, f host table. */

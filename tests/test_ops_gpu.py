@@ -189,6 +189,49 @@ def test_qknorm_rope_vt_and_attention(hip, variant, L, H, extra, kv_len, split):
         assert float(out[kv_len:].float().abs().sum()) == 0.0           # pad_input semantics (math.py:96)
 
 
+@pytest.mark.parametrize("variant", [8, 12])
+@pytest.mark.parametrize("L,H,extra,kv_len,split,B", [(64, 2, 0, None, 0, 1), (40, 2, 0, None, 16, 1), (200, 3, 256, None, 0, 1),
+                                                      (333, 2, 0, 301, 128, 1), (1, 1, 0, None, 0, 1), (1664, 4, 0, None, 512, 1),
+                                                      (300, 2, 0, None, 44, 2)])
+def test_attention_with_in_kernel_query_norm(hip, variant, L, H, extra, kv_len, split, B):
+    """Variants 8 / 12 can apply QKNorm + RoPE to the RAW query rows while loading them (q_norm=...): the pre-pass then does
+    K and V^T only (parts = QKN_K | QKN_VT) and must leave the q columns untouched.  Same result as the pre-pass route."""
+    ld = 3 * H * 128 + extra
+    qkv = rnd(B * L, ld, seed=7)
+    qs, ks = (1 + 0.1 * rnd(128, seed=8)).to(torch.bfloat16), (1 + 0.1 * rnd(128, seed=9)).to(torch.bfloat16)
+    qs2, ks2 = (1 + 0.1 * rnd(128, seed=10)).to(torch.bfloat16), (1 + 0.1 * rnd(128, seed=11)).to(torch.bfloat16)
+    rope = torch.stack([rope_table(L)] + [rope_table(L).flip(0)] * (B - 1)).contiguous() if B > 1 else rope_table(L)
+    Lpad = (L + 63) // 64 * 64
+    vt = torch.zeros((B, H, 128, Lpad), dtype=torch.bfloat16, device=DEV)
+    kvl = None if kv_len is None else torch.tensor([kv_len] * B, dtype=torch.int32, device=DEV)
+    # route 1: everything in the pre-pass
+    w1 = qkv.clone()
+    hip.qknorm_rope_vt(w1, qs, ks, rope, vt, L, H, q_scale2=qs2, k_scale2=ks2, split=split, B=B)
+    o1 = torch.full((B * L, H * 128), float("nan"), dtype=torch.bfloat16, device=DEV)
+    hip.attention(w1, vt, o1, L, H, kv_len=kvl, variant=variant, B=B)
+    # route 2: K and V^T in the pre-pass, the queries inside the attention kernel
+    w2 = qkv.clone()
+    hip.qknorm_rope_vt(w2, qs, ks, rope, vt, L, H, q_scale2=qs2, k_scale2=ks2, split=split, B=B, parts=hip.QKN_K | hip.QKN_VT)
+    torch.cuda.synchronize()
+    assert torch.equal(w2[:, :H * 128], qkv[:, :H * 128])                  # q columns untouched
+    assert torch.equal(w2[:, H * 128:2 * H * 128], w1[:, H * 128:2 * H * 128])
+    o2 = torch.full((B * L, H * 128), float("nan"), dtype=torch.bfloat16, device=DEV)
+    hip.attention(w2, vt, o2, L, H, kv_len=kvl, variant=variant, B=B, q_norm=(qs, qs2, split, rope))
+    torch.cuda.synchronize()
+    check(o2, o1.float(), tol=1e-2)
+    # and against the torch reference of the whole chain, per sample
+    for b in range(B):
+        rb = rope[b] if B > 1 else rope
+        x = qkv[b * L:(b + 1) * L]
+        qa, ka, _ = R.qknorm_rope_ref(x, qs, ks, rb, H)
+        qb_, kb_, _ = R.qknorm_rope_ref(x, qs2, ks2, rb, H)
+        qref, kref = torch.cat([qa[:split], qb_[split:]]), torch.cat([ka[:split], kb_[split:]])
+        v = x[:, 2 * H * 128: 3 * H * 128].float().reshape(L, H, 128)
+        check(o2[b * L:(b + 1) * L], R.attention_ref(qref, kref, v, kv_len))
+    with pytest.raises(hip.VclozeHipError):                                # only the one-wave-per-SIMD kernel has it
+        hip.attention(w2, vt, o2, L, H, variant=3, B=B, q_norm=(qs, qs2, split, rope))
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 7, 8, 12])
 def test_attention_softmax_rescale_branch(hip, variant):
     """Force the online-softmax running max to jump late (a spiked key in the LAST tile) and early."""

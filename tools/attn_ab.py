@@ -25,10 +25,11 @@ for L in (3968, 6656):
     stream = hip.cur_stream()
     scr = hip.attention_scratch(dev)
     def run(l, var):
-        # int vc_attention(qkv, ld, bstride, vt, out, ldo, out_bstride, kv_len, B, L, Lpad, H, variant, stream)
-        rc = l.vc_attention(C.c_void_p(qkv.data_ptr()), C.c_int64(qkv.stride(0)), C.c_int64(0), C.c_void_p(vt.data_ptr()), C.c_void_p(o.data_ptr()),
-                            C.c_int64(o.stride(0)), C.c_int64(0), C.c_void_p(0), C.c_int32(1), C.c_int32(L), C.c_int32(Lpad), C.c_int32(H), C.c_int32(var),
-                            C.c_void_p(scr.data_ptr()), C.c_int64(scr.numel()), C.c_void_p(stream))
+        a = hip.Attention()
+        a.qkv, a.ld, a.bstride, a.vt, a.out, a.ldo, a.out_bstride = qkv.data_ptr(), qkv.stride(0), 0, vt.data_ptr(), o.data_ptr(), o.stride(0), 0
+        a.B, a.L, a.Lpad, a.H, a.variant = 1, L, Lpad, H, var
+        a.scratch, a.scratch_bytes = scr.data_ptr(), scr.numel()
+        rc = l.vc_attention(C.byref(a), C.c_void_p(stream))
         assert rc == 0, rc
     run(getlib("main"), 1); ref = o.clone()
     for v in variants:

@@ -1,5 +1,6 @@
 """A/B timing of qknorm_rope_vt builds inside one process.   python tools/qkn_ab.py main u4 u8"""
 import sys, os, ctypes as C, torch
+PARTS = int(os.environ.get("VC_QKN_PARTS", "7"))   # 7 = q, k and V^T; 6 = k and V^T only
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from visualcloze_amd import hip
 dev = "cuda:0"
@@ -20,7 +21,7 @@ for v in sys.argv[1:]:
 def run(l):
     rc = l.vc_qknorm_rope_vt(C.c_void_p(qkv.data_ptr()), C.c_int64(qkv.stride(0)), C.c_int64(0), C.c_void_p(qs.data_ptr()), C.c_void_p(ks.data_ptr()),
                              C.c_void_p(0), C.c_void_p(0), C.c_int32(L), C.c_void_p(rope.data_ptr()), C.c_int64(0), C.c_void_p(vt.data_ptr()),
-                             C.c_int32(1), C.c_int32(L), C.c_int32(Lp), C.c_int32(H), C.c_void_p(stream))
+                             C.c_int32(1), C.c_int32(L), C.c_int32(Lp), C.c_int32(H), C.c_int32(PARTS), C.c_void_p(stream))
     assert rc == 0, rc
 tot = {v: 0.0 for v in libs}
 R, n = 6, 20

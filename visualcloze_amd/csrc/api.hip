@@ -15,8 +15,9 @@ extern "C" {
 
 int vc_abi_version(void) { return VC_ABI_VERSION; }
 const char* vc_last_error(void) { return g_err; }
-void vc_struct_sizes(int32_t out[3]) {
+void vc_struct_sizes(int32_t out[4]) {
   out[0] = (int32_t)sizeof(VcGemmProblem); out[1] = (int32_t)sizeof(VcGemmArgs); out[2] = (int32_t)sizeof(VcLnStream);
+  out[3] = (int32_t)sizeof(VcAttention);
 }
 
 int vc_device_count(void) {
@@ -51,14 +52,13 @@ int vc_ln_modulate2(const VcLnStream* a, const VcLnStream* b, int64_t mod_bstrid
 }
 int vc_qknorm_rope_vt(void* qkv, int64_t ld, int64_t bstride, const void* q_scale, const void* k_scale,
                       const void* q_scale2, const void* k_scale2, int32_t split, const float* rope,
-                      int64_t rope_bstride, void* vt, int32_t B, int32_t L, int32_t Lpad, int32_t H, void* stream) {
-  return vc_qknorm_rope_vt_launch(qkv, ld, bstride, q_scale, k_scale, q_scale2, k_scale2, split, rope, rope_bstride, vt, B, L, Lpad, H, S(stream), ERRBUF);
+                      int64_t rope_bstride, void* vt, int32_t B, int32_t L, int32_t Lpad, int32_t H, int32_t parts, void* stream) {
+  return vc_qknorm_rope_vt_launch(qkv, ld, bstride, q_scale, k_scale, q_scale2, k_scale2, split, rope, rope_bstride, vt, B, L, Lpad, H,
+                                  parts, S(stream), ERRBUF);
 }
-int vc_attention(const void* qkv, int64_t ld, int64_t bstride, const void* vt, void* out, int64_t ldo,
-                 int64_t out_bstride, const int32_t* kv_len, int32_t B, int32_t L, int32_t Lpad, int32_t H,
-                 int32_t variant, void* scratch, int64_t scratch_bytes, void* stream) {
-  return vc_attention_launch(qkv, ld, bstride, vt, out, ldo, out_bstride, kv_len, B, L, Lpad, H, variant, scratch, scratch_bytes,
-                             S(stream), ERRBUF);
+int vc_attention(const VcAttention* a, void* stream) {
+  if (!a) { snprintf(g_err, sizeof(g_err), "attention: null args"); return VC_ERR_ARG; }
+  return vc_attention_launch(*a, S(stream), ERRBUF);
 }
 int64_t vc_attention_scratch_bytes(void) { return vc_attention_scratch_bytes_impl(); }
 int vc_timestep_embedding(const float* t, const float* freqs, void* out_bf16, int32_t n, int32_t half,

@@ -391,22 +391,26 @@ int64_t vc_attention_scratch_bytes_impl() {
   return std::max((int64_t)2 * attn_cu_count() * 2 * PART_FLOATS * (int64_t)sizeof(float), vc_attention64_scratch_bytes_impl(attn_cu_count()));
 }
 
-int vc_attention_launch(const void* qkv, int64_t ld, int64_t bstride, const void* vt, void* out, int64_t ldo,
-                        int64_t out_bstride, const int32_t* kv_len, int32_t B, int32_t L, int32_t Lpad,
-                        int32_t H, int32_t variant, void* scratch, int64_t scratch_bytes, hipStream_t s, char* err, int errlen) {
+int vc_attention_launch(const VcAttention& A, hipStream_t s, char* err, int errlen) {
+  const void* qkv = A.qkv; const void* vt = A.vt; void* out = A.out; const int32_t* kv_len = A.kv_len;
+  const int64_t ld = A.ld, bstride = A.bstride, ldo = A.ldo, out_bstride = A.out_bstride;
+  const int32_t B = A.B, L = A.L, Lpad = A.Lpad, H = A.H;
+  int32_t variant = A.variant;
+  void* scratch = A.scratch; const int64_t scratch_bytes = A.scratch_bytes;
   if (!qkv || !vt || !out) { snprintf(err, errlen, "attention: null pointer"); return VC_ERR_ARG; }
   if (B <= 0 || L <= 0 || H <= 0) { snprintf(err, errlen, "attention: empty problem B=%d L=%d H=%d", B, L, H); return VC_ERR_ARG; }
   if (Lpad < L || Lpad % KVB) { snprintf(err, errlen, "attention: Lpad=%d must be a multiple of %d and >= L=%d", Lpad, KVB, L); return VC_ERR_ARG; }
   if (ld % 8 || ldo % 4 || bstride % 8) { snprintf(err, errlen, "attention: strides must keep 16-B row alignment"); return VC_ERR_ARG; }
   if ((uint64_t)128 * (uint64_t)Lpad >= (1ull << 31)) { snprintf(err, errlen, "attention: Lpad too large"); return VC_ERR_ARG; }
   if ((uint64_t)(Lpad + KVB) * (uint64_t)ld * 2ull >= (1ull << 32)) { snprintf(err, errlen, "attention: one sample's K rows exceed 32-bit byte offsets (L=%d ld=%ld)", L, (long)ld); return VC_ERR_ARG; }
+  if (A.q_scale && !(variant & 8)) { snprintf(err, errlen, "attention: in-kernel QKNorm + RoPE of the queries (q_scale) exists for variants 8 / 12 only"); return VC_ERR_ARG; }
+  if (A.q_scale && !A.rope) { snprintf(err, errlen, "attention: q_scale given without a rope table"); return VC_ERR_ARG; }
   AttnArgs a;
   a.qkv = (const bf16_t*)qkv; a.vt = (const bf16_t*)vt; a.out = (bf16_t*)out; a.kv_len = kv_len;
   a.ld = ld; a.bstride = bstride; a.ldo = ldo; a.out_bstride = out_bstride;
   a.B = B; a.L = L; a.Lpad = Lpad; a.H = H;
   if (variant & 8)    // one wave per SIMD, 64 queries per wave (attention64.hip); +4 = tail split
-    return vc_attention64_launch(qkv, ld, bstride, vt, out, ldo, out_bstride, kv_len, B, L, Lpad, H, (variant & 4) != 0, scratch,
-                                 scratch_bytes, attn_cu_count(), g_attn_debug_ts, s, err, errlen);
+    return vc_attention64_launch(A, (variant & 4) != 0, attn_cu_count(), g_attn_debug_ts, s, err, errlen);
   a.debug_ts = g_attn_debug_ts;
   a.full_rounds = -1; a.tail_items = 0; a.tail_units = 0; a.part = (float*)scratch;
   const int lds = 2 * STAGE;

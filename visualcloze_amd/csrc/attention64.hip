@@ -56,6 +56,8 @@ struct Attn64Args {
   int32_t B, L, Lpad, H, qblocks, items;
   int32_t full_rounds, tail_items, tail_units;   // tail split, as attention.hip (full_rounds < 0 = off)
   float* part;
+  // optional in-kernel QKNorm + RoPE of the query rows (q_scale != nullptr): as vc_qknorm_rope_vt
+  const bf16_t* q_scale; const bf16_t* q_scale2; const float* rope; int64_t rope_bstride; int32_t split;
   uint64_t* debug_ts;   // profiling builds only (-DVC_ATTN_TIMESTAMPS): per workgroup (start, end, tiles)
 };
 
@@ -266,18 +268,46 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
     const int q0 = qb_i * QB + wave * QW;
     sfor<0, 2>([&](auto QBc) {
       constexpr int qb = decltype(QBc)::value;
-      const bf16_t* qp = qbase + (long)min(q0 + qb * 32 + lq, L - 1) * a.ld + hh * 8;
+      const int tok = min(q0 + qb * 32 + lq, L - 1);
+      const bf16_t* qp = qbase + (long)tok * a.ld + hh * 8;
       u32x4 raw[8];
 #pragma unroll
       for (int t = 0; t < 8; ++t) raw[t] = *(const u32x4*)(qp + t * 16);
-      sfor<0, 8>([&](auto T) {
-        constexpr int t = decltype(T)::value;
-        sfor<0, 4>([&](auto E) {        // q * (128^-0.5 * log2 e), rounded to bf16 once more: S comes out in the log2 domain
-          constexpr int e = decltype(E)::value;
-          const uint32_t w = raw[t][e];
-          agpr_write<A_Q + (qb * 8 + t) * 4 + e>(__builtin_bit_cast(float, pack2bf(lo_bf(w) * c_scale, hi_bf(w) * c_scale)));
+      if (a.q_scale) {
+        // QKNorm (RMS over the 128 dims of the head: this lane's 64 + its partner's in the other half-wave; layers.py:63-84)
+        // and RoPE (math.py:112-117) on the raw projection output, then the softmax scale; rounding points of the
+        // reference: (x * rrms) -> bf16, * scale -> bf16; the rotated value is rounded ONCE, with the scale folded in
+        float ss = 0.f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float x0 = lo_bf(raw[t][e]), x1 = hi_bf(raw[t][e]); ss += x0 * x0; ss += x1 * x1; }
+        const float rrms = 1.0f / sqrtf(xsum32(ss) * (1.0f / 128.0f) + 1e-6f);
+        const bf16_t* gsc = (tok < a.split ? a.q_scale : a.q_scale2) + hh * 8;
+        const float* rp = a.rope + (long)b * a.rope_bstride + (long)tok * 128 + hh * 8;
+        sfor<0, 8>([&](auto T) {
+          constexpr int t = decltype(T)::value;
+          const u32x4 gw = *(const u32x4*)(gsc + t * 16);
+          const f32x4 c0 = *(const f32x4*)(rp + t * 16), c1 = *(const f32x4*)(rp + t * 16 + 4);
+          const float cs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+          sfor<0, 4>([&](auto E) {
+            constexpr int e = decltype(E)::value;
+            const float x0 = rbf(rbf(lo_bf(raw[t][e]) * rrms) * lo_bf(gw[e])), x1 = rbf(rbf(hi_bf(raw[t][e]) * rrms) * hi_bf(gw[e]));
+            const float co = cs[2 * e], si = cs[2 * e + 1];
+            agpr_write<A_Q + (qb * 8 + t) * 4 + e>(
+                __builtin_bit_cast(float, pack2bf((co * x0 - si * x1) * c_scale, (si * x0 + co * x1) * c_scale)));
+          });
         });
-      });
+      } else {
+        sfor<0, 8>([&](auto T) {
+          constexpr int t = decltype(T)::value;
+          sfor<0, 4>([&](auto E) {        // q * (128^-0.5 * log2 e), rounded to bf16 once more: S comes out in the log2 domain
+            constexpr int e = decltype(E)::value;
+            const uint32_t w = raw[t][e];
+            agpr_write<A_Q + (qb * 8 + t) * 4 + e>(__builtin_bit_cast(float, pack2bf(lo_bf(w) * c_scale, hi_bf(w) * c_scale)));
+          });
+        });
+      }
     });
     sfor<0, 128>([&](auto I) { agpr_write<A_O + decltype(I)::value>(0.f); });
     wait_vm<0>();
@@ -584,15 +614,17 @@ __global__ __launch_bounds__(256) void attn64_merge_kernel(const Attn64Args a, i
 
 int64_t vc_attention64_scratch_bytes_impl(int n_cu) { return (int64_t)n_cu * 2 * PART64_FLOATS * (int64_t)sizeof(float); }
 
-int vc_attention64_launch(const void* qkv, int64_t ld, int64_t bstride, const void* vt, void* out, int64_t ldo,
-                          int64_t out_bstride, const int32_t* kv_len, int32_t B, int32_t L, int32_t Lpad, int32_t H,
-                          bool tail_split, void* scratch, int64_t scratch_bytes, int n_cu, uint64_t* debug_ts, hipStream_t s,
-                          char* err, int errlen) {
+int vc_attention64_launch(const VcAttention& A, bool tail_split, int n_cu, uint64_t* debug_ts, hipStream_t s, char* err, int errlen) {
   Attn64Args a;
   a.debug_ts = debug_ts;
-  a.qkv = (const bf16_t*)qkv; a.vt = (const bf16_t*)vt; a.out = (bf16_t*)out; a.kv_len = kv_len;
-  a.ld = ld; a.bstride = bstride; a.ldo = ldo; a.out_bstride = out_bstride;
-  a.B = B; a.L = L; a.Lpad = Lpad; a.H = H;
+  const int32_t B = A.B, L = A.L, H = A.H;
+  const int32_t* kv_len = A.kv_len;
+  void* scratch = A.scratch; const int64_t scratch_bytes = A.scratch_bytes;
+  a.qkv = (const bf16_t*)A.qkv; a.vt = (const bf16_t*)A.vt; a.out = (bf16_t*)A.out; a.kv_len = kv_len;
+  a.ld = A.ld; a.bstride = A.bstride; a.ldo = A.ldo; a.out_bstride = A.out_bstride;
+  a.B = B; a.L = L; a.Lpad = A.Lpad; a.H = H;
+  a.q_scale = (const bf16_t*)A.q_scale; a.q_scale2 = (const bf16_t*)(A.q_scale2 ? A.q_scale2 : A.q_scale);
+  a.rope = A.rope; a.rope_bstride = A.rope_bstride; a.split = A.q_scale2 ? A.split : L;
   a.qblocks = (L + QB - 1) / QB;
   a.items = a.qblocks * H * B;
   a.full_rounds = -1; a.tail_items = 0; a.tail_units = 0; a.part = (float*)scratch;

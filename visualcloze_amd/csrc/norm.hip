@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_vt_kernel(bf16_t* __restrict_
                                                              const bf16_t* __restrict__ q_scale2,
                                                              const bf16_t* __restrict__ k_scale2, int split,
                                                              const float* __restrict__ rope, long rope_bstride,
-                                                             bf16_t* __restrict__ vt, int L, int Lpad, int H) {
+                                                             bf16_t* __restrict__ vt, int L, int Lpad, int H, int parts) {
   __shared__ uint32_t tl[128 * 33];
   const int tid = threadIdx.x;
   const int t0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_vt_kernel(bf16_t* __restrict_
 
   // ---- phase 1: q and k rows ----
 #pragma unroll 2
-  for (int p = 0; p < 8; ++p) {
+  for (int p = (parts & 1) ? 0 : 4; p < ((parts & 2) ? 8 : 4); ++p) {
     const int rowid = p * 16 + (tid >> 4);
     const int which = rowid >> 6;  // 0 = q, 1 = k
     const int tok = t0 + (rowid & 63);
@@ -139,6 +139,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_vt_kernel(bf16_t* __restrict_
   }
 
   // ---- phase 2: V tile [64 tok][128 d] -> vt[d][t0 .. t0+63] ----
+  if (!(parts & 4)) return;
   const bf16_t* vbase = base + 2 * (H * 128);
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -209,15 +210,16 @@ int vc_ln_modulate_launch(const void* x, int64_t ldx, void* y, int64_t ldy, cons
 
 int vc_qknorm_rope_vt_launch(void* qkv, int64_t ld, int64_t bstride, const void* q_scale, const void* k_scale,
                              const void* q_scale2, const void* k_scale2, int32_t split, const float* rope, int64_t rope_bstride, void* vt, int32_t B, int32_t L, int32_t Lpad,
-                             int32_t H, hipStream_t s, char* err, int errlen) {
+                             int32_t H, int32_t parts, hipStream_t s, char* err, int errlen) {
   if (!qkv || !q_scale || !k_scale || !rope || !vt) { snprintf(err, errlen, "qknorm_rope_vt: null pointer"); return VC_ERR_ARG; }
+  if (parts <= 0 || parts > 7) { snprintf(err, errlen, "qknorm_rope_vt: parts=%d must be a non-empty subset of VC_QKN_Q | VC_QKN_K | VC_QKN_VT", parts); return VC_ERR_ARG; }
   if (!q_scale2 || !k_scale2) { q_scale2 = q_scale; k_scale2 = k_scale; split = L; }
   if (B <= 0 || L <= 0 || H <= 0) { snprintf(err, errlen, "qknorm_rope_vt: empty problem"); return VC_ERR_ARG; }
   if (Lpad < L || Lpad % 64 || ld % 8 || bstride % 8) { snprintf(err, errlen, "qknorm_rope_vt: Lpad=%d must be a multiple of 64 >= L=%d; ld, bstride multiples of 8", Lpad, L); return VC_ERR_ARG; }
   const dim3 grid((L + 63) / 64, H, B), block(256);
   hipLaunchKernelGGL(qknorm_rope_vt_kernel, grid, block, 0, s, (bf16_t*)qkv, (long)ld, (long)bstride,
                      (const bf16_t*)q_scale, (const bf16_t*)k_scale, (const bf16_t*)q_scale2, (const bf16_t*)k_scale2, split,
-                     rope, (long)rope_bstride, (bf16_t*)vt, L, Lpad, H);
+                     rope, (long)rope_bstride, (bf16_t*)vt, L, Lpad, H, parts);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { snprintf(err, errlen, "qknorm_rope_vt launch: %s", hipGetErrorString(e)); return VC_ERR_HIP; }
   return VC_OK;

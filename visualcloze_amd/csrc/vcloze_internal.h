@@ -5,14 +5,9 @@
 #include "../../include/vcloze_hip.h"
 
 int vc_gemm_launch(VcGemmArgs a, int tile_cfg, hipStream_t s, char* err, int errlen);
-int vc_attention_launch(const void* qkv, int64_t ld, int64_t bstride, const void* vt, void* out, int64_t ldo,
-                        int64_t out_bstride, const int32_t* kv_len, int32_t B, int32_t L, int32_t Lpad, int32_t H,
-                        int32_t variant, void* scratch, int64_t scratch_bytes, hipStream_t s, char* err, int errlen);
+int vc_attention_launch(const VcAttention& a, hipStream_t s, char* err, int errlen);
 int64_t vc_attention_scratch_bytes_impl();
-int vc_attention64_launch(const void* qkv, int64_t ld, int64_t bstride, const void* vt, void* out, int64_t ldo,
-                          int64_t out_bstride, const int32_t* kv_len, int32_t B, int32_t L, int32_t Lpad, int32_t H,
-                          bool tail_split, void* scratch, int64_t scratch_bytes, int n_cu, uint64_t* debug_ts, hipStream_t s,
-                          char* err, int errlen);
+int vc_attention64_launch(const VcAttention& a, bool tail_split, int n_cu, uint64_t* debug_ts, hipStream_t s, char* err, int errlen);
 int64_t vc_attention64_scratch_bytes_impl(int n_cu);
 int vc_ln_modulate2_launch(const VcLnStream* a, const VcLnStream* b, int64_t mod_bstride, int32_t D, const int32_t* step_ptr,
                            int64_t mod_step_stride, hipStream_t s, char* err, int errlen);
@@ -21,7 +16,7 @@ int vc_ln_modulate_launch(const void* x, int64_t ldx, void* y, int64_t ldy, cons
                           const int32_t* step_ptr, int64_t mod_step_stride, hipStream_t s, char* err, int errlen);
 int vc_qknorm_rope_vt_launch(void* qkv, int64_t ld, int64_t bstride, const void* q_scale, const void* k_scale,
                              const void* q_scale2, const void* k_scale2, int32_t split, const float* rope, int64_t rope_bstride, void* vt, int32_t B, int32_t L, int32_t Lpad,
-                             int32_t H, hipStream_t s, char* err, int errlen);
+                             int32_t H, int32_t parts, hipStream_t s, char* err, int errlen);
 int vc_temb_launch(const float* t, const float* freqs, void* out, int n, int half, int round_t, hipStream_t s, char* err, int errlen);
 int vc_silu_launch(const void* x, void* y, int64_t n, hipStream_t s, char* err, int errlen);
 int vc_act2d_launch(const void* x, int64_t ldx, void* y, int64_t ldy, int32_t rows, int32_t cols, int32_t act, hipStream_t s,

@@ -116,6 +116,7 @@ class FluxEngine:
         self._ws: Dict[tuple, Workspace] = {}
         self.attn_variant = 12     # one wave per SIMD x 64 queries, tail items cut along the keys (hip.attention; 3 = round-1 kernel)
         self.attn_scratch = hip.attention_scratch(dev)
+        self.fuse_qnorm = True     # variants 8 / 12: QKNorm + RoPE of the queries inside the attention kernel
         self.tile_cfg = 0
         self.stream = torch.cuda.Stream(device=dev)   # capture needs a non-default stream
         self._ref_scratch: Dict[tuple, torch.Tensor] = {}
@@ -194,7 +195,7 @@ class FluxEngine:
         """hipGraph of ONE solver step (Flux evaluation + Euler update + device step-counter increment).
         Everything step-dependent (modulation rows, dt) is indexed on the device by ws.STEP, so the same
         graph replays for every step of every sample batch with this geometry."""
-        key = (ws.ragged, self.attn_variant, self.tile_cfg)
+        key = (ws.ragged, self.attn_variant, self.tile_cfg, self.fuse_qnorm)
         if ws.graph is None or ws.graph_key != key:
             xs = ws.XS.clone()
             self.eval_once(ws, ws.STEP, euler=True, s=s)      # warm-up: sets func attributes outside capture
@@ -299,12 +300,16 @@ class FluxEngine:
         self._gemm(ps, epi=hip.EPI_GATE_RES, step_ptr=c.step_ptr, gate_step_stride=c.mss, s=c.s)
 
     def _attention(self, c, scales, split):
-        """QKNorm + RoPE (+ V^T) and the joint attention over ws.QKV -> CAT[:, :D] (layers.py:165-185 / 236-241)."""
+        """QKNorm + RoPE (+ V^T) and the joint attention over ws.QKV -> CAT[:, :D] (layers.py:165-185 / 236-241).  With the
+        one-wave-per-SIMD kernel (variants 8 / 12) the query rows are normalised where they are loaded, inside the
+        attention kernel, and the pre-pass touches only K and V."""
         ws, s = c.ws, c.s
         q1, k1, q2, k2 = scales
-        hip.qknorm_rope_vt(ws.QKV, q1, k1, ws.ROPE, ws.VT, ws.L, self.H, stream=s, q_scale2=q2, k_scale2=k2, split=split, B=ws.B)
+        fused_q = bool(self.attn_variant & 8) and self.fuse_qnorm
+        hip.qknorm_rope_vt(ws.QKV, q1, k1, ws.ROPE, ws.VT, ws.L, self.H, stream=s, q_scale2=q2, k_scale2=k2, split=split, B=ws.B,
+                           parts=(hip.QKN_K | hip.QKN_VT) if fused_q else (hip.QKN_Q | hip.QKN_K | hip.QKN_VT))
         hip.attention(ws.QKV, ws.VT, c.ATT, ws.L, self.H, kv_len=c.kvl, variant=self.attn_variant, stream=s, B=ws.B,
-                      scratch=self.attn_scratch)
+                      scratch=self.attn_scratch, q_norm=(q1, q2, split, ws.ROPE) if fused_q else None)
 
     def double_block(self, c, i: int) -> None:
         """DoubleStreamBlock i (layers.py:158-196) on ws.XI / ws.XT, in place."""

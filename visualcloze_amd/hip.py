@@ -50,6 +50,15 @@ class LnStream(C.Structure):
                 ("scale", C.c_void_p), ("rows", C.c_int32), ("rows_per_batch", C.c_int32)]
 
 
+class Attention(C.Structure):
+    """VcAttention of include/vcloze_hip.h."""
+    _fields_ = [("qkv", C.c_void_p), ("ld", C.c_int64), ("bstride", C.c_int64), ("vt", C.c_void_p), ("out", C.c_void_p),
+                ("ldo", C.c_int64), ("out_bstride", C.c_int64), ("kv_len", C.c_void_p),
+                ("B", C.c_int32), ("L", C.c_int32), ("Lpad", C.c_int32), ("H", C.c_int32), ("variant", C.c_int32), ("split", C.c_int32),
+                ("scratch", C.c_void_p), ("scratch_bytes", C.c_int64),
+                ("q_scale", C.c_void_p), ("q_scale2", C.c_void_p), ("rope", C.c_void_p), ("rope_bstride", C.c_int64)]
+
+
 # every symbol include/vcloze_hip.h declares: name -> (restype, argtypes)
 _vp, _i32, _i64 = C.c_void_p, C.c_int32, C.c_int64
 SYMBOLS = {
@@ -61,8 +70,8 @@ SYMBOLS = {
     "vc_gemm": (C.c_int, [C.POINTER(GemmArgs), C.c_int, _vp]),
     "vc_ln_modulate": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp]),
     "vc_ln_modulate2": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i64, _vp]),
-    "vc_qknorm_rope_vt": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp]),
-    "vc_attention": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
+    "vc_qknorm_rope_vt": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "vc_attention": (C.c_int, [C.POINTER(Attention), _vp]),
     "vc_attention_scratch_bytes": (_i64, []),
     "vc_timestep_embedding": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "vc_silu": (C.c_int, [_vp, _vp, _i64, _vp]),
@@ -131,9 +140,9 @@ def lib() -> C.CDLL:
             fn.restype, fn.argtypes = res, args
         if l.vc_abi_version() != ABI_VERSION:
             raise VclozeHipError(f"libvcloze_hip.so ABI version {l.vc_abi_version()} != {ABI_VERSION} expected by hip.py - rebuild")
-        sizes = (C.c_int32 * 3)()
+        sizes = (C.c_int32 * 4)()
         l.vc_struct_sizes(sizes)          # a stale library whose structs disagree with these ctypes mirrors must not run
-        if list(sizes) != [C.sizeof(GemmProblem), C.sizeof(GemmArgs), C.sizeof(LnStream)]:
+        if list(sizes) != [C.sizeof(GemmProblem), C.sizeof(GemmArgs), C.sizeof(LnStream), C.sizeof(Attention)]:
             raise VclozeHipError(f"libvcloze_hip.so struct sizes {list(sizes)} differ from the ctypes mirrors - rebuild")
         _lib = l
     return _lib
@@ -247,9 +256,13 @@ def ln_modulate2(streams, step_ptr=None, mod_step_stride=0, stream=None, mod_bst
                                  _p(step_ptr), mod_step_stride, stream if stream is not None else cur_stream()), "vc_ln_modulate2")
 
 
-def qknorm_rope_vt(qkv, q_scale, k_scale, rope, vt, L, H, stream=None, q_scale2=None, k_scale2=None, split=0, B=1):
+QKN_Q, QKN_K, QKN_VT = 1, 2, 4
+
+
+def qknorm_rope_vt(qkv, q_scale, k_scale, rope, vt, L, H, stream=None, q_scale2=None, k_scale2=None, split=0, B=1,
+                   parts=QKN_Q | QKN_K | QKN_VT):
     """qkv: [L, >=3*H*128] rows (q|k|v at column 0, H*128, 2*H*128); rope: [L,64,2] f32; vt: [H,128,Lpad].
-    rows < split use (q_scale, k_scale), the rest (q_scale2, k_scale2) when given."""
+    rows < split use (q_scale, k_scale), the rest (q_scale2, k_scale2) when given.  parts: which of q / k / V^T to do."""
     _bf16(qkv, "qkv")
     if rope.dtype != torch.float32 or not rope.is_contiguous():
         raise VclozeHipError("rope table must be contiguous f32 [B?,L,64,2]")
@@ -257,7 +270,7 @@ def qknorm_rope_vt(qkv, q_scale, k_scale, rope, vt, L, H, stream=None, q_scale2=
     # B > 1: qkv rows are sample-major ([B*L, ld]), rope [B,L,64,2], vt [B,H,128,Lpad]
     _check(lib().vc_qknorm_rope_vt(qkv.data_ptr(), qkv.stride(0), L * qkv.stride(0), q_scale.data_ptr(), k_scale.data_ptr(),
                                    _p(q_scale2), _p(k_scale2), split, rope.data_ptr(), L * 128 if rope.dim() == 4 else 0,
-                                   vt.data_ptr(), B, L, Lpad, H,
+                                   vt.data_ptr(), B, L, Lpad, H, parts,
                                    stream if stream is not None else cur_stream()), "vc_qknorm_rope_vt")
 
 
@@ -273,18 +286,28 @@ def attention_scratch(device) -> torch.Tensor:
     return _attn_scratch[key]
 
 
-def attention(qkv, vt, out, L, H, kv_len=None, variant=0, stream=None, B=1, scratch=None):
+def attention(qkv, vt, out, L, H, kv_len=None, variant=0, stream=None, B=1, scratch=None, q_norm=None):
     """out: [B*L, >=H*128] rows (B L (H D)), sample-major like qkv; kv_len: optional int32 device tensor [B];
-    scratch: uint8 device buffer of >= vc_attention_scratch_bytes() for variant 7 (taken from attention_scratch()
-    when omitted)."""
+    scratch: uint8 device buffer of >= vc_attention_scratch_bytes() for the tail split (taken from attention_scratch()
+    when omitted); q_norm = (q_scale, q_scale2 | None, split, rope): QKNorm + RoPE of the RAW query rows inside the kernel
+    (variants 8 / 12; the pre-pass then runs with parts = QKN_K | QKN_VT)."""
     _bf16(qkv, "qkv"); _bf16(vt, "vt"); _bf16(out, "out")
-    Lpad = vt.shape[-1]
     if scratch is None and variant & 4:
         scratch = attention_scratch(qkv.device)
-    _check(lib().vc_attention(qkv.data_ptr(), qkv.stride(0), L * qkv.stride(0), vt.data_ptr(), out.data_ptr(),
-                              out.stride(0), L * out.stride(0), _p(kv_len), B, L, Lpad, H, variant,
-                              _p(scratch), scratch.numel() if scratch is not None else 0,
-                              stream if stream is not None else cur_stream()), "vc_attention")
+    a = Attention()
+    a.qkv, a.ld, a.bstride = qkv.data_ptr(), qkv.stride(0), L * qkv.stride(0)
+    a.vt, a.out, a.ldo, a.out_bstride = vt.data_ptr(), out.data_ptr(), out.stride(0), L * out.stride(0)
+    a.kv_len = _p(kv_len)
+    a.B, a.L, a.Lpad, a.H, a.variant = B, L, vt.shape[-1], H, variant
+    a.scratch, a.scratch_bytes = _p(scratch), scratch.numel() if scratch is not None else 0
+    if q_norm is not None:
+        qs, qs2, split, rope = q_norm
+        _bf16(qs, "q_scale")
+        if rope.dtype != torch.float32 or not rope.is_contiguous():
+            raise VclozeHipError("rope table must be contiguous f32 [B?,L,64,2]")
+        a.q_scale, a.q_scale2, a.split = qs.data_ptr(), _p(qs2), split
+        a.rope, a.rope_bstride = rope.data_ptr(), L * 128 if rope.dim() == 4 else 0
+    _check(lib().vc_attention(C.byref(a), stream if stream is not None else cur_stream()), "vc_attention")
 
 
 def timestep_embedding(t_f32, freqs_f32, out_bf16, round_t_bf16=False, stream=None):

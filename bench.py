@@ -225,17 +225,19 @@ def roofline_attention(job, iters=3):
     eng, ws = job.eng, job.ws
     s = job.s
     with torch.cuda.stream(eng.stream):
-        hip.attention(ws.QKV, ws.VT, ws.CAT[:, :eng.D], ws.L, eng.H, variant=eng.attn_variant, stream=s, B=ws.B,
+        hip.attention(ws.QKV, ws.VT, ws.CAT[:, :eng.D], ws.L, eng.H, variant=eng.attention_variant(ws), stream=s, B=ws.B,
                       scratch=eng.attn_scratch)
         e0, e1 = hip.Event(), hip.Event()
         e0.record(s)
         for _ in range(iters * 10):
-            hip.attention(ws.QKV, ws.VT, ws.CAT[:, :eng.D], ws.L, eng.H, variant=eng.attn_variant, stream=s, B=ws.B,
+            hip.attention(ws.QKV, ws.VT, ws.CAT[:, :eng.D], ws.L, eng.H, variant=eng.attention_variant(ws), stream=s, B=ws.B,
                       scratch=eng.attn_scratch)
         e1.record(s)
         ms = e0.elapsed_ms(e1) / (iters * 10)
     fl = 4.0 * ws.L * ws.L * eng.D * ws.B
-    return dict(kernel="attn_fwd_kernel", avg_launch_us=round(ms * 1e3, 2), achieved=round(fl / ms / 1e9, 1),
+    v = eng.attention_variant(ws)
+    return dict(kernel="attn64_kernel (+ attn64_merge_kernel)" if v & 8 else "attn_fwd_kernel", variant=v,
+                avg_launch_us=round(ms * 1e3, 2), achieved=round(fl / ms / 1e9, 1),
                 unit="TFLOP/s", frac=round(fl / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4))
 
 

@@ -60,6 +60,26 @@ def test_forward_b1_vs_golden_and_oracle(model, golden):
     assert rel_l2(got, _oracle(sd, inp, torch.tensor([0.7]))) < TOL_ORACLE
 
 
+@pytest.mark.parametrize("variant,fuse", [(12, True), (12, False), (8, True), (3, False), (7, False)])
+def test_forward_every_attention_route_vs_golden(golden, variant, fuse):
+    """The engine picks the attention kernel by size (tiny grids -> the 32-queries-per-wave kernel); here every route is
+    forced on the tiny model: the one-wave-per-SIMD kernel with and without the in-kernel query norm, with and without the
+    tail split, and the round-1 kernel - each against the reference's own forward (B = 1 and ragged B = 2)."""
+    from tests.helpers import tiny_model
+    from tests.procedural import tiny_inputs
+    m, sd = tiny_model()
+    eng = m.engine()
+    eng.attn_variant, eng.fuse_qnorm = variant, fuse
+    inp = tiny_inputs(B=1)
+    got = _fwd(m, inp, torch.tensor([0.7]))
+    assert rel_l2(got, golden["flux_b1"]) < TOL_GOLDEN
+    assert rel_l2(got, _oracle(sd, inp, torch.tensor([0.7]))) < TOL_ORACLE
+    inp2 = tiny_inputs(B=2, seed=7)
+    inp2["img_mask"][1, -12:] = 0
+    got2 = _fwd(m, inp2, torch.tensor([0.9, 0.25])).float().cpu()
+    assert rel_l2(got2, torch.tensor(golden["flux_b2"])) < TOL_GOLDEN
+
+
 def test_unmerged_lora_mode_vs_reference_bf16_run(golden):
     """lora_mode="ref" executes LinearLora.forward as the reference does (base GEMM, two skinny GEMMs, three bf16
     roundings - models/modules/lora.py:92-98) instead of the merged weight.  It tracks the reference's OWN bf16 run

@@ -71,9 +71,13 @@ constexpr int QB = 4 * QW;                          // queries per work item
 
 constexpr int A_O = 0, A_Q = 128, A_K = 192;        // AGPR map
 
-// one partial result of the tail split: [wave 4][32 groups][lane 64][4] f32 + [wave 4][qb 2][lane 64] (m, l)
-constexpr int PART64_O = 4 * 32 * 64 * 4;
-constexpr int PART64_FLOATS = PART64_O + 4 * 2 * 64 * 2;
+// one partial result of the tail split: O^T fragments NORMALISED by the piece's own row sums, as f16 (11-bit mantissa:
+// 8x finer than the bf16 output; values are convex combinations of V) [wave 4][qb 2][16 groups][lane 64][4 x f16],
+// then [wave 4][qb 2][lane 64] (m, l) in f32.  Half the bytes of f32 accumulators: the pieces are written once and read
+// once through the Infinity Cache, 17 MB each way at cfg 2.
+constexpr int PART64_O_BYTES = 4 * 2 * 16 * 64 * 8;
+constexpr int PART64_BYTES = PART64_O_BYTES + 4 * 2 * 64 * 8;
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 VC_DEV int chunk_begin64(int c, int units, int chunks) { return (int)(((long)c * units) / chunks); }
 
 VC_DEV int swap23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
@@ -392,7 +396,9 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
     auto qk_step = [&](f32x16& Sx, auto Cc, auto Tc, const u32x4& kaug) {
       constexpr int c = decltype(Cc)::value, qb = c >> 1, u = c & 1, t = decltype(Tc)::value;
       if constexpr (t < 8) mfma_qk<A_K + (u * 8 + t) * 4, A_Q + (qb * 8 + t) * 4, t == 0>(Sx);
+#ifndef VC_A64_NO_AUG       // analysis builds only (wrong results)
       else mfma_aug(Sx, kaug, qaug[qb]);
+#endif
     };
 
     // ---- first tile, not overlapped: S(kt0) = K(kt0) . Q^T (m = 0), its row max, K(kt0+1) fragments ----
@@ -484,7 +490,9 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
         if constexpr (g == 10) decide0();
         if constexpr (g == 11) decide1(I0{});
         if constexpr (g == 12) decide1(I1{});
+#ifndef VC_A64_NO_AUG
         if constexpr (g == 13) decide2(std::integral_constant<int, (BASE + 4) % 6>{}, false);
+#endif
 #endif
 #ifndef VC_A64_NO_LDS
         if constexpr ((g & 1) && g < 16) {          // V^T fragment (dt + 2, s) into the register (dt, s) just retired
@@ -519,18 +527,21 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
 
     // ---- epilogue ----
     asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");     // ring quiet, last P.V MFMAs retired
-    if (piece >= 0) {          // part of an item's keys only: un-normalised O^T fragments + (m, l), merged by attn64_merge_kernel
-      float* pp = a.part + (long)piece * PART64_FLOATS;
-      sfor<0, 32>([&](auto Gq) {
-        constexpr int g = decltype(Gq)::value;
-        f32x4 w = {agpr_read<A_O + g * 4 + 0>(), agpr_read<A_O + g * 4 + 1>(), agpr_read<A_O + g * 4 + 2>(), agpr_read<A_O + g * 4 + 3>()};
-        *(f32x4*)(pp + ((wave * 32 + g) * 64 + lane) * 4) = w;
+    if (piece >= 0) {          // part of an item's keys only: (O / l, m, l) of this key range, merged by attn64_merge_kernel
+      char* pp = (char*)a.part + (long)piece * PART64_BYTES;
+      sfor<0, 2>([&](auto QBc) {
+        constexpr int qb = decltype(QBc)::value;
+        const float l_tot = xsum32(l_acc[qb]);
+        const float inv = 1.0f / l_tot;
+        sfor<0, 16>([&](auto Gq) {
+          constexpr int g = decltype(Gq)::value, A0 = A_O + (qb * 4 + (g >> 2)) * 16 + (g & 3) * 4;
+          const f16x4 w = {(_Float16)(agpr_read<A0 + 0>() * inv), (_Float16)(agpr_read<A0 + 1>() * inv),
+                           (_Float16)(agpr_read<A0 + 2>() * inv), (_Float16)(agpr_read<A0 + 3>() * inv)};
+          *(f16x4*)(pp + (((wave * 2 + qb) * 16 + g) * 64 + lane) * 8) = w;
+        });
+        const f32x2 ml = {m_run[qb], l_tot};
+        *(f32x2*)(pp + PART64_O_BYTES + ((wave * 2 + qb) * 64 + lane) * 8) = ml;
       });
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb) {
-        f32x2 ml = {m_run[qb], xsum32(l_acc[qb])};
-        *(f32x2*)(pp + PART64_O + ((wave * 2 + qb) * 64 + lane) * 2) = ml;
-      }
     } else {
       sfor<0, 2>([&](auto QBc) {
         constexpr int qb = decltype(QBc)::value;
@@ -559,9 +570,10 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
 #endif
 }
 
-// Combines the pieces of the tail items (see attention.hip::attn_merge_kernel); thread layout = the writer's.
+// Combines the pieces of the tail items: out = sum_p w_p (O_p / l_p) / sum_p w_p, w_p = l_p 2^(m_p - max m).  One
+// workgroup per (tail item, query block of the wave); thread layout = the writer's.
 __global__ __launch_bounds__(256) void attn64_merge_kernel(const Attn64Args a, int G) {
-  const int it = blockIdx.x;
+  const int it = blockIdx.x >> 1, qb = blockIdx.x & 1;
   const int nkt = (a.L + KVB - 1) / KVB;
   const int u0 = it * nkt, u1 = u0 + nkt;
   int c = (int)(((long)u0 * G) / a.tail_units);
@@ -574,45 +586,52 @@ __global__ __launch_bounds__(256) void attn64_merge_kernel(const Attn64Args a, i
   const int id = xcd_remap(item, a.items);
   const int qb_i = id % a.qblocks, bh = id / a.qblocks;
   const int h = bh % a.H, b = bh / a.H;
-  for (int qb = 0; qb < 2; ++qb) {
-    float m = -INFINITY;
-    for (int cc = c; cc < G && chunk_begin64(cc, a.tail_units, G) < u1; ++cc) {
-      if (chunk_begin64(cc + 1, a.tail_units, G) == chunk_begin64(cc, a.tail_units, G)) continue;
-      const int piece = cc * 2 + (it - chunk_begin64(cc, a.tail_units, G) / nkt);
-      m = fmaxf(m, a.part[(long)piece * PART64_FLOATS + PART64_O + ((wave * 2 + qb) * 64 + lane) * 2]);
-    }
-    f32x4 acc[16];
+  const char* base = (const char*)a.part;
+  const long ml_off = PART64_O_BYTES + ((wave * 2 + qb) * 64 + lane) * 8;
+  float m = -INFINITY;
+  for (int cc = c; cc < G && chunk_begin64(cc, a.tail_units, G) < u1; ++cc) {
+    if (chunk_begin64(cc + 1, a.tail_units, G) == chunk_begin64(cc, a.tail_units, G)) continue;   // empty chunk (fewer units than blocks)
+    const int piece = cc * 2 + (it - chunk_begin64(cc, a.tail_units, G) / nkt);
+    m = fmaxf(m, *(const float*)(base + (long)piece * PART64_BYTES + ml_off));
+  }
+  float acc[16][4];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float l = 0.f;
-    for (int cc = c; cc < G && chunk_begin64(cc, a.tail_units, G) < u1; ++cc) {
-      if (chunk_begin64(cc + 1, a.tail_units, G) == chunk_begin64(cc, a.tail_units, G)) continue;
-      const int piece = cc * 2 + (it - chunk_begin64(cc, a.tail_units, G) / nkt);
-      const float* pp = a.part + (long)piece * PART64_FLOATS;
-      const f32x2 ml = *(const f32x2*)(pp + PART64_O + ((wave * 2 + qb) * 64 + lane) * 2);
-      const float sc = __builtin_amdgcn_exp2f(ml[0] - m);
-      l += ml[1] * sc;
+  for (int i = 0; i < 16; ++i)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] += *(const f32x4*)(pp + ((wave * 32 + qb * 16 + i) * 64 + lane) * 4) * sc;
-    }
-    const int q = qb_i * QB + wave * QW + qb * 32 + lq;
-    if (q < a.L) {
-      const float inv = 1.0f / l;
-      bf16_t* orow = a.out + (long)b * a.out_bstride + (long)q * a.ldo + h * 128;
+    for (int e = 0; e < 4; ++e) acc[i][e] = 0.f;
+  float wsum = 0.f;
+  for (int cc = c; cc < G && chunk_begin64(cc, a.tail_units, G) < u1; ++cc) {
+    if (chunk_begin64(cc + 1, a.tail_units, G) == chunk_begin64(cc, a.tail_units, G)) continue;
+    const int piece = cc * 2 + (it - chunk_begin64(cc, a.tail_units, G) / nkt);
+    const char* pp = base + (long)piece * PART64_BYTES;
+    f16x4 v[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        u32x2 w;
-        w[0] = pack2bf(acc[i][0] * inv, acc[i][1] * inv);
-        w[1] = pack2bf(acc[i][2] * inv, acc[i][3] * inv);
-        *(u32x2*)(orow + (i >> 2) * 32 + (i & 3) * 8 + hh * 4) = w;
-      }
+    for (int i = 0; i < 16; ++i) v[i] = *(const f16x4*)(pp + (((wave * 2 + qb) * 16 + i) * 64 + lane) * 8);
+    const f32x2 ml = *(const f32x2*)(pp + ml_off);
+    const float w = ml[1] * __builtin_amdgcn_exp2f(ml[0] - m);
+    wsum += w;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][e] += w * (float)v[i][e];
+  }
+  const int q = qb_i * QB + wave * QW + qb * 32 + lq;
+  if (q < a.L) {
+    const float inv = 1.0f / wsum;
+    bf16_t* orow = a.out + (long)b * a.out_bstride + (long)q * a.ldo + h * 128;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      u32x2 w;
+      w[0] = pack2bf(acc[i][0] * inv, acc[i][1] * inv);
+      w[1] = pack2bf(acc[i][2] * inv, acc[i][3] * inv);
+      *(u32x2*)(orow + (i >> 2) * 32 + (i & 3) * 8 + hh * 4) = w;
     }
   }
 }
 
 }  // namespace
 
-int64_t vc_attention64_scratch_bytes_impl(int n_cu) { return (int64_t)n_cu * 2 * PART64_FLOATS * (int64_t)sizeof(float); }
+int64_t vc_attention64_scratch_bytes_impl(int n_cu) { return (int64_t)n_cu * 2 * PART64_BYTES; }
 
 int vc_attention64_launch(const VcAttention& A, bool tail_split, int n_cu, uint64_t* debug_ts, hipStream_t s, char* err, int errlen) {
   Attn64Args a;
@@ -642,7 +661,7 @@ int vc_attention64_launch(const VcAttention& A, bool tail_split, int n_cu, uint6
   if (tail_split && !kv_len && tail > 0 && scratch && scratch_bytes >= vc_attention64_scratch_bytes_impl(n_cu) && split_tiles + 4 < nkt) {
     a.full_rounds = rounds; a.tail_items = tail; a.tail_units = tail * nkt;
     hipLaunchKernelGGL(attn64_kernel, dim3(G), dim3(256), LDS64, s, a);
-    hipLaunchKernelGGL(attn64_merge_kernel, dim3(tail), dim3(256), 0, s, a, G);
+    hipLaunchKernelGGL(attn64_merge_kernel, dim3(tail * 2), dim3(256), 0, s, a, G);
   } else {
     hipLaunchKernelGGL(attn64_kernel, dim3(std::min(a.items, G)), dim3(256), LDS64, s, a);
   }

@@ -114,7 +114,11 @@ class FluxEngine:
         self.H = geom.num_heads
         self.mlp = int(geom.hidden_size * geom.mlp_ratio)
         self._ws: Dict[tuple, Workspace] = {}
-        self.attn_variant = 12     # one wave per SIMD x 64 queries, tail items cut along the keys (hip.attention; 3 = round-1 kernel)
+        # hip.attention variant; None = by size: the one-wave-per-SIMD kernel (12: 4 waves x 64 queries per work item, tail
+        # items cut along the keys) once there is at least one 256-query item per CU, the 32-queries-per-wave kernel (3)
+        # below that (measured: L = 1664 -> 52 vs 60 us; L = 3968 -> 196 vs 183; 6656 -> 495 vs 455; 7424 -> 679 vs 581)
+        self.attn_variant = None
+        self.n_cu = hip.device_cus(dev)
         self.attn_scratch = hip.attention_scratch(dev)
         self.fuse_qnorm = True     # variants 8 / 12: QKNorm + RoPE of the queries inside the attention kernel
         self.tile_cfg = 0
@@ -299,16 +303,22 @@ class FluxEngine:
             ps.append(self._prob(n_, a_, o_, res=o_, gate=g_, rows_per_batch=rpb, gate_bstride=c.nm, **av))
         self._gemm(ps, epi=hip.EPI_GATE_RES, step_ptr=c.step_ptr, gate_step_stride=c.mss, s=c.s)
 
+    def attention_variant(self, ws: Workspace) -> int:
+        if self.attn_variant is not None:
+            return self.attn_variant
+        return 12 if ((ws.L + 255) // 256) * self.H * ws.B >= self.n_cu else 3
+
     def _attention(self, c, scales, split):
         """QKNorm + RoPE (+ V^T) and the joint attention over ws.QKV -> CAT[:, :D] (layers.py:165-185 / 236-241).  With the
         one-wave-per-SIMD kernel (variants 8 / 12) the query rows are normalised where they are loaded, inside the
         attention kernel, and the pre-pass touches only K and V."""
         ws, s = c.ws, c.s
         q1, k1, q2, k2 = scales
-        fused_q = bool(self.attn_variant & 8) and self.fuse_qnorm
+        variant = self.attention_variant(ws)
+        fused_q = bool(variant & 8) and self.fuse_qnorm
         hip.qknorm_rope_vt(ws.QKV, q1, k1, ws.ROPE, ws.VT, ws.L, self.H, stream=s, q_scale2=q2, k_scale2=k2, split=split, B=ws.B,
                            parts=(hip.QKN_K | hip.QKN_VT) if fused_q else (hip.QKN_Q | hip.QKN_K | hip.QKN_VT))
-        hip.attention(ws.QKV, ws.VT, c.ATT, ws.L, self.H, kv_len=c.kvl, variant=self.attn_variant, stream=s, B=ws.B,
+        hip.attention(ws.QKV, ws.VT, c.ATT, ws.L, self.H, kv_len=c.kvl, variant=variant, stream=s, B=ws.B,
                       scratch=self.attn_scratch, q_norm=(q1, q2, split, ws.ROPE) if fused_q else None)
 
     def double_block(self, c, i: int) -> None:

@@ -158,6 +158,14 @@ def require_gpu() -> None:
         raise VclozeHipError("no ROCm device visible: " + lib().vc_last_error().decode())
 
 
+def device_cus(device=None) -> int:
+    """compute units of the device (256 on MI355X)"""
+    idx = torch.device(device).index if device is not None else torch.cuda.current_device()
+    n = C.c_int()
+    _check(lib().vc_device_info(idx or 0, None, 0, C.byref(n), None), "vc_device_info")
+    return n.value
+
+
 def cur_stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 

@@ -33,6 +33,8 @@ WORKLOADS = {
     "512-grid-2x3": dict(rows=2, row_latent=(64, 192), steps=30),
     "384-grid-1x2": dict(rows=1, row_latent=(48, 96), steps=4),
     "384-grid-3x4": dict(rows=3, row_latent=(48, 192), steps=50),
+    # cfg 5's SDEdit upsample stage of one 1024x1024 target (visualcloze.py:184-234): 10 points from strength 0.4, no shift
+    "1024-sdedit-upsample": dict(rows=1, row_latent=(128, 128), steps=10, t0=0.4, do_shift=False),
 }
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense, MI355X_MICROARCH.md
 
@@ -98,12 +100,12 @@ def make_inputs(dev, wl, seed, B=1):
 class Job:
     """Drives the engine exactly as transport._sample_fused does, but one solver step per call."""
 
-    def __init__(self, model, x, kw, num_points):
+    def __init__(self, model, x, kw, num_points, t0=0.0, do_shift=True):
         from visualcloze_amd.transport import model_times, solver_time_grid
         self.model, self.eng = model, model.engine()
         self.x, self.kw = x, kw
         N, T = x.shape[1], kw["txt"].shape[1]
-        t = solver_time_grid(num_points, N, 0, 1, True, 1)
+        t = solver_time_grid(num_points, N, t0, 1, do_shift, 1)
         self.S = num_points - 1
         self.eval_t = model_times(t, x)
         self.dts = (t[1:] - t[:-1]).contiguous()
@@ -365,7 +367,7 @@ def main(argv=None):
         eng.attn_variant = a.attn_variant
     PB = a.per_gpu_batch
     x, kw = make_inputs(dev, wl, seed=par.sample_seed(0, rank * PB), B=PB)   # seed from the global sample index
-    job = Job(model, x, kw, wl["steps"])
+    job = Job(model, x, kw, wl["steps"], t0=wl.get("t0", 0.0), do_shift=wl.get("do_shift", True))
 
     with torch.cuda.stream(eng.stream):
         elapsed = timed_region(job, a.steps, a.warmup, max_over_ranks=lambda s: par.max_over_ranks(s, dev))
@@ -375,7 +377,8 @@ def main(argv=None):
     T, N = 512, x.shape[1]
     rec = result_record(a, wl, world, elapsed, T, N, bcast_s, weight_bytes)
     rec["numa_node"] = numa
-    rec["hbm_allocated_gb"] = round(torch.cuda.max_memory_allocated(dev) / 1e9, 1)
+    rec["hbm_resident_gb"] = round(torch.cuda.memory_allocated(dev) / 1e9, 1)        # merged weights + workspaces while sampling
+    rec["hbm_peak_gb"] = round(torch.cuda.max_memory_allocated(dev) / 1e9, 1)        # during the one-time LoRA merge
     if rank == 0:
         rec["precompute_ms"] = round(job.precompute_ms(), 3)
         rec["roofline"] = roofline_gemm(job)

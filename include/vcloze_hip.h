@@ -109,7 +109,9 @@ int vc_qknorm_rope_vt(void* qkv, int64_t ld, int64_t bstride, const void* q_scal
 /* Joint text+image attention, non-causal, D=128, softmax scale 128^-0.5 (math.py:63-99 /
  * flash_attn_varlen_func).  q,k from the qkv rows above; vt from vc_qknorm_rope_vt.
  * kv_len[b] (host-visible semantics: keys >= kv_len masked, query rows >= kv_len written as 0,
- * = pad_input of math.py:96); NULL = all L.  out: [B, L, H*128] bf16, row stride ldo.
+ * = pad_input of math.py:96); NULL = all L.  kv_gap (optional, with kv_len): int32 [B][2] = (lo, hi): keys and query rows
+ * lo <= i < hi are masked as well - the padded tail of the TEXT stream in the joint (txt, img) order; with a valid-first
+ * permutation of each stream on the host this covers arbitrary masks (math.py:9-60).  out: [B, L, H*128] bf16, row stride ldo.
  * variant: 0 = 8 waves x 32 queries per workgroup, 1 = 4 waves x 32 queries (two workgroups per CU); +2 = the same
  * kernel on a persistent grid (one workgroup per resident slot, work items assigned statically); variants 0-3 produce
  * bit-identical results.  8 = ONE WAVE PER SIMD, 4 waves x 64 queries, software-pipelined inside the wave
@@ -129,6 +131,7 @@ typedef struct VcAttention {
   int32_t B, L, Lpad, H, variant, split;
   void* scratch; int64_t scratch_bytes;
   const void* q_scale; const void* q_scale2; const float* rope; int64_t rope_bstride;
+  const int32_t* kv_gap;
 } VcAttention;
 int vc_attention(const VcAttention* a, void* stream);
 int64_t vc_attention_scratch_bytes(void);

@@ -133,26 +133,34 @@ def gelu_tanh(x: Tensor) -> Tensor:
     return torch.nn.functional.gelu(x, approximate="tanh")
 
 
-def sdpa(q: Tensor, k: Tensor, v: Tensor, P: Prec, kv_len: Optional[List[int]] = None) -> Tensor:
-    """flash_attn_varlen_func semantics (math.py:85-96): softmax(q k^T * d^-0.5) v over the unpadded
-    keys of each batch element, non-causal; padded query rows come back as zeros (pad_input).
+def sdpa(q: Tensor, k: Tensor, v: Tensor, P: Prec, kv_len=None) -> Tensor:
+    """flash_attn_varlen_func semantics behind `_upad_input` / `pad_input` (math.py:9-60,85-96): softmax(q k^T * d^-0.5) v
+    over the UNMASKED keys of each batch element, for its unmasked query rows; masked query rows come back as zeros.
+    kv_len: None (everything attends), a list of prefix lengths, or a bool / int mask [B, L] (any pattern).
     q,k,v: [B,H,L,D] -> [B,L,H*D]."""
     B, H, L, D = q.shape
     out = torch.zeros(B, L, H * D)
     for b in range(B):
-        n = L if kv_len is None else int(kv_len[b])
+        if kv_len is None:
+            idx = torch.arange(L)
+        elif torch.is_tensor(kv_len) and kv_len.dim() == 2:
+            idx = torch.nonzero(kv_len[b], as_tuple=False).flatten()
+        else:
+            idx = torch.arange(int(kv_len[b]))
+        n = idx.numel()
+        qq, kk, vv = q[b][:, idx].float(), k[b][:, idx].float(), v[b][:, idx].float()
         hc = max(1, min(H, (1 << 28) // max(1, n * n)))     # heads per chunk: score tensors stay <= 1 GiB (L = 7424 fits)
         for h0 in range(0, H, hc):
             hs = slice(h0, min(H, h0 + hc))
-            s = (q[b, hs, :n].float() @ k[b, hs, :n].float().transpose(-1, -2)) * (D ** -0.5)
+            s = (qq[hs] @ kk[hs].transpose(-1, -2)) * (D ** -0.5)
             if P.mode == "bf16":
                 # flash-attn keeps the un-normalised P in bf16 for the PV matmul and divides by the f32 row sum last
                 m = s.max(dim=-1, keepdim=True).values
                 e = torch.exp(s - m)
-                o = (P.r(e) @ v[b, hs, :n].float()) / e.sum(dim=-1, keepdim=True)
+                o = (P.r(e) @ vv[hs]) / e.sum(dim=-1, keepdim=True)
             else:
-                o = torch.softmax(s, dim=-1) @ v[b, hs, :n].float()
-            out[b, :n, h0 * D:(h0 + o.shape[0]) * D] = P.r(o.permute(1, 0, 2).reshape(n, o.shape[0] * D))
+                o = torch.softmax(s, dim=-1) @ vv[hs]
+            out[b, idx, h0 * D:(h0 + o.shape[0]) * D] = P.r(o.permute(1, 0, 2).reshape(n, o.shape[0] * D))
     return out
 
 
@@ -274,8 +282,8 @@ def compute_vec(sd, timesteps, guidance, y, G: FluxGeometry, P: Prec, ls=1.0, gu
 def flux_forward(sd: Dict[str, Tensor], G: FluxGeometry, img, img_ids, txt, txt_ids, timesteps, y,
                  txt_mask=None, img_mask=None, guidance=None, P: Prec = Prec(), lora_scale: float = 1.0,
                  taps: Optional[dict] = None) -> Tensor:
-    """Flux.forward, models/model.py:85-124.  Masks must be prefix masks (ones then zeros), which is all
-    models/sampling.py:41-46,68-70,98 ever produces; the joint mask is cat(txt_mask, img_mask)."""
+    """Flux.forward, models/model.py:85-124; the joint mask is cat(txt_mask, img_mask), any pattern (the reference's
+    callers only produce right-padded ones, models/sampling.py:41-46,68-70,98)."""
     if img.ndim != 3 or txt.ndim != 3:
         raise ValueError("Input img and txt tensors must have 3 dimensions.")
     ls = lora_scale
@@ -284,12 +292,7 @@ def flux_forward(sd: Dict[str, Tensor], G: FluxGeometry, img, img_ids, txt, txt_
     kv_len = None
     if img_mask is not None and txt_mask is not None:
         joint = torch.cat((txt_mask, img_mask), 1)
-        kv_len = [int(v) for v in joint.sum(dim=1)]
-        for b in range(B):  # prefix property of the UNPADDED joint sequence == all ones up to kv_len
-            if not bool(joint[b, : kv_len[b]].all()):
-                raise ValueError("oracle supports prefix masks only")
-        if all(v == T + N for v in kv_len):
-            kv_len = None
+        kv_len = None if bool(joint.all()) else joint.bool()
     img = linear(sd, "img_in", img.float(), P, ls)
     vec = compute_vec(sd, timesteps.float(), None if guidance is None else guidance.float(), y.float(), G, P, ls)
     txt = linear(sd, "txt_in", txt.float(), P, ls)

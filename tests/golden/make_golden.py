@@ -138,6 +138,12 @@ def main():
         out["attn_full"] = RM.attention(q2, k2, v2, pe=pe2, attn_mask=full).numpy()
         out["attn_ragged"] = RM.attention(q2, k2, v2, pe=pe2, attn_mask=ragged).numpy()
         out["attn_ragged_mask"] = ragged.numpy()
+        general = full.clone()            # holes anywhere (math.py:9-60 gathers arbitrary masks)
+        general[0, [3, 4, 17, 39]] = 0
+        general[1, :2] = 0
+        general[1, 20:29] = 0
+        out["attn_general"] = RM.attention(q2, k2, v2, pe=pe2, attn_mask=general).numpy()
+        out["attn_general_mask"] = general.numpy()
         # LinearLora with rank clipped to min(in, out) = 4
         ll = LinearLora(in_features=12, out_features=4, bias=torch.zeros(4), rank=8, dtype=torch.float32,
                         device=torch.device("cpu"), scale=0.5)
@@ -170,6 +176,12 @@ def main():
         inp2["img_mask"][1, -12:] = 0      # second sample is a shorter grid, padded (sampling.py:68-70)
         out["flux_b2_t"] = np.array([0.9, 0.25], dtype=np.float32)
         out["flux_b2"] = fwd(inp2, torch.tensor([0.9, 0.25])).numpy()
+        inp3 = tiny_inputs(B=2, seed=7)   # holes in BOTH streams of sample 1, text padding on sample 0
+        inp3["txt_mask"][0, -5:] = 0
+        inp3["txt_mask"][1, [1, 7, 8]] = 0
+        inp3["img_mask"][1, [0, 5, 6, 13, 23]] = 0
+        out["flux_general_txt_mask"], out["flux_general_img_mask"] = inp3["txt_mask"].numpy(), inp3["img_mask"].numpy()
+        out["flux_general"] = fwd(inp3, torch.tensor([0.9, 0.25])).numpy()
 
         # ---------------- sampler: time grids + trajectories ----------------
         sampler = Sampler(create_transport("Linear", "velocity", do_shift=True))

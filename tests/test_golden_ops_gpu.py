@@ -152,6 +152,40 @@ def test_attention_vs_reference(hip, golden, variant, case):
         assert float(ref[1, n1:].abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize("variant", [0, 3, 8, 12])
+@pytest.mark.parametrize("split", [16, 24])
+def test_attention_general_mask_vs_reference(hip, golden, variant, split):
+    """A mask with holes anywhere (math.py:9-60 gathers arbitrary masks): the sequence is cut into two streams at
+    `split`, MaskLayout moves each stream's valid rows first, the kernel masks [kv_len, L) and the gap (n_txt, split),
+    the rows are scattered back and must equal the reference's `attention(..., attn_mask=general)`."""
+    from visualcloze_amd.model import MaskLayout
+    L = golden["pe_ids"].shape[1]
+    mask = torch.tensor(golden["attn_general_mask"])
+    lay = MaskLayout(mask[:, :split], mask[:, split:], 2, split, L - split)
+    assert lay.perm_t is not None and lay.perm_i is not None
+    sl = slice(0, 2)
+    q2, k2, v2 = (ptensor((2, 2, L, 128), s, q=6) for s in (21, 22, 23))
+    qr, kr = pe_apply(golden["pe"], q2), pe_apply(golden["pe"], k2)
+    rows = torch.stack([_qkv_rows(qr[b], kr[b], v2[b]) for b in range(2)])      # [2, L, 3*H*128], caller order
+    rows = torch.cat((lay.txt_rows(rows[:, :split], sl), lay.img_rows(rows[:, split:], sl)), 1)
+    qkv = bf(rows.reshape(2 * L, -1))
+    Lp = 64
+    vt = torch.zeros(2, H, 128, Lp, dtype=torch.bfloat16, device=DEV)
+    vt[..., :L] = qkv.reshape(2, L, 3, H, 128)[:, :, 2].permute(0, 2, 3, 1)
+    out = torch.full((2 * L, H * 128), float("nan"), dtype=torch.bfloat16, device=DEV)
+    kvl = torch.tensor(lay.kv_len(sl), dtype=torch.int32, device=DEV)
+    gap = torch.tensor(lay.kv_gap(sl), dtype=torch.int32, device=DEV)
+    hip.attention(qkv, vt, out, L, H, kv_len=kvl, variant=variant, B=2, kv_gap=gap)
+    torch.cuda.synchronize()
+    o = out.reshape(2, L, H * 128).float().cpu()
+    inv_t = torch.argsort(lay.perm_t, dim=1)
+    back = torch.cat((torch.gather(o[:, :split], 1, inv_t[..., None].expand(2, split, H * 128)),
+                      lay.img_rows_back(o[:, split:], sl)), 1)
+    ref = torch.tensor(golden["attn_general"])
+    check(back, ref)
+    assert float(back[mask == 0].abs().sum()) == 0.0 and float(ref[mask == 0].abs().sum()) == 0.0
+
+
 def test_rank_clipped_lora_merge_vs_reference(hip, golden):
     """LinearLora (lora.py:34-98) with rank clipped to min(in, out) = 4 and scale 0.5: the product executes the merged
     weight; in = 12 and out = 4 are zero-padded to the GEMM's K % 64 / N % 8 granularity."""

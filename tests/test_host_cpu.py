@@ -118,3 +118,37 @@ def test_model_times_follow_the_state_dtype(golden):
     seen = []
     fn(torch.zeros(1, 24, 2, dtype=torch.bfloat16), lambda x, timesteps, **kw: (seen.append(float(timesteps[0])), x * 0)[1], {})
     assert np.array_equal(np.array(seen), golden["traj_bf16_model_t"])
+
+
+def test_mask_layout_valid_first_permutation():
+    """MaskLayout: any (txt_mask, img_mask) -> per-stream stable valid-first row order + (kv_len, one masked gap); right-
+    padded masks are the identity; img_rows_back undoes img_rows."""
+    import torch
+    from visualcloze_amd.model import MaskLayout
+    B, T, N = 3, 6, 8
+    tm = torch.ones(B, T, dtype=torch.int32)
+    im = torch.ones(B, N, dtype=torch.int32)
+    tm[0, 4:] = 0                      # right-padded
+    im[0, 5:] = 0
+    tm[1, [0, 3]] = 0                  # holes
+    im[1, [2, 7]] = 0
+    lay = MaskLayout(tm, im, B, T, N)
+    assert lay.perm_t[0].tolist() == list(range(T)) and lay.perm_i[0].tolist() == list(range(N))
+    assert lay.perm_t[1].tolist() == [1, 2, 4, 5, 0, 3] and lay.perm_i[1].tolist() == [0, 1, 3, 4, 5, 6, 2, 7]
+    assert lay.kv_len(slice(0, 3)) == [T + 5, T + 6, T + 8]
+    assert lay.kv_gap(slice(0, 3)) == [(4, T), (4, T), (0, 0)] and lay.kv_gap(slice(2, 3)) is None
+    x = torch.arange(B * N * 2, dtype=torch.float32).reshape(B, N, 2)
+    sl = slice(1, 3)
+    px = lay.img_rows(x, sl)
+    assert torch.equal(px[0, :, 0], x[1, lay.perm_i[1], 0]) and torch.equal(px[1], x[2])
+    assert torch.equal(lay.img_rows_back(px, sl), x[sl])
+    ids = torch.arange(B * T * 3).reshape(B, T, 3)
+    assert torch.equal(lay.txt_rows(ids, slice(1, 2))[0], ids[1, lay.perm_t[1]])
+    # prefix masks and no masks: nothing is moved
+    tm2, im2 = torch.ones(2, T), torch.ones(2, N)
+    im2[1, -3:] = 0
+    lay2 = MaskLayout(tm2, im2, 2, T, N)
+    assert lay2.perm_t is None and lay2.perm_i is None and lay2.kv_gap(slice(0, 2)) is None
+    assert lay2.kv_len(slice(0, 2)) == [T + N, T + N - 3]
+    lay3 = MaskLayout(None, None, 2, T, N)
+    assert lay3.kv_len(slice(0, 2)) == [T + N] * 2 and lay3.kv_gap(slice(0, 2)) is None

@@ -55,6 +55,10 @@ def test_attention_full_and_ragged(golden):
     got = O.sdpa(rq, rk, v, F32, kv_len=kv)
     close(got, golden["attn_ragged"])
     assert float(got[1, kv[1]:].abs().max()) == 0.0               # padded query rows -> zeros (pad_input)
+    gm = torch.tensor(golden["attn_general_mask"])                 # holes anywhere: _upad_input gathers any mask
+    got = O.sdpa(rq, rk, v, F32, kv_len=gm)
+    close(got, golden["attn_general"])
+    assert float(got[gm == 0].abs().max()) == 0.0
 
 
 def test_lora_rank_clip(golden):
@@ -88,6 +92,9 @@ def test_flux_forward(golden, tiny_sd):
     inp2 = tiny_inputs(B=2, seed=7)
     inp2["img_mask"][1, -12:] = 0
     close(_fwd(tiny_sd, inp2, torch.tensor(golden["flux_b2_t"]), F32), golden["flux_b2"])
+    inp3 = tiny_inputs(B=2, seed=7)                                # non-prefix masks in both streams
+    inp3["txt_mask"], inp3["img_mask"] = torch.tensor(golden["flux_general_txt_mask"]), torch.tensor(golden["flux_general_img_mask"])
+    close(_fwd(tiny_sd, inp3, torch.tensor(golden["flux_b2_t"]), F32), golden["flux_general"])
 
 
 def test_errors(tiny_sd):

@@ -26,6 +26,7 @@ struct AttnArgs {
   const bf16_t* vt;
   bf16_t* out;
   const int32_t* kv_len;
+  const int32_t* kv_gap;      // optional [B][2]: keys / query rows lo <= i < hi masked too (padded tail of the text stream)
   int64_t ld, bstride, ldo, out_bstride;
   int32_t B, L, Lpad, H, qblocks, items;
   // tail split (variant +4): whole items for `full_rounds` rounds, then the remaining `tail_items` are cut into
@@ -93,6 +94,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs a) 
   const int h = bh % a.H, b = bh / a.H;
   const int L = a.L;
   const int kvlen = a.kv_len ? a.kv_len[b] : L;
+  const int gap_lo = a.kv_gap ? a.kv_gap[2 * b] : 0, gap_hi = a.kv_gap ? a.kv_gap[2 * b + 1] : 0;
 
   const bf16_t* __restrict__ qbase = a.qkv + (long)b * a.bstride + h * 128;
   const bf16_t* __restrict__ kbase = qbase + a.H * 128;
@@ -225,14 +227,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs a) 
 #endif
     }
     stamp();
-    // mask keys beyond kv_len (only the last tile can hold any)
-    if (kt * KVB + KVB > kvlen) {
+    // mask keys beyond kv_len (only the last tile can hold any) and inside the gap (tiles that overlap it)
+    if (kt * KVB + KVB > kvlen || (kt * KVB < gap_hi && kt * KVB + KVB > gap_lo)) {
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = kt * KVB + u * 32 + ((r >> 3) << 4) + hh * 8 + (r & 7);
-          if (key >= kvlen) s[u][r] = -INFINITY;
+          if (key >= kvlen || (key >= gap_lo && key < gap_hi)) s[u][r] = -INFINITY;
         }
     }
     // online softmax (log2 domain)
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs a) 
     f32x2 ml = {m_run, l_tot};
     *(f32x2*)(pp + PART_O + (wave * 64 + lane) * 2) = ml;
   } else if (q < L) {
-    const float inv = (q < kvlen) ? 1.0f / l_tot : 0.0f;  // padded query rows -> 0 (pad_input, math.py:96)
+    const float inv = (q < kvlen && !(q >= gap_lo && q < gap_hi)) ? 1.0f / l_tot : 0.0f;  // padded query rows -> 0 (pad_input, math.py:96)
     bf16_t* orow = a.out + (long)b * a.out_bstride + (long)q * a.ldo + h * 128;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
@@ -404,9 +406,11 @@ int vc_attention_launch(const VcAttention& A, hipStream_t s, char* err, int errl
   if ((uint64_t)128 * (uint64_t)Lpad >= (1ull << 31)) { snprintf(err, errlen, "attention: Lpad too large"); return VC_ERR_ARG; }
   if ((uint64_t)(Lpad + KVB) * (uint64_t)ld * 2ull >= (1ull << 32)) { snprintf(err, errlen, "attention: one sample's K rows exceed 32-bit byte offsets (L=%d ld=%ld)", L, (long)ld); return VC_ERR_ARG; }
   if (A.q_scale && !(variant & 8)) { snprintf(err, errlen, "attention: in-kernel QKNorm + RoPE of the queries (q_scale) exists for variants 8 / 12 only"); return VC_ERR_ARG; }
+  if (A.kv_gap && !kv_len) { snprintf(err, errlen, "attention: kv_gap needs kv_len"); return VC_ERR_ARG; }
   if (A.q_scale && !A.rope) { snprintf(err, errlen, "attention: q_scale given without a rope table"); return VC_ERR_ARG; }
   AttnArgs a;
   a.qkv = (const bf16_t*)qkv; a.vt = (const bf16_t*)vt; a.out = (bf16_t*)out; a.kv_len = kv_len;
+  a.kv_gap = kv_len ? A.kv_gap : nullptr;
   a.ld = ld; a.bstride = bstride; a.ldo = ldo; a.out_bstride = out_bstride;
   a.B = B; a.L = L; a.Lpad = Lpad; a.H = H;
   if (variant & 8)    // one wave per SIMD, 64 queries per wave (attention64.hip); +4 = tail split

@@ -52,6 +52,7 @@ struct Attn64Args {
   const bf16_t* vt;
   bf16_t* out;
   const int32_t* kv_len;
+  const int32_t* kv_gap;      // optional [B][2]: keys / query rows lo <= i < hi masked too
   int64_t ld, bstride, ldo, out_bstride;
   int32_t B, L, Lpad, H, qblocks, items;
   int32_t full_rounds, tail_items, tail_units;   // tail split, as attention.hip (full_rounds < 0 = off)
@@ -233,6 +234,8 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
     const int h = bh % a.H, b = bh / a.H;
     const int L = a.L;
     const int kvlen = a.kv_len ? __builtin_amdgcn_readfirstlane(a.kv_len[b]) : L;
+    const int gap_lo = a.kv_gap ? __builtin_amdgcn_readfirstlane(a.kv_gap[2 * b]) : 0;
+    const int gap_hi = a.kv_gap ? __builtin_amdgcn_readfirstlane(a.kv_gap[2 * b + 1]) : 0;
     const int nkt = (kvlen + KVB - 1) / KVB;
     if (kt1 < 0) kt1 = nkt;
 #ifdef VC_ATTN_TIMESTAMPS
@@ -337,7 +340,8 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
     };
     // k_aug fragment of key block u of tile n: dimension 128 = 1, dimension 129 = (key >= kv_len)
     auto make_kaug = [&](int n, int u) -> u32x4 {
-      const uint32_t m = (n * KVB + u * 32 + krow >= kvlen) ? (0x3f800000u & aug_on) : 0u;
+      const int key = n * KVB + u * 32 + krow;
+      const uint32_t m = (key >= kvlen || (key >= gap_lo && key < gap_hi)) ? (0x3f800000u & aug_on) : 0u;
       return u32x4{kaug_one | m, 0u, 0u, 0u};
     };
     float mxp[4];
@@ -547,7 +551,7 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
         constexpr int qb = decltype(QBc)::value;
         const float l_tot = xsum32(l_acc[qb]);
         const int q = q0 + qb * 32 + lq;
-        const float inv = (q < kvlen) ? 1.0f / l_tot : 0.0f;     // padded query rows -> 0 (pad_input, math.py:96)
+        const float inv = (q < kvlen && !(q >= gap_lo && q < gap_hi)) ? 1.0f / l_tot : 0.0f;     // padded query rows -> 0 (pad_input, math.py:96)
         bf16_t* orow = a.out + (long)b * a.out_bstride + (long)min(q, L - 1) * a.ldo + h * 128;
         sfor<0, 16>([&](auto Gq) {
           constexpr int g = decltype(Gq)::value, dt = g >> 2, gg = g & 3, A0 = A_O + (qb * 4 + dt) * 16 + gg * 4;
@@ -640,6 +644,7 @@ int vc_attention64_launch(const VcAttention& A, bool tail_split, int n_cu, uint6
   const int32_t* kv_len = A.kv_len;
   void* scratch = A.scratch; const int64_t scratch_bytes = A.scratch_bytes;
   a.qkv = (const bf16_t*)A.qkv; a.vt = (const bf16_t*)A.vt; a.out = (bf16_t*)A.out; a.kv_len = kv_len;
+  a.kv_gap = kv_len ? A.kv_gap : nullptr;
   a.ld = A.ld; a.bstride = A.bstride; a.ldo = A.ldo; a.out_bstride = A.out_bstride;
   a.B = B; a.L = L; a.Lpad = A.Lpad; a.H = H;
   a.q_scale = (const bf16_t*)A.q_scale; a.q_scale2 = (const bf16_t*)(A.q_scale2 ? A.q_scale2 : A.q_scale);

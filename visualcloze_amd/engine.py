@@ -24,7 +24,7 @@ HBM layout per geometry (B samples, T text tokens, N image tokens, L = T+N, D hi
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Dict, Optional, Sequence
+from typing import Dict, Optional, Sequence, Tuple
 
 import torch
 
@@ -98,7 +98,9 @@ class Workspace:
         self.DTS = torch.zeros(steps, dtype=torch.float32, device=dev)
         self.STEP = torch.zeros(1, dtype=torch.int32, device=dev)
         self.KVLEN = torch.full((B,), L, dtype=torch.int32, device=dev)
+        self.KVGAP = torch.zeros(B, 2, dtype=torch.int32, device=dev)   # masked tail of the text stream, joint order
         self.ragged = False
+        self.gapped = False
         self.graph: Optional[hip.Graph] = None
         self.graph_key = None
 
@@ -199,7 +201,7 @@ class FluxEngine:
         """hipGraph of ONE solver step (Flux evaluation + Euler update + device step-counter increment).
         Everything step-dependent (modulation rows, dt) is indexed on the device by ws.STEP, so the same
         graph replays for every step of every sample batch with this geometry."""
-        key = (ws.ragged, self.attn_variant, self.tile_cfg, self.fuse_qnorm)
+        key = (ws.ragged, ws.gapped, self.attn_variant, self.tile_cfg, self.fuse_qnorm)
         if ws.graph is None or ws.graph_key != key:
             xs = ws.XS.clone()
             self.eval_once(ws, ws.STEP, euler=True, s=s)      # warm-up: sets func attributes outside capture
@@ -212,17 +214,24 @@ class FluxEngine:
 
     # ------------------------------------------------------------------ per-batch precompute
     def prepare_sample(self, ws: Workspace, txt, y, guidance, guidance_is_bf16: bool, img_ids, txt_ids,
-                       timesteps: torch.Tensor, kv_len: Sequence[int], s=None, timesteps_is_bf16: bool = False) -> None:
+                       timesteps: torch.Tensor, kv_len: Sequence[int], s=None, timesteps_is_bf16: bool = False,
+                       kv_gap: Optional[Sequence[Tuple[int, int]]] = None) -> None:
         """Everything that does not depend on x: txt_in(txt), the vec path and all modulations for every
         (step, sample) (model.py:102-108 + layers.py:120-126 for all 57+1 modules), the RoPE tables.
         txt [B,T,ctx], y [B,vec], guidance [B] or None, img_ids [B,N,3], txt_ids [B,T,3], timesteps [S] (shared by
-        the batch) or [S,B], kv_len: B ints (<= L)."""
+        the batch) or [S,B], kv_len: B ints (<= L); kv_gap: B (lo, hi) pairs, a second masked row range per sample
+        (the padded tail of the text stream once `model.mask_layout` has moved every stream's valid rows first)."""
         W, D, B, S = self.W, self.D, ws.B, ws.steps
         ts = timesteps.to(torch.float32).reshape(S, -1)
         ws.TS.copy_((ts.expand(S, B) if ts.shape[1] == 1 else ts).reshape(-1), non_blocking=True)
         kv = [int(v) for v in kv_len]
         ws.KVLEN.copy_(torch.tensor(kv, dtype=torch.int32), non_blocking=True)
-        ws.ragged = any(v < ws.L for v in kv)
+        gap = [(0, 0)] * B if kv_gap is None else [(int(lo), int(hi)) for lo, hi in kv_gap]
+        if any(not (0 <= lo <= hi <= v) for (lo, hi), v in zip(gap, kv)):
+            raise hip.VclozeHipError(f"kv_gap {gap} must lie inside [0, kv_len) = {kv}")
+        ws.KVGAP.copy_(torch.tensor(gap, dtype=torch.int32), non_blocking=True)
+        ws.gapped = any(hi > lo for lo, hi in gap)
+        ws.ragged = ws.gapped or any(v < ws.L for v in kv)
         # RoPE angles in float64 on the host exactly as math.py:102-109, stored as (cos, sin) f32 per sample
         ids = torch.cat((txt_ids.reshape(B, ws.T, 3), img_ids.reshape(B, ws.N, 3)), dim=1).to("cpu", torch.float64)
         cs = []
@@ -280,6 +289,7 @@ class FluxEngine:
         c.HID_I, c.HID_T = ws.HID[:B * N], ws.HID[B * N:]
         c.ATT = ws.CAT[:, :D]
         c.kvl = ws.KVLEN if ws.ragged else None
+        c.kvgap = ws.KVGAP if ws.gapped else None
         # joint-order views of the first sample's rows + batch strides (row m of a stream -> sample m // rows)
         c.qkv_i = dict(M=B * N, c_rpb=N, c_bstride=L * ws.QKV.stride(0))
         c.qkv_t = dict(M=B * T, c_rpb=T, c_bstride=L * ws.QKV.stride(0))
@@ -319,7 +329,7 @@ class FluxEngine:
         hip.qknorm_rope_vt(ws.QKV, q1, k1, ws.ROPE, ws.VT, ws.L, self.H, stream=s, q_scale2=q2, k_scale2=k2, split=split, B=ws.B,
                            parts=(hip.QKN_K | hip.QKN_VT) if fused_q else (hip.QKN_Q | hip.QKN_K | hip.QKN_VT))
         hip.attention(ws.QKV, ws.VT, c.ATT, ws.L, self.H, kv_len=c.kvl, variant=variant, stream=s, B=ws.B,
-                      scratch=self.attn_scratch, q_norm=(q1, q2, split, ws.ROPE) if fused_q else None)
+                      scratch=self.attn_scratch, q_norm=(q1, q2, split, ws.ROPE) if fused_q else None, kv_gap=c.kvgap)
 
     def double_block(self, c, i: int) -> None:
         """DoubleStreamBlock i (layers.py:158-196) on ws.XI / ws.XT, in place."""

@@ -56,7 +56,8 @@ class Attention(C.Structure):
                 ("ldo", C.c_int64), ("out_bstride", C.c_int64), ("kv_len", C.c_void_p),
                 ("B", C.c_int32), ("L", C.c_int32), ("Lpad", C.c_int32), ("H", C.c_int32), ("variant", C.c_int32), ("split", C.c_int32),
                 ("scratch", C.c_void_p), ("scratch_bytes", C.c_int64),
-                ("q_scale", C.c_void_p), ("q_scale2", C.c_void_p), ("rope", C.c_void_p), ("rope_bstride", C.c_int64)]
+                ("q_scale", C.c_void_p), ("q_scale2", C.c_void_p), ("rope", C.c_void_p), ("rope_bstride", C.c_int64),
+                ("kv_gap", C.c_void_p)]
 
 
 # every symbol include/vcloze_hip.h declares: name -> (restype, argtypes)
@@ -294,7 +295,7 @@ def attention_scratch(device) -> torch.Tensor:
     return _attn_scratch[key]
 
 
-def attention(qkv, vt, out, L, H, kv_len=None, variant=0, stream=None, B=1, scratch=None, q_norm=None):
+def attention(qkv, vt, out, L, H, kv_len=None, variant=0, stream=None, B=1, scratch=None, q_norm=None, kv_gap=None):
     """out: [B*L, >=H*128] rows (B L (H D)), sample-major like qkv; kv_len: optional int32 device tensor [B];
     scratch: uint8 device buffer of >= vc_attention_scratch_bytes() for the tail split (taken from attention_scratch()
     when omitted); q_norm = (q_scale, q_scale2 | None, split, rope): QKNorm + RoPE of the RAW query rows inside the kernel
@@ -306,6 +307,7 @@ def attention(qkv, vt, out, L, H, kv_len=None, variant=0, stream=None, B=1, scra
     a.qkv, a.ld, a.bstride = qkv.data_ptr(), qkv.stride(0), L * qkv.stride(0)
     a.vt, a.out, a.ldo, a.out_bstride = vt.data_ptr(), out.data_ptr(), out.stride(0), L * out.stride(0)
     a.kv_len = _p(kv_len)
+    a.kv_gap = _p(kv_gap)      # int32 [B, 2] device tensor: (lo, hi) of a second masked range (needs kv_len)
     a.B, a.L, a.Lpad, a.H, a.variant = B, L, vt.shape[-1], H, variant
     a.scratch, a.scratch_bytes = _p(scratch), scratch.numel() if scratch is not None else 0
     if q_norm is not None:

@@ -155,6 +155,63 @@ class LastLayer(_NoTorchForward):
         self.adaLN_modulation = _Seq(_Empty(), Linear(hidden_size, 2 * hidden_size))
 
 
+class MaskLayout:
+    """How (txt_mask, img_mask) map onto the kernels' masks.  flash-attn's varlen path (math.py:9-60) drops masked rows
+    of the joint sequence wherever they are; attention does not care about key order (RoPE travels with the row), every
+    other op of Flux.forward is per-row, so each stream's rows are reordered VALID FIRST (stable), which leaves
+        [txt valid | txt masked | img valid | img masked]
+    = a prefix length kv_len = T + n_img plus one masked gap (n_txt, T) per sample, and the result rows are scattered
+    back.  Right-padded masks (all the reference's callers build, sampling.py:41-46,68-70,98) are the identity case."""
+
+    def __init__(self, txt_mask, img_mask, B: int, T: int, N: int):
+        self.B, self.T, self.N = B, T, N
+        self.perm_t = self.perm_i = self.inv_i = None
+        if txt_mask is None or img_mask is None:
+            self.n_txt, self.n_img = [T] * B, [N] * B
+            return
+        tm = txt_mask.reshape(B, T).to("cpu") != 0
+        im = img_mask.reshape(B, N).to("cpu") != 0
+        self.n_txt = [int(v) for v in tm.sum(1)]
+        self.n_img = [int(v) for v in im.sum(1)]
+        pt = torch.sort((~tm).to(torch.uint8), dim=1, stable=True).indices
+        pi = torch.sort((~im).to(torch.uint8), dim=1, stable=True).indices
+        if not torch.equal(pt, torch.arange(T).expand(B, T)):
+            self.perm_t = pt
+        if not torch.equal(pi, torch.arange(N).expand(B, N)):
+            self.perm_i = pi
+            self.inv_i = torch.argsort(pi, dim=1)
+
+    def kv_len(self, sl: slice) -> List[int]:
+        return [self.T + n for n in self.n_img[sl]]
+
+    def kv_gap(self, sl: slice):
+        gaps = [(n, self.T) if n < self.T else (0, 0) for n in self.n_txt[sl]]
+        return gaps if any(hi > lo for lo, hi in gaps) else None
+
+    @staticmethod
+    def _take(x: Tensor, perm, sl: slice) -> Tensor:
+        x = x[sl]
+        if perm is None:
+            return x
+        idx = perm[sl].to(x.device)
+        return torch.gather(x, 1, idx.reshape(idx.shape + (1,) * (x.dim() - 2)).expand(x.shape))
+
+    def txt_rows(self, x: Tensor, sl: slice) -> Tensor:
+        """rows of a [B, T, ...] text-stream tensor (txt, txt_ids) in kernel order"""
+        return self._take(x, self.perm_t, sl)
+
+    def img_rows(self, x: Tensor, sl: slice) -> Tensor:
+        """rows of a [B, N, ...] image-stream tensor (img / x, cond, img_ids) in kernel order"""
+        return self._take(x, self.perm_i, sl)
+
+    def img_rows_back(self, x: Tensor, sl: slice) -> Tensor:
+        """kernel-order [bs, N, ...] image-stream rows back in the caller's order"""
+        if self.inv_i is None:
+            return x
+        idx = self.inv_i[sl].to(x.device)
+        return torch.gather(x, 1, idx.reshape(idx.shape + (1,) * (x.dim() - 2)).expand(x.shape))
+
+
 def per_sample(v: Optional[Tensor], B: int) -> Optional[Tensor]:
     """A per-sample vector [B]; a single value (the pipeline's `guidance = torch.full((1,), cfg)`, visualcloze.py:413)
     broadcasts over the batch as it does in the reference's `vec + guidance_in(...)`."""
@@ -307,16 +364,6 @@ class Flux(nn.Module):
         return self._engine
 
     # ------------------------------------------------------------------ the B1 boundary
-    @staticmethod
-    def _kv_len(txt_mask, img_mask, b, T, N) -> int:
-        if txt_mask is None or img_mask is None:
-            return T + N
-        joint = torch.cat((txt_mask[b], img_mask[b]), 0).to("cpu")
-        n = int(joint.sum())
-        if not bool(joint[:n].all()):
-            raise hip.VclozeHipError("only prefix (right-padded) masks are supported — all models/sampling.py emits")
-        return n
-
     @torch.no_grad()
     def forward(self, img: Tensor, img_ids: Tensor, txt: Tensor, txt_ids: Tensor, timesteps: Tensor, y: Tensor,
                 txt_mask: Tensor = None, img_mask: Tensor = None, guidance: Optional[Tensor] = None) -> Tensor:
@@ -333,17 +380,17 @@ class Flux(nn.Module):
         gbf16 = guidance is not None and guidance.dtype == torch.bfloat16
         guidance = per_sample(guidance, B)
         timesteps = per_sample(timesteps, B)
+        lay = MaskLayout(txt_mask, img_mask, B, T, N)
         for b0 in range(0, B, eng.MAX_BATCH):          # samples of a chunk run as ONE stacked launch sequence
             bs = min(eng.MAX_BATCH, B - b0)
             sl = slice(b0, b0 + bs)
             ws = eng.workspace(T, N, 1, bs)
-            eng.prepare_sample(ws, bf(txt[sl]), bf(y[sl]), None if guidance is None else guidance[sl], gbf16, img_ids[sl],
-                               txt_ids[sl], timesteps[sl].float().reshape(1, bs),
-                               [self._kv_len(txt_mask, img_mask, b, T, N) for b in range(b0, b0 + bs)],
-                               timesteps_is_bf16=timesteps.dtype == torch.bfloat16)
-            ws.XIN.copy_(bf(img[sl]).reshape(bs * N, -1))
+            eng.prepare_sample(ws, bf(lay.txt_rows(txt, sl)), bf(y[sl]), None if guidance is None else guidance[sl], gbf16,
+                               lay.img_rows(img_ids, sl), lay.txt_rows(txt_ids, sl), timesteps[sl].float().reshape(1, bs),
+                               lay.kv_len(sl), timesteps_is_bf16=timesteps.dtype == torch.bfloat16, kv_gap=lay.kv_gap(sl))
+            ws.XIN.copy_(bf(lay.img_rows(img, sl)).reshape(bs * N, -1))
             eng.eval_once(ws, None, euler=False, concat=False)
-            out[sl].copy_(ws.V.reshape(bs, N, -1))
+            out[sl].copy_(lay.img_rows_back(ws.V.reshape(bs, N, -1), sl))
         return out.to(img.dtype) if img.dtype.is_floating_point else out
 
 

@@ -139,8 +139,9 @@ def _sample_fused(flux, x, kw, t, return_trajectory):
     out = torch.empty(B, N, C, dtype=torch.bfloat16, device=dev)
     traj = []
     gbf16 = guidance is not None and guidance.dtype == torch.bfloat16
-    from .model import per_sample
+    from .model import MaskLayout, per_sample
     guidance = per_sample(guidance, B)
+    lay = MaskLayout(kw.get("txt_mask"), kw.get("img_mask"), B, T, N)
     st = eng.stream
     st.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(st):
@@ -149,22 +150,22 @@ def _sample_fused(flux, x, kw, t, return_trajectory):
             bs = min(eng.MAX_BATCH, B - b0)
             sl = slice(b0, b0 + bs)
             ws = eng.workspace(T, N, S, bs)
-            kv_len = [flux._kv_len(kw.get("txt_mask"), kw.get("img_mask"), b, T, N) for b in range(b0, b0 + bs)]
-            eng.prepare_sample(ws, bf(txt[sl]), bf(y[sl]), None if guidance is None else guidance[sl], gbf16,
-                               kw["img_ids"][sl], kw["txt_ids"][sl], eval_t, kv_len, s=s)
+            eng.prepare_sample(ws, bf(lay.txt_rows(txt, sl)), bf(y[sl]), None if guidance is None else guidance[sl], gbf16,
+                               lay.img_rows(kw["img_ids"], sl), lay.txt_rows(kw["txt_ids"], sl), eval_t, lay.kv_len(sl), s=s,
+                               kv_gap=lay.kv_gap(sl))
             ws.DTS.copy_(dts, non_blocking=True)
             ws.STEP.zero_()
-            ws.XS.copy_(bf(x[sl]).reshape(bs * N, C))
-            ws.COND.copy_(bf(cond[sl]).reshape(bs * N, -1))
+            ws.XS.copy_(bf(lay.img_rows(x, sl)).reshape(bs * N, C))     # the state stays in kernel row order for all steps
+            ws.COND.copy_(bf(lay.img_rows(cond, sl)).reshape(bs * N, -1))
             graph = eng.step_graph(ws, s)
             states = []
             for _ in range(S):
                 graph.launch(s)          # one Flux evaluation + Euler update + step counter increment
                 if return_trajectory:
-                    states.append(ws.XS.reshape(bs, N, C).clone())
+                    states.append(lay.img_rows_back(ws.XS.reshape(bs, N, C), sl).clone())
             if return_trajectory:
                 traj.append(torch.stack(states))                  # [S, bs, N, C]
-            out[sl].copy_(ws.XS.reshape(bs, N, C))
+            out[sl].copy_(lay.img_rows_back(ws.XS.reshape(bs, N, C), sl))
     torch.cuda.current_stream().wait_stream(st)
     if return_trajectory:
         full = torch.cat((x.to(dev, torch.bfloat16)[None], torch.cat(traj, dim=1)), dim=0)

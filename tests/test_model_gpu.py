@@ -177,7 +177,12 @@ def test_sampler_general_masks_vs_oracle():
     def model_fn(xin, tm):
         return O.flux_forward(sd, G, xin, inp["img_ids"], inp["txt"], inp["txt_ids"], tm, inp["y"], inp["txt_mask"],
                               inp["img_mask"], inp["guidance"], P=P)
-    states, _ = O.sample_euler(model_fn, inp["x"], inp["cond"], O.time_grid(4, inp["x"].shape[1], True, 1), P)
+    orig = O.compute_vec                   # _kw hands the sampler an f32 guidance tensor
+    O.compute_vec = lambda *a, **k: orig(*a, **{**k, "guidance_is_bf16": False})
+    try:
+        states, _ = O.sample_euler(model_fn, inp["x"], inp["cond"], O.time_grid(4, inp["x"].shape[1], True, 1), P)
+    finally:
+        O.compute_vec = orig
     e_or, e_eager = rel_l2(fused, states[-1]), rel_l2(fused, eager)
     parity_log(f"[tiny, general masks] fused sampler vs bf16 oracle {e_or:.3e}, vs host-driven stepping {e_eager:.3e}")
     assert e_or < 3e-2 and e_eager < 1e-2

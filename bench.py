@@ -98,31 +98,26 @@ def make_inputs(dev, wl, seed, B=1):
 
 
 class Job:
-    """Drives the engine exactly as transport._sample_fused does, but one solver step per call."""
+    """Drives the product path exactly as transport._sample_fused does - the C handle API (vc_flux_prepare /
+    vc_flux_sample_begin / vc_flux_sample_steps) - but one solver step per call, as the timing contract counts steps."""
 
     def __init__(self, model, x, kw, num_points, t0=0.0, do_shift=True):
-        from visualcloze_amd.transport import model_times, solver_time_grid
-        self.model, self.eng = model, model.engine()
-        self.x, self.kw = x, kw
-        N, T = x.shape[1], kw["txt"].shape[1]
-        t = solver_time_grid(num_points, N, t0, 1, do_shift, 1)
+        from visualcloze_amd.transport import solver_time_grid
+        self.model, self.eng, self.h = model, model.engine(), model.handle()
+        if self.h is None:
+            raise SystemExit("bench.py measures the handle path (model.use_handle, merged LoRA)")
+        self.x, self.kw = x.contiguous(), kw
+        self.N, self.T = x.shape[1], kw["txt"].shape[1]
+        self.t = solver_time_grid(num_points, self.N, t0, 1, do_shift, 1)
         self.S = num_points - 1
-        self.eval_t = model_times(t, x)
-        self.dts = (t[1:] - t[:-1]).contiguous()
-        self.ws = self.eng.workspace(T, N, self.S, x.shape[0])
         self.s = self.eng.stream.cuda_stream
         self.step_in_sample = self.S   # forces a prepare on the first step
+        self._ws = None
 
     def begin_sample(self):
-        eng, ws, kw = self.eng, self.ws, self.kw
-        B = self.x.shape[0]
-        eng.prepare_sample(ws, kw["txt"], kw["y"], kw["guidance"], True, kw["img_ids"], kw["txt_ids"], self.eval_t,
-                           [ws.L] * B, s=self.s)
-        ws.DTS.copy_(self.dts, non_blocking=True)
-        ws.STEP.zero_()
-        ws.XS.copy_(self.x.reshape(B * ws.N, -1))
-        ws.COND.copy_(kw["cond"].reshape(B * ws.N, -1))
-        self.graph = eng.step_graph(ws, self.s)
+        kw = self.kw
+        self.h.prepare(kw["txt"], kw["y"], kw["guidance"], True, kw["img_ids"], kw["txt_ids"], self.S, stream=self.s)
+        self.h.sample_begin(self.x, kw["cond"], self.t, True, self.s)
         self.step_in_sample = 0
 
     def restart_sample(self):
@@ -131,8 +126,29 @@ class Job:
     def step(self):
         if self.step_in_sample >= self.S:
             self.begin_sample()
-        self.graph.launch(self.s)
+        self.h.sample_steps(1, self.s)
         self.step_in_sample += 1
+
+    def state(self):
+        out = torch.empty_like(self.x)
+        self.h.sample_end(out, self.s)
+        return out
+
+    @property
+    def ws(self):
+        """A prepared workspace of the Python-ordered engine: operand memory (activations, gates) for the roofline legs,
+        which launch single kernels through the op-level ABI."""
+        if self._ws is None:
+            from visualcloze_amd.transport import model_times
+            kw, B = self.kw, self.x.shape[0]
+            ws = self.eng.workspace(self.T, self.N, self.S, B)
+            self.eng.prepare_sample(ws, kw["txt"], kw["y"], kw["guidance"], True, kw["img_ids"], kw["txt_ids"],
+                                    model_times(self.t, self.x), [ws.L] * B, s=self.s)
+            ws.XS.copy_(self.x.reshape(B * ws.N, -1))
+            ws.COND.copy_(kw["cond"].reshape(B * ws.N, -1))
+            self.eng.eval_once(ws, ws.STEP, euler=False, s=self.s)      # fills the activations the kernels are timed on
+            self._ws = ws
+        return self._ws
 
     def precompute_ms(self, iters=3):
         """wall time of one begin_sample() (host RoPE table + H2D, txt_in, vec path, the all-steps modulation GEMM)"""
@@ -371,7 +387,9 @@ def main(argv=None):
 
     with torch.cuda.stream(eng.stream):
         elapsed = timed_region(job, a.steps, a.warmup, max_over_ranks=lambda s: par.max_over_ranks(s, dev))
-    final = job.ws.XS.float()
+    with torch.cuda.stream(eng.stream):
+        final = job.state().float()
+    torch.cuda.synchronize()
     assert torch.isfinite(final).all(), "non-finite latent"
 
     T, N = 512, x.shape[1]

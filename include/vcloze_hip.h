@@ -21,12 +21,13 @@ extern "C" {
 #define VC_ERR_HIP (-2)
 #define VC_ERR_STATE (-3)
 
-#define VC_ABI_VERSION 2
+#define VC_ABI_VERSION 3
 int vc_abi_version(void);
 const char* vc_last_error(void);
-/* sizeof(VcGemmProblem), sizeof(VcGemmArgs), sizeof(VcLnStream), sizeof(VcAttention) as this library was compiled: a
- * binding checks them against its own mirrors at load time, so a stale .so cannot silently disagree with the caller. */
-void vc_struct_sizes(int32_t out[4]);
+/* sizeof(VcGemmProblem), sizeof(VcGemmArgs), sizeof(VcLnStream), sizeof(VcAttention), sizeof(VcFluxConfig),
+ * sizeof(VcFluxInputs) as this library was compiled: a binding checks them against its own mirrors at load time, so a
+ * stale .so cannot silently disagree with the caller. */
+void vc_struct_sizes(int32_t out[6]);
 /* number of visible devices / name of device 0 ("" when none) — fails loudly, never falls back */
 int vc_device_count(void);
 int vc_device_info(int dev, char* name, int namelen, int* cu_count, int64_t* hbm_bytes);
@@ -220,6 +221,70 @@ int vc_layernorm(const void* x, const void* weight, const void* bias, void* y, i
 int vc_mul(const void* a, const void* b, void* y, int64_t n, void* stream);
 int vc_add(const void* a, const void* b, void* y, int64_t n, void* stream);
 int vc_quick_gelu(const void* x, void* y, int64_t n, void* stream);
+
+/* ---- handle API: the whole of Flux.forward, and the whole fixed-grid Euler loop, behind one call each ----
+ * vc_flux_forward       replaces Flux.forward                      (models/model.py:85-124)
+ * vc_flux_sample_euler  replaces odeint(method="euler") over it    (transport/integrators.py:106-120, transport.py:361-410:
+ *                       drift = -model(x || cond, 1 - t); x += dt * drift with the reference's bf16 roundings)
+ * The handle holds no tensor: weights are zero-copy views bound by name, every activation lives in a caller-provided
+ * workspace.  It does own small host-side state (a pinned staging buffer, the captured hipGraph of one solver step, events).
+ * One handle per device per process; not thread-safe per handle.  bf16 everywhere, LoRA pairs already folded into the
+ * bound weights (W + s*B@A, lora.py:92-98; the un-merged parity mode stays on the op-level API). */
+typedef struct VcFluxConfig {   /* FluxParams, models/model.py:18-32 */
+  int32_t in_channels, out_channels, vec_in_dim, context_in_dim, hidden_size, num_heads, depth, depth_single_blocks;
+  int32_t mlp_hidden;           /* hidden_size * mlp_ratio */
+  int32_t guidance_embed;
+  int32_t axes_dim[3];          /* sum = 128 */
+  int32_t theta;
+} VcFluxConfig;
+int vc_flux_create(const VcFluxConfig* cfg, void** handle);
+int vc_flux_destroy(void* handle);
+/* name = reference module path of an nn.Linear ("img_in", "time_in.in_layer", "double_blocks.3.img_attn.qkv",
+ * "single_blocks.7.linear1", "final_layer.linear", ...): w [rows, cols] bf16 with row stride ldw, bias [rows] or NULL;
+ * or of a QKNorm scale ("double_blocks.3.img_attn.norm.query_norm.scale": w [128], rows = 1);
+ * or "modulation": EVERY Modulation / adaLN Linear (layers.py:120-126, 253) stacked along the rows in the order
+ * double_blocks.i.img_mod.lin, double_blocks.i.txt_mod.lin (i ascending), single_blocks.i.modulation.lin,
+ * final_layer.adaLN_modulation.1 - vc_flux_mod_offset(name) is each module's first row, vc_flux_mod_offset(NULL) the total -
+ * so that one GEMM yields every shift / scale / gate of every solver step;
+ * or, optionally, "timestep_freqs": the 128 F32 frequencies exp(-ln(10000) * k / 128) of timestep_embedding
+ * (layers.py:41-43) as the caller's framework computes them (rows = 1, cols = 128; default: exp in f64, rounded to f32,
+ * which is within 1 ulp of torch's f32 exp).  Pointers must stay valid while bound. */
+int vc_flux_bind_weight(void* handle, const char* name, const void* w, const void* bias, int32_t rows, int32_t cols, int64_t ldw);
+int64_t vc_flux_mod_offset(void* handle, const char* module_name);
+/* knobs for tests and A/B runs: "attn_variant" (-1 = by size, the default), "tile_cfg" (0), "fuse_qnorm" (1) */
+int vc_flux_set_option(void* handle, const char* name, int32_t value);
+int64_t vc_flux_workspace_bytes(void* handle, int32_t B, int32_t T, int32_t N, int32_t max_steps);
+
+typedef struct VcFluxInputs {   /* everything of model_kwargs that does not change along the trajectory */
+  int32_t B, T, N, max_steps;   /* samples stacked in one launch sequence; text / image tokens; solver steps the workspace holds */
+  const void* txt;              /* [B, T, context_in_dim] bf16, device */
+  const void* y;                /* [B, vec_in_dim] bf16, device */
+  const float* guidance;        /* HOST [B], NULL without guidance_embed */
+  const float* img_ids;         /* HOST [B, N, 3] */
+  const float* txt_ids;         /* HOST [B, T, 3] */
+  const int32_t* kv_len;        /* HOST [B] or NULL: rows >= kv_len[b] of the joint (txt, img) sequence are masked */
+  const int32_t* kv_gap;        /* HOST [B][2] or NULL: a second masked range (see VcAttention.kv_gap) */
+  int32_t guidance_is_bf16;     /* the caller's guidance tensor is bf16: 1000 * g rounds to bf16 (layers.py:38) */
+  int32_t _pad;
+} VcFluxInputs;
+/* txt_in, the guidance / vector embedders, the RoPE table (f64 on the host as math.py:102-109), masks; zeroes the V^T
+ * padding.  workspace: device memory, >= vc_flux_workspace_bytes(B, T, N, max_steps), 256-B aligned, the caller's for as
+ * long as forward / sample calls follow. */
+int vc_flux_prepare(void* handle, const VcFluxInputs* in, void* workspace, int64_t workspace_bytes, void* stream);
+/* ONE evaluation: out [B, N, out_channels] = Flux(img [B, N, in_channels]; timesteps HOST [B]) */
+int vc_flux_forward(void* handle, const void* img, const float* timesteps, int32_t timesteps_is_bf16, void* out, void* stream);
+/* The loop.  x [B, N, out_channels] bf16: in = x(t_grid[0]), out = x(t_grid[n_points-1]); cond [B, N, in - out channels];
+ * t_grid HOST f32 [n_points] (n_points - 1 <= max_steps evaluations); state_is_bf16: the caller's ODE state is bf16, so the
+ * model sees 1 - bf16(t_i) (torchdiffeq hands the drift t.to(y.dtype)), dt stays t[i+1] - t[i] in f32; trajectory: NULL or
+ * [n_points - 1][B][N][out_channels] receiving the state after every step.  One captured hipGraph per step (re-captured only
+ * when geometry, masks' kind, workspace or options change); with stream == NULL the steps are launched uncaptured.
+ * begin / steps / end expose the same loop piecewise (bench.py times single steps): sample_euler = begin; steps(n-1); end. */
+int vc_flux_sample_euler(void* handle, void* x, const void* cond, const float* t_grid, int32_t n_points, int32_t state_is_bf16,
+                         void* trajectory, void* stream);
+int vc_flux_sample_begin(void* handle, const void* x, const void* cond, const float* t_grid, int32_t n_points,
+                         int32_t state_is_bf16, void* stream);
+int vc_flux_sample_steps(void* handle, int32_t n_steps, void* trajectory, void* stream);
+int vc_flux_sample_end(void* handle, void* x_out, void* stream);
 
 /* ---- hipGraph helpers: capture the launches issued on `stream` between begin/end ---- */
 int vc_stream_create(void** stream);

@@ -208,9 +208,15 @@ def test_fused_sampler_equals_eager_per_geometry(small_model, geom):
     fused = fn(x, m.forward, kw)
     fused2 = fn(x, m.forward, kw)
     eager = fn(x, lambda xx, **k: m.forward(xx, **k), kw)
+    m.use_handle = False                          # the same plan ordered from Python over the op-level ABI
+    try:
+        fused_py = fn(x, m.forward, kw)
+    finally:
+        m.use_handle = True
     torch.cuda.synchronize()
     assert fused.shape == (1, 1, x.shape[1], 64) and torch.isfinite(fused.float()).all()
     assert torch.equal(fused, fused2)
+    assert torch.equal(fused, fused_py)           # vc_flux_sample_euler == graph replays driven from engine.py, bit for bit
     assert rel_l2(fused, eager) < 5e-3            # same kernels; eager does the Euler update with torch
 
 

@@ -1,0 +1,184 @@
+"""The handle API (vc_flux_*, include/vcloze_hip.h): Flux.forward and the whole Euler loop as one C call
+each.  The launch plan in csrc/flux_engine.hip must produce the SAME BITS as the Python-ordered plan (engine.FluxEngine)
+over the op-level ABI - same kernels, same order, same operands - which the other GPU tests pin to the oracle and the
+reference's golden vectors; here additionally against the golden vectors directly, plus the API's error behaviour."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def rel_l2(a, b):
+    a, b = torch.as_tensor(a).float().cpu(), torch.as_tensor(b).float().cpu()
+    return ((a - b).norm() / b.norm()).item()
+
+
+@pytest.fixture(scope="module")
+def model():
+    from tests.helpers import tiny_model
+    return tiny_model()
+
+
+def _fwd(m, inp, t, use_handle):
+    m.use_handle = use_handle
+    img = torch.cat((inp["x"], inp["cond"]), -1)
+    out = m(img.to(DEV, torch.bfloat16), img_ids=inp["img_ids"].to(DEV), txt=inp["txt"].to(DEV, torch.bfloat16),
+            txt_ids=inp["txt_ids"].to(DEV), timesteps=t.to(DEV), y=inp["y"].to(DEV, torch.bfloat16),
+            txt_mask=inp["txt_mask"].to(DEV), img_mask=inp["img_mask"].to(DEV), guidance=inp["guidance"].to(DEV))
+    torch.cuda.synchronize()
+    m.use_handle = True
+    return out
+
+
+def _kw(inp):
+    return dict(txt=inp["txt"].to(DEV, torch.bfloat16), txt_ids=inp["txt_ids"].to(DEV), txt_mask=inp["txt_mask"].to(DEV),
+                y=inp["y"].to(DEV, torch.bfloat16), img_ids=inp["img_ids"].to(DEV), img_mask=inp["img_mask"].to(DEV),
+                cond=inp["cond"].to(DEV, torch.bfloat16), guidance=inp["guidance"].to(DEV))
+
+
+def _masks(kind, inp):
+    if kind == "ragged":
+        inp["img_mask"][1, -12:] = 0
+    elif kind == "holes":
+        inp["txt_mask"][0, [0, 5]] = 0
+        inp["txt_mask"][1, -4:] = 0
+        inp["img_mask"][0, [1, 2, 9]] = 0
+    return inp
+
+
+@pytest.mark.parametrize("variant", [None, 3, 12])
+@pytest.mark.parametrize("masks", ["full", "ragged", "holes"])
+def test_forward_handle_equals_python_plan_bitwise(model, golden, masks, variant):
+    from tests.procedural import tiny_inputs
+    m, _ = model
+    m.engine().attn_variant = variant
+    try:
+        inp = _masks(masks, tiny_inputs(B=2, seed=7))
+        t = torch.tensor([0.9, 0.25])
+        a, b = _fwd(m, inp, t, True), _fwd(m, inp, t, False)
+        assert m.handle() is not None
+        assert torch.equal(a, b)
+        if masks == "ragged":
+            assert rel_l2(a, golden["flux_b2"]) < 3e-2          # the reference's own Flux.forward on these inputs
+    finally:
+        m.engine().attn_variant = None
+
+
+def test_forward_handle_vs_golden_b1(model, golden):
+    from tests.procedural import tiny_inputs
+    m, _ = model
+    got = _fwd(m, tiny_inputs(B=1), torch.tensor([0.7]), True)
+    assert rel_l2(got, golden["flux_b1"]) < 3e-2
+
+
+@pytest.mark.parametrize("masks", ["full", "holes"])
+def test_sampler_handle_equals_python_plan_bitwise_and_golden(model, golden, masks):
+    """vc_flux_sample_euler (one call per trajectory) against graph replays ordered from Python, state by state."""
+    from tests.procedural import tiny_inputs
+    from visualcloze_amd.transport import Sampler, create_transport
+    m, _ = model
+    B = 1 if masks == "full" else 2
+    inp = _masks(masks, tiny_inputs(B=B) if B == 1 else tiny_inputs(B=2, seed=11))
+    fn = Sampler(create_transport()).sample_ode(sampling_method="euler", num_steps=5, do_shift=True, time_shifting_factor=1)
+    x = inp["x"].to(DEV, torch.bfloat16)
+    x_before = x.clone()
+    a = fn(x, m.forward, _kw(inp))
+    m.use_handle = False
+    try:
+        b = fn(x, m.forward, _kw(inp))
+    finally:
+        m.use_handle = True
+    assert torch.equal(x, x_before)                            # the caller's state is never updated in place
+    assert a.shape == b.shape == (1, B) + tuple(inp["x"].shape[1:])
+    assert torch.equal(a, b)
+    if masks == "full":
+        assert rel_l2(a[-1], golden["traj_states"][-1]) < 6e-2  # the reference's own sample_ode run (fp32)
+
+
+def test_sampler_trajectory_and_piecewise_steps(model):
+    """trajectory buffer = the state after every step; begin / steps(k) / steps(S-k) / end == sample_euler."""
+    from tests.procedural import tiny_inputs
+    from visualcloze_amd.transport import solver_time_grid
+    m, _ = model
+    inp = tiny_inputs(B=1)
+    h = m.handle()
+    kw = _kw(inp)
+    S = 4
+    t = solver_time_grid(S + 1, inp["x"].shape[1], 0.0, 1, True, 1)
+    st = m.engine().stream
+    with torch.cuda.stream(st):
+        s = st.cuda_stream
+        h.prepare(kw["txt"], kw["y"], kw["guidance"], False, kw["img_ids"], kw["txt_ids"], S, stream=s)
+        x1 = inp["x"].to(DEV, torch.bfloat16).clone()
+        traj = torch.empty((S,) + tuple(x1.shape), dtype=torch.bfloat16, device=DEV)
+        h.sample_euler(x1, kw["cond"], t, True, s, trajectory=traj)
+        x2 = inp["x"].to(DEV, torch.bfloat16).clone()
+        h.sample_begin(x2, kw["cond"], t, True, s)
+        h.sample_steps(1, s)
+        mid = torch.empty_like(x2)
+        h.sample_end(mid, s)
+        h.sample_steps(S - 1, s)
+        out = torch.empty_like(x2)
+        h.sample_end(out, s)
+    torch.cuda.synchronize()
+    assert torch.equal(traj[-1], x1) and torch.equal(out, x1) and torch.equal(mid, traj[0])
+    assert torch.equal(x2, inp["x"].to(DEV, torch.bfloat16))   # begin / steps never write the caller's x
+    assert not torch.equal(traj[0], traj[1])
+    with pytest.raises(Exception, match="more steps"):
+        h.sample_steps(1, st.cuda_stream)
+
+
+def test_handle_error_behaviour(model):
+    from tests.procedural import TINY, tiny_inputs
+    from visualcloze_amd import hip
+    from visualcloze_amd.handle import FluxHandle
+    m, _ = model
+    L = hip.lib()
+    p = m.params
+    D = p.hidden_size
+    cfg = hip.FluxConfig(p.in_channels, p.out_channels, p.vec_in_dim, p.context_in_dim, D, p.num_heads, p.depth,
+                         p.depth_single_blocks, int(D * p.mlp_ratio), 1, (C.c_int32 * 3)(*p.axes_dim), p.theta)
+    h = C.c_void_p()
+    assert L.vc_flux_create(C.byref(cfg), C.byref(h)) == 0
+    try:
+        ws = torch.empty(L.vc_flux_workspace_bytes(h, 1, 16, 24, 2) + 256, dtype=torch.uint8, device=DEV)
+        base = (ws.data_ptr() + 255) & ~255
+        inp = tiny_inputs(B=1)
+        kw = _kw(inp)
+        f32 = lambda a: np.ascontiguousarray(a.float().cpu().numpy())  # noqa: E731
+        ii, ti, g = f32(inp["img_ids"]), f32(inp["txt_ids"]), f32(inp["guidance"])
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
+        args = hip.FluxInputs(1, 16, 24, 2, kw["txt"].data_ptr(), kw["y"].data_ptr(), fp(g), fp(ii), fp(ti), None, None, 0, 0)
+        assert L.vc_flux_prepare(h, C.byref(args), base, ws.numel() - 256, None) == -3           # VC_ERR_STATE
+        assert b"not bound" in L.vc_last_error()
+        out = torch.empty(1, 24, 64, dtype=torch.bfloat16, device=DEV)
+        t = np.asarray([0.5], np.float32)
+        assert L.vc_flux_forward(h, out.data_ptr(), fp(t), 0, out.data_ptr(), None) == -3        # not prepared
+        assert L.vc_flux_set_option(h, b"no_such_knob", 1) == -1
+        assert L.vc_flux_mod_offset(h, b"double_blocks.0.txt_mod.lin") == 6 * D
+        assert L.vc_flux_mod_offset(h, b"nope") == -1
+        bad = hip.FluxConfig(p.in_channels, p.out_channels, p.vec_in_dim, p.context_in_dim, D + 8, p.num_heads, p.depth,
+                             p.depth_single_blocks, int(D * p.mlp_ratio), 1, (C.c_int32 * 3)(*p.axes_dim), p.theta)
+        h2 = C.c_void_p()
+        assert L.vc_flux_create(C.byref(bad), C.byref(h2)) == -1 and b"head_dim 128" in L.vc_last_error()
+    finally:
+        assert L.vc_flux_destroy(h) == 0
+    # a fully bound handle: wrong shapes / too small a workspace / too many steps are refused with a message
+    fh = FluxHandle(m.params, m.engine().W, m.engine().dev)
+    inp = tiny_inputs(B=1)
+    kw = _kw(inp)
+    fh.prepare(kw["txt"], kw["y"], kw["guidance"], False, kw["img_ids"], kw["txt_ids"], 2)
+    x = inp["x"].to(DEV, torch.bfloat16).clone()
+    from visualcloze_amd.transport import solver_time_grid
+    with pytest.raises(hip.VclozeHipError, match="workspace holds"):
+        fh.sample_euler(x, kw["cond"], solver_time_grid(6, 24, 0.0, 1, True, 1), True, m.engine().stream.cuda_stream)
+    with pytest.raises(hip.VclozeHipError, match="guidance"):
+        fh.prepare(kw["txt"], kw["y"], None, False, kw["img_ids"], kw["txt_ids"], 2)
+    with pytest.raises(hip.VclozeHipError, match="kv_len"):
+        fh.prepare(kw["txt"], kw["y"], kw["guidance"], False, kw["img_ids"], kw["txt_ids"], 2, kv_len=[41])
+    torch.cuda.synchronize()

@@ -15,9 +15,9 @@ extern "C" {
 
 int vc_abi_version(void) { return VC_ABI_VERSION; }
 const char* vc_last_error(void) { return g_err; }
-void vc_struct_sizes(int32_t out[4]) {
+void vc_struct_sizes(int32_t out[6]) {
   out[0] = (int32_t)sizeof(VcGemmProblem); out[1] = (int32_t)sizeof(VcGemmArgs); out[2] = (int32_t)sizeof(VcLnStream);
-  out[3] = (int32_t)sizeof(VcAttention);
+  out[3] = (int32_t)sizeof(VcAttention); out[4] = (int32_t)sizeof(VcFluxConfig); out[5] = (int32_t)sizeof(VcFluxInputs);
 }
 
 int vc_device_count(void) {
@@ -139,6 +139,39 @@ int vc_pack_mask(const void* mask, void* tokens, int32_t H, int32_t W, int64_t l
 }
 int vc_unpack_latent(const void* tokens, int64_t ld, int32_t col0, void* latent, int32_t C, int32_t h, int32_t w, void* stream) {
   return vc_unpack_latent_launch(tokens, ld, col0, latent, C, h, w, S(stream), ERRBUF);
+}
+
+/* ---- handle API (flux_engine.hip) ---- */
+int vc_flux_create(const VcFluxConfig* cfg, void** handle) { return vc_flux_create_impl(cfg, handle, ERRBUF); }
+int vc_flux_destroy(void* handle) { return vc_flux_destroy_impl(handle, ERRBUF); }
+int vc_flux_bind_weight(void* handle, const char* name, const void* w, const void* bias, int32_t rows, int32_t cols, int64_t ldw) {
+  return vc_flux_bind_weight_impl(handle, name, w, bias, rows, cols, ldw, ERRBUF);
+}
+int64_t vc_flux_mod_offset(void* handle, const char* module_name) { return vc_flux_mod_offset_impl(handle, module_name); }
+int vc_flux_set_option(void* handle, const char* name, int32_t value) { return vc_flux_set_option_impl(handle, name, value, ERRBUF); }
+int64_t vc_flux_workspace_bytes(void* handle, int32_t B, int32_t T, int32_t N, int32_t max_steps) {
+  return vc_flux_workspace_bytes_impl(handle, B, T, N, max_steps);
+}
+int vc_flux_prepare(void* handle, const VcFluxInputs* in, void* workspace, int64_t workspace_bytes, void* stream) {
+  return vc_flux_prepare_impl(handle, in, workspace, workspace_bytes, S(stream), ERRBUF);
+}
+int vc_flux_forward(void* handle, const void* img, const float* timesteps, int32_t timesteps_is_bf16, void* out, void* stream) {
+  return vc_flux_forward_impl(handle, img, timesteps, timesteps_is_bf16, out, S(stream), ERRBUF);
+}
+int vc_flux_sample_begin(void* handle, const void* x, const void* cond, const float* t_grid, int32_t n_points, int32_t state_is_bf16,
+                         void* stream) {
+  return vc_flux_sample_begin_impl(handle, x, cond, t_grid, n_points, state_is_bf16, S(stream), ERRBUF);
+}
+int vc_flux_sample_steps(void* handle, int32_t n_steps, void* trajectory, void* stream) {
+  return vc_flux_sample_steps_impl(handle, n_steps, trajectory, S(stream), ERRBUF);
+}
+int vc_flux_sample_end(void* handle, void* x_out, void* stream) { return vc_flux_sample_end_impl(handle, x_out, S(stream), ERRBUF); }
+int vc_flux_sample_euler(void* handle, void* x, const void* cond, const float* t_grid, int32_t n_points, int32_t state_is_bf16,
+                         void* trajectory, void* stream) {
+  int rc = vc_flux_sample_begin_impl(handle, x, cond, t_grid, n_points, state_is_bf16, S(stream), ERRBUF);
+  if (rc == VC_OK) rc = vc_flux_sample_steps_impl(handle, n_points - 1, trajectory, S(stream), ERRBUF);
+  if (rc == VC_OK) rc = vc_flux_sample_end_impl(handle, x, S(stream), ERRBUF);
+  return rc;
 }
 
 /* ---- streams / graphs / events ---- */

@@ -47,3 +47,19 @@ int vc_rownorm_launch(const void* x, const void* w, const void* b, void* y, int 
 int vc_ewise_launch(const void* a, const void* b, void* y, int64_t n, int op, hipStream_t s, char* err, int errlen);
 int vc_conv3x3_launch(const void* x, const void* w, const void* bias, void* out, int64_t ldc, const void* res, int64_t ldres,
                       const void* gate, int H, int W, int C, int O, int mode, hipStream_t s, char* err, int errlen);
+
+// flux_engine.hip: the handle API
+int vc_flux_create_impl(const VcFluxConfig* cfg, void** handle, char* err, int errlen);
+int vc_flux_destroy_impl(void* handle, char* err, int errlen);
+int vc_flux_bind_weight_impl(void* handle, const char* name, const void* w, const void* bias, int32_t rows, int32_t cols, int64_t ldw,
+                             char* err, int errlen);
+int64_t vc_flux_mod_offset_impl(void* handle, const char* name);
+int vc_flux_set_option_impl(void* handle, const char* name, int32_t value, char* err, int errlen);
+int64_t vc_flux_workspace_bytes_impl(void* handle, int32_t B, int32_t T, int32_t N, int32_t max_steps);
+int vc_flux_prepare_impl(void* handle, const VcFluxInputs* in, void* workspace, int64_t workspace_bytes, hipStream_t s, char* err, int errlen);
+int vc_flux_forward_impl(void* handle, const void* img, const float* timesteps, int32_t timesteps_is_bf16, void* out, hipStream_t s,
+                         char* err, int errlen);
+int vc_flux_sample_begin_impl(void* handle, const void* x, const void* cond, const float* t_grid, int32_t n_points, int32_t state_is_bf16,
+                              hipStream_t s, char* err, int errlen);
+int vc_flux_sample_steps_impl(void* handle, int32_t n_steps, void* trajectory, hipStream_t s, char* err, int errlen);
+int vc_flux_sample_end_impl(void* handle, void* x_out, hipStream_t s, char* err, int errlen);

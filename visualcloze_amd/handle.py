@@ -1,0 +1,153 @@
+"""`FluxHandle`: the handle API of include/vcloze_hip.h (vc_flux_*) behind torch tensors — Flux.forward and the whole
+fixed-grid Euler loop as ONE C call each.  The launch plan lives in csrc/flux_engine.hip; this class
+binds the prepared (bf16, LoRA-merged) weights by reference-module path, owns the workspace tensors and converts the
+host-side inputs (ids, timesteps, masks) to the plain arrays the ABI takes.  `engine.FluxEngine` is the same plan spelt
+in Python over the op-level ABI; it stays for the un-merged LoRA parity mode and for per-block taps."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import hip
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a.detach().to("cpu", torch.float32).numpy() if torch.is_tensor(a) else np.asarray(a, np.float32),
+                                dtype=np.float32)
+
+
+def _fp(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _ip(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+class FluxHandle:
+    MAX_BATCH = 4      # samples per launch sequence, as engine.FluxEngine
+
+    def __init__(self, params, weights, dev: torch.device):
+        self.params, self.dev, self.W = params, dev, weights
+        D = params.hidden_size
+        cfg = hip.FluxConfig(params.in_channels, params.out_channels, params.vec_in_dim, params.context_in_dim, D, params.num_heads,
+                             params.depth, params.depth_single_blocks, int(D * params.mlp_ratio), int(bool(params.guidance_embed)),
+                             (C.c_int32 * 3)(*params.axes_dim), int(params.theta))
+        self.h = C.c_void_p()
+        with torch.cuda.device(dev):
+            hip._check(hip.lib().vc_flux_create(C.byref(cfg), C.byref(self.h)), "vc_flux_create")
+        L = hip.lib()
+        for name, off in weights.mod_off.items():          # the stacking order is part of the ABI
+            if L.vc_flux_mod_offset(self.h, name.encode()) != off:
+                raise hip.VclozeHipError(f"modulation row offset of {name} differs between model.prepare and libvcloze_hip.so")
+        if L.vc_flux_mod_offset(self.h, None) != weights.n_mod:
+            raise hip.VclozeHipError("stacked modulation size differs between model.prepare and libvcloze_hip.so")
+        for name, w in weights.w.items():
+            if name.endswith(".linear1.qkv") or name.endswith(".linear1.mlp"):
+                continue                                    # row ranges of linear1, which is bound whole
+            b = weights.b.get(name)
+            rows, cols = (1, w.numel()) if w.dim() == 1 else tuple(w.shape)
+            self._bind(name, w, b, rows, cols)
+        self._bind("modulation", weights.mod_w, weights.mod_b, *weights.mod_w.shape)
+        hip._check(L.vc_flux_bind_weight(self.h, b"timestep_freqs", weights.temb_freqs.data_ptr(), None, 1, 128, 128),
+                   "vc_flux_bind_weight(timestep_freqs)")      # torch's own f32 table: bit-equal to the Python-ordered plan
+        self._ws: Dict[tuple, torch.Tensor] = {}
+        self._opts: Dict[str, int] = {}
+        self.geom: Optional[Tuple[int, int, int, int]] = None
+
+    def _bind(self, name, w, b, rows, cols):
+        hip._bf16(w, name)
+        if w.stride(-1) != 1 or (b is not None and not b.is_contiguous()):
+            raise hip.VclozeHipError(f"{name}: weight rows / bias must be contiguous")
+        hip._check(hip.lib().vc_flux_bind_weight(self.h, name.encode(), w.data_ptr(), hip._p(b), rows, cols,
+                                                 w.stride(0) if w.dim() == 2 else cols), f"vc_flux_bind_weight({name})")
+
+    def __del__(self):
+        try:
+            if self.h:
+                hip.lib().vc_flux_destroy(self.h)
+                self.h = C.c_void_p()
+        except Exception:
+            pass
+
+    def set_options(self, attn_variant=None, tile_cfg=0, fuse_qnorm=True) -> None:
+        want = dict(attn_variant=-1 if attn_variant is None else int(attn_variant), tile_cfg=int(tile_cfg), fuse_qnorm=int(bool(fuse_qnorm)))
+        for k, v in want.items():
+            if self._opts.get(k) != v:
+                hip._check(hip.lib().vc_flux_set_option(self.h, k.encode(), v), f"vc_flux_set_option({k})")
+                self._opts[k] = v
+
+    def workspace(self, B: int, T: int, N: int, S: int) -> torch.Tensor:
+        key = (B, T, N, S)
+        ws = self._ws.get(key)
+        if ws is None:
+            if len(self._ws) > 8:
+                self._ws.clear()
+            n = hip.lib().vc_flux_workspace_bytes(self.h, B, T, N, S)
+            if n <= 0:
+                raise hip.VclozeHipError(f"vc_flux_workspace_bytes({key}) = {n}")
+            ws = torch.empty(n + 256, dtype=torch.uint8, device=self.dev)
+            self._ws[key] = ws
+        return ws
+
+    def prepare(self, txt, y, guidance, guidance_is_bf16: bool, img_ids, txt_ids, max_steps: int,
+                kv_len: Optional[Sequence[int]] = None, kv_gap: Optional[Sequence[Tuple[int, int]]] = None, stream=None) -> None:
+        """txt [B,T,ctx] / y [B,vec] bf16 device tensors; guidance [B] (any device) or None; ids [B,N|T,3]; kv_len B ints;
+        kv_gap B (lo, hi) pairs (model.MaskLayout)."""
+        hip._bf16(txt, "txt"); hip._bf16(y, "y")
+        B, T = txt.shape[0], txt.shape[1]
+        N = img_ids.shape[-2]
+        txt, y = txt.contiguous(), y.contiguous()
+        g = None if guidance is None else _f32(guidance.reshape(-1).expand(B) if guidance.numel() == 1 else guidance.reshape(B))
+        ii, ti = _f32(img_ids.reshape(B, N, 3)), _f32(txt_ids.reshape(B, T, 3))
+        kv = None if kv_len is None or all(int(v) == T + N for v in kv_len) else np.asarray([int(v) for v in kv_len], np.int32)
+        gp = None
+        if kv_gap is not None and any(hi > lo for lo, hi in kv_gap):
+            gp = np.asarray([[int(lo), int(hi)] for lo, hi in kv_gap], np.int32).reshape(-1)
+            if kv is None:
+                kv = np.full(B, T + N, np.int32)
+        ws = self.workspace(B, T, N, max_steps)
+        base = (ws.data_ptr() + 255) & ~255
+        inp = hip.FluxInputs(B, T, N, max_steps, txt.data_ptr(), y.data_ptr(), _fp(g), _fp(ii), _fp(ti), _ip(kv), _ip(gp),
+                             int(bool(guidance_is_bf16)), 0)
+        hip._check(hip.lib().vc_flux_prepare(self.h, C.byref(inp), base, ws.numel() - (base - ws.data_ptr()),
+                                             stream if stream is not None else hip.cur_stream()), "vc_flux_prepare")
+        self.geom = (B, T, N, max_steps)
+        self._keep = (txt, y, ws)
+
+    def forward(self, img, timesteps, timesteps_is_bf16: bool, out, stream=None) -> None:
+        """img [B,N,in] bf16 -> out [B,N,out] bf16 (both contiguous), timesteps: B values"""
+        hip._bf16(img, "img"); hip._bf16(out, "out")
+        if not (img.is_contiguous() and out.is_contiguous()):
+            raise hip.VclozeHipError("vc_flux_forward: contiguous img / out expected")
+        t = _f32(timesteps).reshape(-1)
+        if t.size != self.geom[0]:
+            raise hip.VclozeHipError(f"vc_flux_forward: {t.size} timesteps for a batch of {self.geom[0]}")
+        hip._check(hip.lib().vc_flux_forward(self.h, img.data_ptr(), _fp(t), int(bool(timesteps_is_bf16)), out.data_ptr(),
+                                             stream if stream is not None else hip.cur_stream()), "vc_flux_forward")
+
+    def sample_begin(self, x, cond, t_grid, state_is_bf16: bool, stream) -> None:
+        hip._bf16(x, "x"); hip._bf16(cond, "cond")
+        if not (x.is_contiguous() and cond.is_contiguous()):
+            raise hip.VclozeHipError("vc_flux_sample: contiguous x / cond expected")
+        t = _f32(t_grid).reshape(-1)
+        hip._check(hip.lib().vc_flux_sample_begin(self.h, x.data_ptr(), cond.data_ptr(), _fp(t), t.size, int(bool(state_is_bf16)), stream),
+                   "vc_flux_sample_begin")
+
+    def sample_steps(self, n: int, stream, trajectory=None) -> None:
+        hip._check(hip.lib().vc_flux_sample_steps(self.h, n, hip._p(trajectory), stream), "vc_flux_sample_steps")
+
+    def sample_end(self, x_out, stream) -> None:
+        hip._check(hip.lib().vc_flux_sample_end(self.h, x_out.data_ptr(), stream), "vc_flux_sample_end")
+
+    def sample_euler(self, x, cond, t_grid, state_is_bf16: bool, stream, trajectory=None) -> None:
+        """x [B,N,C] bf16 in place: x(t_grid[0]) -> x(t_grid[-1]); trajectory: optional [S,B,N,C] bf16 buffer"""
+        hip._bf16(x, "x"); hip._bf16(cond, "cond")
+        if not (x.is_contiguous() and cond.is_contiguous()) or (trajectory is not None and not trajectory.is_contiguous()):
+            raise hip.VclozeHipError("vc_flux_sample_euler: contiguous x / cond / trajectory expected")
+        t = _f32(t_grid).reshape(-1)
+        hip._check(hip.lib().vc_flux_sample_euler(self.h, x.data_ptr(), cond.data_ptr(), _fp(t), t.size, int(bool(state_is_bf16)),
+                                                  hip._p(trajectory), stream), "vc_flux_sample_euler")

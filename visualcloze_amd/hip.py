@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VC_HIP_LIB") or os.path.join(_HERE, "lib", "libvcloze_hip.so")   # VC_HIP_LIB: profiling build
 CSRC = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 2                # VC_ABI_VERSION of include/vcloze_hip.h
+ABI_VERSION = 3                # VC_ABI_VERSION of include/vcloze_hip.h
 GEMM_MAX_PROBLEMS = 4          # VC_GEMM_MAX_PROBLEMS: grouped problems per vc_gemm launch
 EPI_BIAS, EPI_GELU, EPI_GATE_RES, EPI_SILU = 0, 1, 2, 3
 
@@ -60,6 +60,21 @@ class Attention(C.Structure):
                 ("kv_gap", C.c_void_p)]
 
 
+class FluxConfig(C.Structure):
+    """VcFluxConfig of include/vcloze_hip.h."""
+    _fields_ = [("in_channels", C.c_int32), ("out_channels", C.c_int32), ("vec_in_dim", C.c_int32), ("context_in_dim", C.c_int32),
+                ("hidden_size", C.c_int32), ("num_heads", C.c_int32), ("depth", C.c_int32), ("depth_single_blocks", C.c_int32),
+                ("mlp_hidden", C.c_int32), ("guidance_embed", C.c_int32), ("axes_dim", C.c_int32 * 3), ("theta", C.c_int32)]
+
+
+class FluxInputs(C.Structure):
+    """VcFluxInputs of include/vcloze_hip.h (txt / y device pointers, everything else host arrays)."""
+    _fields_ = [("B", C.c_int32), ("T", C.c_int32), ("N", C.c_int32), ("max_steps", C.c_int32),
+                ("txt", C.c_void_p), ("y", C.c_void_p), ("guidance", C.POINTER(C.c_float)), ("img_ids", C.POINTER(C.c_float)),
+                ("txt_ids", C.POINTER(C.c_float)), ("kv_len", C.POINTER(C.c_int32)), ("kv_gap", C.POINTER(C.c_int32)),
+                ("guidance_is_bf16", C.c_int32), ("_pad", C.c_int32)]
+
+
 # every symbol include/vcloze_hip.h declares: name -> (restype, argtypes)
 _vp, _i32, _i64 = C.c_void_p, C.c_int32, C.c_int64
 SYMBOLS = {
@@ -101,6 +116,18 @@ SYMBOLS = {
     "vc_nchw_to_nhwc": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i64, C.c_float, C.c_float, _vp]),
     "vc_nhwc_to_nchw": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _vp]),
     "vc_gaussian_sample": (C.c_int, [_vp, _i32, _vp, _vp, _i32, _i64, C.c_float, C.c_float, _vp]),
+    "vc_flux_create": (C.c_int, [C.POINTER(FluxConfig), C.POINTER(_vp)]),
+    "vc_flux_destroy": (C.c_int, [_vp]),
+    "vc_flux_bind_weight": (C.c_int, [_vp, C.c_char_p, _vp, _vp, _i32, _i32, _i64]),
+    "vc_flux_mod_offset": (_i64, [_vp, C.c_char_p]),
+    "vc_flux_set_option": (C.c_int, [_vp, C.c_char_p, _i32]),
+    "vc_flux_workspace_bytes": (_i64, [_vp, _i32, _i32, _i32, _i32]),
+    "vc_flux_prepare": (C.c_int, [_vp, C.POINTER(FluxInputs), _vp, _i64, _vp]),
+    "vc_flux_forward": (C.c_int, [_vp, _vp, C.POINTER(C.c_float), _i32, _vp, _vp]),
+    "vc_flux_sample_euler": (C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_float), _i32, _i32, _vp, _vp]),
+    "vc_flux_sample_begin": (C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_float), _i32, _i32, _vp]),
+    "vc_flux_sample_steps": (C.c_int, [_vp, _i32, _vp, _vp]),
+    "vc_flux_sample_end": (C.c_int, [_vp, _vp, _vp]),
     "vc_stream_create": (C.c_int, [C.POINTER(_vp)]),
     "vc_stream_destroy": (C.c_int, [_vp]),
     "vc_stream_sync": (C.c_int, [_vp]),
@@ -141,9 +168,10 @@ def lib() -> C.CDLL:
             fn.restype, fn.argtypes = res, args
         if l.vc_abi_version() != ABI_VERSION:
             raise VclozeHipError(f"libvcloze_hip.so ABI version {l.vc_abi_version()} != {ABI_VERSION} expected by hip.py - rebuild")
-        sizes = (C.c_int32 * 4)()
+        sizes = (C.c_int32 * 6)()
         l.vc_struct_sizes(sizes)          # a stale library whose structs disagree with these ctypes mirrors must not run
-        if list(sizes) != [C.sizeof(GemmProblem), C.sizeof(GemmArgs), C.sizeof(LnStream), C.sizeof(Attention)]:
+        if list(sizes) != [C.sizeof(GemmProblem), C.sizeof(GemmArgs), C.sizeof(LnStream), C.sizeof(Attention),
+                           C.sizeof(FluxConfig), C.sizeof(FluxInputs)]:
             raise VclozeHipError(f"libvcloze_hip.so struct sizes {list(sizes)} differ from the ctypes mirrors - rebuild")
         _lib = l
     return _lib

@@ -253,7 +253,12 @@ class Flux(nn.Module):
              for _ in range(params.depth_single_blocks)])
         self.final_layer = LastLayer(self.hidden_size, 1, self.out_channels)
         self._engine: Optional[FluxEngine] = None
+        self._handle = None
         self._fingerprint = None
+        # True: Flux.forward and the fused sampler run through the C handle API (vc_flux_*, csrc/flux_engine.hip), one
+        # call per evaluation / per trajectory.  False (or lora_mode "ref"): the same launch plan ordered from Python
+        # (engine.FluxEngine) over the op-level ABI - bit-identical results, kept for the parity mode and per-block taps.
+        self.use_handle = True
         # "merged": W + s*B@A folded once (the product mode).  "ref": LinearLora.forward executed as the
         # reference does - base GEMM, two skinny GEMMs, three bf16 roundings (models/modules/lora.py:92-98) - so that
         # the merge's one-rounding deviation is a choice, not a necessity; slower (+8 % FLOPs, unfused epilogues).
@@ -344,6 +349,7 @@ class Flux(nn.Module):
         freqs = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half).to(dev)
         pw = PreparedWeights(w=w, b=b, mod_w=mod_w, mod_b=mod_b, mod_off=off, n_mod=o, temb_freqs=freqs, ref=ref)
         self._engine = FluxEngine(self.params, pw, dev)
+        self._handle = None
         if free_parameters:
             for p in self.parameters():
                 p.data = torch.empty(0, dtype=p.dtype, device=p.device)
@@ -356,12 +362,25 @@ class Flux(nn.Module):
         """Forget the prepared (merged, bf16) weights; the next forward / sample re-prepares.  Call after writing the
         parameters through a path that does not bump `_version` (`.data`, dist.broadcast)."""
         self._engine = None
+        self._handle = None
         self._fingerprint = None
 
     def engine(self) -> FluxEngine:
         if self._engine is None or self._fingerprint != self._weights_fingerprint():
             self.prepare()
         return self._engine
+
+    def handle(self):
+        """The C-side engine (`handle.FluxHandle`) over the prepared weights, or None when this model runs the
+        Python-ordered plan (use_handle False, un-merged LoRA mode).  Test / A-B knobs set on `engine()` apply to both."""
+        eng = self.engine()
+        if not self.use_handle or eng.W.ref is not None:
+            return None
+        if self._handle is None or self._handle.W is not eng.W:
+            from .handle import FluxHandle
+            self._handle = FluxHandle(self.params, eng.W, eng.dev)
+        self._handle.set_options(eng.attn_variant, eng.tile_cfg, eng.fuse_qnorm)
+        return self._handle
 
     # ------------------------------------------------------------------ the B1 boundary
     @torch.no_grad()
@@ -381,9 +400,17 @@ class Flux(nn.Module):
         guidance = per_sample(guidance, B)
         timesteps = per_sample(timesteps, B)
         lay = MaskLayout(txt_mask, img_mask, B, T, N)
+        h = self.handle()
         for b0 in range(0, B, eng.MAX_BATCH):          # samples of a chunk run as ONE stacked launch sequence
             bs = min(eng.MAX_BATCH, B - b0)
             sl = slice(b0, b0 + bs)
+            if h is not None:                           # one C call per chunk: vc_flux_prepare + vc_flux_forward
+                h.prepare(bf(lay.txt_rows(txt, sl)), bf(y[sl]), None if guidance is None else guidance[sl], gbf16,
+                          lay.img_rows(img_ids, sl), lay.txt_rows(txt_ids, sl), 1, lay.kv_len(sl), lay.kv_gap(sl))
+                o = torch.empty(bs, N, self.out_channels, dtype=torch.bfloat16, device=dev)
+                h.forward(bf(lay.img_rows(img, sl)), timesteps[sl], timesteps.dtype == torch.bfloat16, o)
+                out[sl].copy_(lay.img_rows_back(o, sl))
+                continue
             ws = eng.workspace(T, N, 1, bs)
             eng.prepare_sample(ws, bf(lay.txt_rows(txt, sl)), bf(y[sl]), None if guidance is None else guidance[sl], gbf16,
                                lay.img_rows(img_ids, sl), lay.txt_rows(txt_ids, sl), timesteps[sl].float().reshape(1, bs),

@@ -144,11 +144,24 @@ def _sample_fused(flux, x, kw, t, return_trajectory):
     lay = MaskLayout(kw.get("txt_mask"), kw.get("img_mask"), B, T, N)
     st = eng.stream
     st.wait_stream(torch.cuda.current_stream())
+    # the C handle runs the whole trajectory of a chunk in ONE call (vc_flux_sample_euler); states in other dtypes than
+    # bf16 / f32 (whose t rounding the ABI does not express) and the un-merged LoRA mode use the Python-ordered plan
+    h = flux.handle() if x.dtype in (torch.bfloat16, torch.float32) else None
     with torch.cuda.stream(st):
         s = st.cuda_stream
         for b0 in range(0, B, eng.MAX_BATCH):        # a chunk of samples advances together, one graph replay per step
             bs = min(eng.MAX_BATCH, B - b0)
             sl = slice(b0, b0 + bs)
+            if h is not None:
+                h.prepare(bf(lay.txt_rows(txt, sl)), bf(y[sl]), None if guidance is None else guidance[sl], gbf16,
+                          lay.img_rows(kw["img_ids"], sl), lay.txt_rows(kw["txt_ids"], sl), S, lay.kv_len(sl), lay.kv_gap(sl), stream=s)
+                xs = lay.img_rows(x, sl).to(dev, torch.bfloat16, copy=True).contiguous()   # updated in place: never the caller's
+                tj = torch.empty(S, bs, N, C, dtype=torch.bfloat16, device=dev) if return_trajectory else None
+                h.sample_euler(xs, bf(lay.img_rows(cond, sl)), t32, x.dtype == torch.bfloat16, s, trajectory=tj)
+                if return_trajectory:
+                    traj.append(torch.stack([lay.img_rows_back(tj[i], sl) for i in range(S)]))
+                out[sl].copy_(lay.img_rows_back(xs, sl))
+                continue
             ws = eng.workspace(T, N, S, bs)
             eng.prepare_sample(ws, bf(lay.txt_rows(txt, sl)), bf(y[sl]), None if guidance is None else guidance[sl], gbf16,
                                lay.img_rows(kw["img_ids"], sl), lay.txt_rows(kw["txt_ids"], sl), eval_t, lay.kv_len(sl), s=s,

@@ -103,9 +103,7 @@ class Job:
 
     def __init__(self, model, x, kw, num_points, t0=0.0, do_shift=True):
         from visualcloze_amd.transport import solver_time_grid
-        self.model, self.eng, self.h = model, model.engine(), model.handle()
-        if self.h is None:
-            raise SystemExit("bench.py measures the handle path (model.use_handle, merged LoRA)")
+        self.model, self.eng, self.h = model, model.engine(), model.handle()     # h None: --python-plan (A/B runs)
         self.x, self.kw = x.contiguous(), kw
         self.N, self.T = x.shape[1], kw["txt"].shape[1]
         self.t = solver_time_grid(num_points, self.N, t0, 1, do_shift, 1)
@@ -116,8 +114,20 @@ class Job:
 
     def begin_sample(self):
         kw = self.kw
-        self.h.prepare(kw["txt"], kw["y"], kw["guidance"], True, kw["img_ids"], kw["txt_ids"], self.S, stream=self.s)
-        self.h.sample_begin(self.x, kw["cond"], self.t, True, self.s)
+        if self.h is None:               # the same plan ordered from Python (engine.FluxEngine), for A/B runs
+            from visualcloze_amd.transport import model_times
+            eng, B = self.eng, self.x.shape[0]
+            ws = self._pyws = eng.workspace(self.T, self.N, self.S, B)
+            eng.prepare_sample(ws, kw["txt"], kw["y"], kw["guidance"], True, kw["img_ids"], kw["txt_ids"],
+                               model_times(self.t, self.x), [ws.L] * B, s=self.s)
+            ws.DTS.copy_((self.t[1:] - self.t[:-1]).contiguous(), non_blocking=True)
+            ws.STEP.zero_()
+            ws.XS.copy_(self.x.reshape(B * ws.N, -1))
+            ws.COND.copy_(kw["cond"].reshape(B * ws.N, -1))
+            self.graph = eng.step_graph(ws, self.s)
+        else:
+            self.h.prepare(kw["txt"], kw["y"], kw["guidance"], True, kw["img_ids"], kw["txt_ids"], self.S, stream=self.s)
+            self.h.sample_begin(self.x, kw["cond"], self.t, True, self.s)
         self.step_in_sample = 0
 
     def restart_sample(self):
@@ -126,10 +136,15 @@ class Job:
     def step(self):
         if self.step_in_sample >= self.S:
             self.begin_sample()
-        self.h.sample_steps(1, self.s)
+        if self.h is None:
+            self.graph.launch(self.s)
+        else:
+            self.h.sample_steps(1, self.s)
         self.step_in_sample += 1
 
     def state(self):
+        if self.h is None:
+            return self._pyws.XS.reshape(self.x.shape).clone()
         out = torch.empty_like(self.x)
         self.h.sample_end(out, self.s)
         return out
@@ -310,6 +325,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tile-cfg", type=int, default=None)
     ap.add_argument("--attn-variant", type=int, default=None)
+    ap.add_argument("--python-plan", action="store_true",
+                    help="A/B: order the launches from Python (engine.FluxEngine) instead of the C handle API")
     ap.add_argument("--per-gpu-batch", type=int, default=1,
                     help="independent grids advanced together by one graph replay on each GPU (throughput mode; "
                          "BASELINE's cfg 2 is 1)")
@@ -381,6 +398,7 @@ def main(argv=None):
         eng.tile_cfg = a.tile_cfg
     if a.attn_variant is not None:
         eng.attn_variant = a.attn_variant
+    model.use_handle = not a.python_plan
     PB = a.per_gpu_batch
     x, kw = make_inputs(dev, wl, seed=par.sample_seed(0, rank * PB), B=PB)   # seed from the global sample index
     job = Job(model, x, kw, wl["steps"], t0=wl.get("t0", 0.0), do_shift=wl.get("do_shift", True))

@@ -559,22 +559,34 @@ int vc_flux_prepare_impl(void* handle, const VcFluxInputs* in, void* workspace, 
   const size_t n_rope = (size_t)B * L * 128;
   TRY(stage_begin(f, (n_rope + 128 + 4 * B + 64) * sizeof(float) + 8 * 256, e));
   float* rope = stage_take<float>(f, n_rope);
-  {  // RoPE angles in float64 exactly as math.py:102-109, stored as (cos, sin) f32 per (token, pair)
+  {  // RoPE angles in float64 exactly as math.py:102-109, stored as (cos, sin) f32 per (token, pair).  Position ids take few
+     // distinct values per axis (grid rows / columns), so cos / sin are evaluated once per (axis, value, frequency).
     int pair0 = 0;
+    std::vector<float> table;
+    std::vector<int> slot((size_t)B * L);
     for (int ax = 0; ax < 3; ++ax) {
-      const int d = f.cfg.axes_dim[ax];
-      for (int j = 0; j < d / 2; ++j) {
+      const int half = f.cfg.axes_dim[ax] / 2, d = f.cfg.axes_dim[ax];
+      std::unordered_map<float, int> seen;
+      std::vector<float> values;
+      for (int b = 0; b < B; ++b)
+        for (int r = 0; r < L; ++r) {
+          const float id = r < T ? in->txt_ids[((size_t)b * T + r) * 3 + ax] : in->img_ids[((size_t)b * N + (r - T)) * 3 + ax];
+          auto it = seen.find(id);
+          if (it == seen.end()) { it = seen.emplace(id, (int)values.size()).first; values.push_back(id); }
+          slot[(size_t)b * L + r] = it->second;
+        }
+      table.resize(values.size() * (size_t)half * 2);
+      for (int j = 0; j < half; ++j) {
         const double omega = 1.0 / pow((double)f.cfg.theta, (double)(2 * j) / (double)d);
-        for (int b = 0; b < B; ++b)
-          for (int r = 0; r < L; ++r) {
-            const float* id = r < T ? in->txt_ids + ((size_t)b * T + r) * 3 : in->img_ids + ((size_t)b * N + (r - T)) * 3;
-            const double ang = (double)id[ax] * omega;
-            float* o = rope + (((size_t)b * L + r) * 64 + pair0 + j) * 2;
-            o[0] = (float)cos(ang);
-            o[1] = (float)sin(ang);
-          }
+        for (size_t v = 0; v < values.size(); ++v) {
+          const double ang = (double)values[v] * omega;
+          table[(v * half + j) * 2] = (float)cos(ang);
+          table[(v * half + j) * 2 + 1] = (float)sin(ang);
+        }
       }
-      pair0 += d / 2;
+      for (size_t row = 0; row < (size_t)B * L; ++row)
+        memcpy(rope + (row * 64 + pair0) * 2, table.data() + (size_t)slot[row] * half * 2, (size_t)half * 2 * sizeof(float));
+      pair0 += half;
     }
   }
   float* freqs = stage_take<float>(f, 128);

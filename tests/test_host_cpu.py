@@ -152,3 +152,15 @@ def test_mask_layout_valid_first_permutation():
     assert lay2.kv_len(slice(0, 2)) == [T + N, T + N - 3]
     lay3 = MaskLayout(None, None, 2, T, N)
     assert lay3.kv_len(slice(0, 2)) == [T + N] * 2 and lay3.kv_gap(slice(0, 2)) is None
+
+
+def test_upsampling_host_glue():
+    """visualcloze.py:165-179 (target size rule) and :437-439 (to_pil_image truncates to 8 bits)."""
+    import torch
+    from visualcloze_amd.pipeline import to_uint8_image, upsampling_size
+    assert upsampling_size(None) == (1024, 1024)
+    assert upsampling_size((2048, 1024)) == (1440, 720)          # area-limited at the aspect ratio, then // 16 * 16
+    assert upsampling_size((500, 300)) == (496, 288)
+    assert upsampling_size((1024, 1024)) == (1024, 1024)
+    im = to_uint8_image(torch.tensor([0.0, 0.999, 1.0]).reshape(3, 1, 1).expand(3, 2, 4))
+    assert im.size == (4, 2) and im.mode == "RGB" and im.getpixel((3, 1)) == (0, 254, 255)

@@ -393,3 +393,63 @@ def test_generate_grid_pixels_to_pixels_vs_chained_oracles(model):
     assert got[0].shape == (3, H, W)
     assert float(got[0].min()) >= 0.0 and float(got[0].max()) <= 1.0
     assert rel_l2(got[0], want) < 6e-2, rel_l2(got[0], want)       # VAE + text + 3 evaluations + VAE, all in bf16
+
+
+def test_two_stage_chain_generate_then_sdedit_upsample(model):
+    """`generate_and_upsample` = process_images with is_upsampling (visualcloze.py:363-465): stage 1, 8-bit quantisation and
+    crop of the target cell, host resize, VAE encode, SDEdit from strength 0.4, decode - against the same steps composed by
+    hand from the separately tested pieces, with ONE generator feeding both stages' noise."""
+    import numpy as np
+    from tests.procedural import TINY, TINY_T5, procedural_ae_param, procedural_text_param, ptensor, tiny_ids
+    from visualcloze_amd import pipeline
+    from visualcloze_amd.text import CLIPTextConfig, CLIPTextModel, T5Config, T5EncoderModel
+    from visualcloze_amd.vae import AutoEncoder, AutoEncoderParams
+    m, _ = model
+    dev = "cuda"
+    AE = dict(resolution=32, in_channels=3, ch=64, out_ch=3, ch_mult=[1, 1, 1, 1], num_res_blocks=1, z_channels=16,
+              scale_factor=0.3611, shift_factor=0.1159)
+    CL = dict(vocab_size=128, hidden_size=TINY["vec_in_dim"], intermediate_size=128, num_hidden_layers=1,
+              num_attention_heads=1, max_position_embeddings=16, layer_norm_eps=1e-5, eos_token_id=127)
+    ae = AutoEncoder(AutoEncoderParams(**AE)); ae.load_state_dict({k: procedural_ae_param(k, v.shape) for k, v in ae.state_dict().items()})
+    ae = ae.to(dev).to(torch.bfloat16)
+    t5 = T5EncoderModel(T5Config(**TINY_T5)); tsd = {k: procedural_text_param(k, v.shape) for k, v in t5.state_dict().items()}
+    tsd["encoder.embed_tokens.weight"] = tsd["shared.weight"]
+    t5.load_state_dict(tsd); t5 = t5.to(dev).to(torch.bfloat16)
+    clip = CLIPTextModel(CLIPTextConfig(**CL)); clip.load_state_dict({k: procedural_text_param(k, v.shape) for k, v in clip.state_dict().items()})
+    clip = clip.to(dev).to(torch.bfloat16)
+    H, W = 32, 64
+    c = lambda t: t.to(dev, torch.bfloat16)  # noqa: E731
+    rows = [c(ptensor((3, H, W), 201 + i, q=7)) for i in range(2)]
+    masks = [c(torch.zeros(1, 1, H, W)), c(torch.cat((torch.zeros(1, 1, H, W // 2), torch.ones(1, 1, H, W // 2)), -1))]
+    enoise = [c(ptensor((1, 16, H // 8, W // 8), 211 + i, q=5)) for i in range(2)]
+    up_noise = [(c(ptensor((16, 6, 8), 221, q=5)), c(ptensor((16, 6, 8), 222, q=5)))]
+    t5_ids, clip_ids = tiny_ids(64, 128, seed=5)[None].to(dev), tiny_ids(16, 128, seed=6, eos=127, eos_at=7)[None].to(dev)
+    ct5, cclip = tiny_ids(64, 128, seed=8)[None].to(dev), tiny_ids(16, 128, seed=9, eos=127, eos_at=5)[None].to(dev)
+    kw = dict(cfg=30.0, steps=4, upsampling_steps=4, upsampling_noise=0.4)
+    got = pipeline.generate_and_upsample(m, ae, t5, clip, rows, masks, t5_ids, clip_ids, 3, 2, [False, True], target_size=(70, 50),
+                                         content_t5_ids=ct5, content_clip_ids=cclip, encode_noise=enoise,
+                                         upsample_encode_noise=up_noise, **kw)
+    torch.cuda.synchronize()
+    assert len(got) == 1 and got[0].shape == (3, 48, 64) and 0.0 <= float(got[0].min()) and float(got[0].max()) <= 1.0
+    # ---- by hand ----
+    rng = torch.Generator(device=dev).manual_seed(3)
+    row = pipeline.generate_grid(m, ae, t5, clip, rows, masks, t5_ids, clip_ids, 3, cfg=30.0, steps=4, encode_noise=enoise,
+                                 decode_rows=[1], rng=rng)[0]
+    a = row.float().mul(255).to(torch.uint8).permute(1, 2, 0).cpu().numpy()          # to_pil_image truncates
+    from PIL import Image
+    cell = Image.fromarray(a[:, W // 2:]).resize((64, 48))                            # the masked (second) cell; bicubic default
+    px = ((torch.from_numpy(np.asarray(cell).copy()).permute(2, 0, 1).float() / 255.0 - 0.5) / 0.5).to(dev, torch.bfloat16)
+    lat = ae.encode(px[None], noise=up_noise[0][0][None])
+    blank = ae.encode(torch.zeros_like(px)[None], noise=up_noise[0][1][None])
+    noise = torch.randn([1, 16, 6, 8], device=dev, generator=rng).to(torch.bfloat16)  # the generator continues (visualcloze.py:456)
+    z = pipeline.sdedit_upsample(m, noise, lat, blank, t5(ct5), clip(cclip)[0], cfg=30.0, steps=4, strength=0.4)
+    want = ((ae.decode(z)[0].float() + 1.0) / 2.0).clamp(0.0, 1.0)
+    assert torch.equal(got[0], want)
+    # without the second stage the crops themselves come back (visualcloze.py:460-462), 8-bit quantised
+    crops = pipeline.generate_and_upsample(m, ae, t5, clip, rows, masks, t5_ids, clip_ids, 3, 2, [True, True], is_upsampling=False,
+                                           encode_noise=enoise, **kw)
+    assert len(crops) == 2 and crops[1].shape == (3, H, W // 2)
+    assert torch.equal(crops[1].cpu(), torch.from_numpy(a[:, W // 2:].copy()).permute(2, 0, 1).float() / 255.0)
+    # strength >= 1: the resized image is returned untouched (visualcloze.py:180-181)
+    same = pipeline.upsample_image(m, ae, t5, clip, crops[1], (64, 48), ct5, cclip, rng, strength=1.0)
+    assert same.shape == (3, 48, 64)

@@ -3,6 +3,7 @@
     rows = denoise_grid(model, noise_rows, cond_latent_rows, mask_rows, txt, vec, cfg=30, steps=30)       # latent space
     up   = sdedit_upsample(model, noise, latent, blank_latent, txt, vec, cfg=30, steps=10, strength=0.4)  # latent space
     imgs = generate_grid(model, ae, t5, clip, row_images, row_masks, t5_ids, clip_ids, seed, ...)         # pixels in/out
+    outs = generate_and_upsample(model, ae, t5, clip, ..., grid_w, mask_position, upsampling_size, ...)   # both stages chained
 
 `generate_grid` chains the whole tensor path of `process_images` (visualcloze.py:363-434): VAE-encode the grid rows,
 pack latents + fill masks into `cond`, draw the per-row noise, encode the prompt with T5 / CLIP, run the fused sampler,
@@ -66,20 +67,23 @@ def sdedit_upsample(model, noise: torch.Tensor, latent: torch.Tensor, blank_late
 def generate_grid(model, ae, t5, clip, row_images: List[torch.Tensor], row_masks: List[torch.Tensor],
                   t5_ids: torch.Tensor, clip_ids: torch.Tensor, seed: int, cfg: float = 30.0, steps: int = 30,
                   encode_noise: Optional[List[torch.Tensor]] = None, decode_rows: Optional[Sequence[int]] = None,
-                  solver: str = "euler", time_shifting_factor=1) -> List[torch.Tensor]:
+                  solver: str = "euler", time_shifting_factor=1, rng: Optional[torch.Generator] = None) -> List[torch.Tensor]:
     """One grid, pixels in, pixels out (visualcloze.py:363-434).
 
     row_images[i]: [3, H, W_row] in [-1, 1] (the images of grid row i side by side); row_masks[i]: [1, 1, H, W_row]
     pixel fill mask (1 = generate); t5_ids [1, 512], clip_ids [1, 77]; `seed` drives the initial noise exactly like
     `torch.Generator(device).manual_seed(seed)` + one `torch.randn` per row (:394-399).  `encode_noise` are the VAE's
     DiagonalGaussian samples per row (None: drawn with torch.randn_like, as the reference's encode does).
-    Returns the decoded rows `decode_rows` (default: all) as [3, H, W_row] tensors in [0, 1] (:430-432)."""
+    `rng`: the generator to draw from instead of a fresh one seeded with `seed` (the upsampling stage keeps drawing from
+    the SAME generator, :450-458).  Returns the decoded rows `decode_rows` (default: all) as [3, H, W_row] tensors in
+    [0, 1] (:430-432)."""
     dev = row_images[0].device
     lat = []
     for i, img in enumerate(row_images):                                               # :377-378
         n = None if encode_noise is None else encode_noise[i]
         lat.append(ae.encode(img[None].to(torch.bfloat16), noise=n))
-    rng = torch.Generator(device=dev).manual_seed(int(seed))                           # :394
+    if rng is None:
+        rng = torch.Generator(device=dev).manual_seed(int(seed))                       # :394
     noise = [torch.randn([1, 16, img.shape[-2] // 8, img.shape[-1] // 8], device=dev, generator=rng).to(torch.bfloat16)
              for img in row_images]                                                    # :395-399
     txt = t5(t5_ids)                                                                   # prepare_modified -> HFEmbedder
@@ -91,3 +95,89 @@ def generate_grid(model, ae, t5, clip, row_images: List[torch.Tensor], row_masks
         img = ae.decode(rows[i])[0]                                                    # :430
         out.append(((img.float() + 1.0) / 2.0).clamp_(0.0, 1.0))                       # :431-432
     return out
+
+
+def to_uint8_image(img01: torch.Tensor):
+    """`to_pil_image(row_sample.float())` (visualcloze.py:437-439): [3,H,W] in [0,1] -> 8-bit RGB PIL image; torchvision's
+    conversion is `pic.mul(255).byte()`, i.e. it TRUNCATES."""
+    from PIL import Image
+    a = img01.detach().float().mul(255).to(torch.uint8).permute(1, 2, 0).contiguous().cpu().numpy()
+    return Image.fromarray(a)
+
+
+def upsampling_size(target_size):
+    """The size rule of `upsampling` (visualcloze.py:165-179): default 1024x1024, at most 1024^2 pixels at the requested
+    aspect ratio, both sides rounded down to multiples of 16.  (w, h) in, (w, h) out."""
+    if target_size is None:
+        target_size = (1024, 1024)
+    if target_size[0] * target_size[1] > 1024 * 1024:
+        aspect = target_size[0] / target_size[1]
+        new_h = int((1024 * 1024 / aspect) ** 0.5)
+        target_size = (int(new_h * aspect), new_h)
+    return (target_size[0] // 16) * 16, (target_size[1] // 16) * 16
+
+
+@torch.no_grad()
+def upsample_image(model, ae, t5, clip, image, target_size, t5_ids: torch.Tensor, clip_ids: torch.Tensor,
+                   rng: torch.Generator, cfg: float = 30.0, steps: int = 10, strength: float = 0.4,
+                   encode_noise: Optional[Sequence[torch.Tensor]] = None, solver: str = "euler") -> torch.Tensor:
+    """`VisualClozeModel.upsampling` (visualcloze.py:147-245) for one image: resize on the host (PIL, bicubic - the
+    default of `Image.resize`), VAE-encode the image and a blank, SDEdit from `strength` with everything masked, decode.
+    image: PIL image or [3,H,W] tensor in [0,1]; t5_ids / clip_ids: the tokenised CONTENT prompt (prefix stripping and
+    tokenisation are host work, :149-163); `encode_noise`: the two DiagonalGaussian draws (image, blank) or None for
+    torch.randn_like as the reference's `.sample()`.  Returns [3, h, w] in [0, 1]."""
+    import numpy as np
+    dev = next(ae.parameters()).device
+    if torch.is_tensor(image):
+        image = to_uint8_image(image)
+    image = image.convert("RGB").resize(upsampling_size(target_size))                  # :179
+    px = torch.from_numpy(np.asarray(image, dtype=np.uint8).copy()).permute(2, 0, 1).float().div(255.0)   # ToTensor, :133-137
+    if strength >= 1.0:
+        return px.to(dev)                                                              # :180-181
+    px = ((px - 0.5) / 0.5).to(dev, torch.bfloat16)                                    # Normalize(0.5, 0.5)
+    n_img, n_blank = (None, None) if encode_noise is None else encode_noise
+    latent = ae.encode(px[None], noise=None if n_img is None else n_img[None] if n_img.dim() == 3 else n_img)      # :200,202
+    blank = ae.encode(torch.zeros_like(px)[None], noise=None if n_blank is None else n_blank[None] if n_blank.dim() == 3 else n_blank)
+    noise = torch.randn([1, 16, latent.shape[-2], latent.shape[-1]], device=dev, generator=rng).to(torch.bfloat16)    # :217
+    txt = t5(t5_ids)
+    vec, _ = clip(clip_ids)
+    z = sdedit_upsample(model, noise, latent, blank, txt, vec, cfg=cfg, steps=steps, strength=strength, solver=solver)
+    img = ae.decode(z)[0]                                                              # :238
+    return ((img.float() + 1.0) / 2.0).clamp_(0.0, 1.0)                                # :239-240
+
+
+@torch.no_grad()
+def generate_and_upsample(model, ae, t5, clip, row_images: List[torch.Tensor], row_masks: List[torch.Tensor],
+                          t5_ids: torch.Tensor, clip_ids: torch.Tensor, seed: int, grid_w: int, mask_position: Sequence[bool],
+                          target_size=None, content_t5_ids: Optional[torch.Tensor] = None,
+                          content_clip_ids: Optional[torch.Tensor] = None, cfg: float = 30.0, steps: int = 30,
+                          upsampling_steps: int = 10, upsampling_noise: float = 0.4, is_upsampling: bool = True,
+                          encode_noise: Optional[List[torch.Tensor]] = None, upsample_encode_noise=None,
+                          solver: str = "euler", time_shifting_factor=1):
+    """Both stages of `process_images` chained (visualcloze.py:363-465): the grid is generated, its LAST row is decoded and
+    quantised to 8 bits as `to_pil_image` does, every cell of that row whose `mask_position` is set is cropped
+    (:452,461) and - with `is_upsampling` - refined by `upsample_image` at `target_size`, all noise coming from ONE
+    generator seeded with `seed` (:394,456).  Returns the output images as [3, h, w] tensors in [0, 1]."""
+    dev = row_images[0].device
+    rng = torch.Generator(device=dev).manual_seed(int(seed))
+    last = len(row_images) - 1
+    row = generate_grid(model, ae, t5, clip, row_images, row_masks, t5_ids, clip_ids, seed, cfg=cfg, steps=steps,
+                        encode_noise=encode_noise, decode_rows=[last], solver=solver, time_shifting_factor=time_shifting_factor,
+                        rng=rng)[0]
+    pil = to_uint8_image(row)                                                          # :437-439
+    ret_w, ret_h = pil.width, pil.height
+    outs, k = [], 0
+    for i, masked in enumerate(mask_position):
+        if not masked:
+            continue
+        cell = pil.crop((i * ret_w // grid_w, 0, (i + 1) * ret_w // grid_w, ret_h))    # :452,461
+        if is_upsampling:
+            en = None if upsample_encode_noise is None else upsample_encode_noise[k]
+            outs.append(upsample_image(model, ae, t5, clip, cell, target_size, content_t5_ids if content_t5_ids is not None else t5_ids,
+                                       content_clip_ids if content_clip_ids is not None else clip_ids, rng, cfg=cfg,
+                                       steps=upsampling_steps, strength=upsampling_noise, encode_noise=en, solver=solver))
+        else:
+            import numpy as np
+            outs.append(torch.from_numpy(np.asarray(cell, dtype=np.uint8).copy()).permute(2, 0, 1).float().div(255.0).to(dev))
+        k += 1
+    return outs

@@ -21,6 +21,7 @@ execution costs ANY implementation, the reference included.
     HIP vs bf16 oracle (same rounding points, merged LoRA)   <= 1.5e-2      (1+1 blocks)    <= 1.5 * floor (full depth)
     HIP vs fp32 oracle                                        <= max(3e-2, 4 * floor) (1+1)  <= 2 * floor   (full depth)
 """
+import os
 import time
 
 import pytest
@@ -252,9 +253,25 @@ class _LazyF32(dict):
         return self[k] if k in self else default
 
 
+FULLDEPTH_FIXTURE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fulldepth_cfg2_oracle.npz")
+PROBE_KEYS = ("img_in.weight", "double_blocks.18.txt_mlp.2.lora_B.weight", "single_blocks.37.linear1.weight",
+              "final_layer.adaLN_modulation.1.bias")
+
+
+def _weights_probe(sd):
+    """integer checksums of four parameters (bf16 bit patterns summed as int64): identifies the weight draw exactly"""
+    return [int(dict.__getitem__(sd, k).contiguous().view(torch.int16).to(torch.int64).sum()) for k in PROBE_KEYS]
+
+
 def test_full_depth_19_38_vs_oracle():
     """ONE evaluation of the full 19 + 38-block model (13.1 B parameters, L = 3968, LoRA r256) against the CPU oracle,
-    both modes.  Error growth through 57 blocks is stated against the oracle's own bf16-vs-fp32 deviation."""
+    both modes.  Error growth through 57 blocks is stated against the oracle's own bf16-vs-fp32 deviation.
+
+    The oracle needs ~9 min on the box's 128 cores, so its two outputs for exactly these weights and inputs are a
+    committed fixture (tests/golden/fulldepth_cfg2_oracle.npz, written by this very test with VC_SAVE_FULLDEPTH=<path>);
+    the fixture is only used when integer checksums of the weights match the draw it was made from - otherwise, or with
+    VC_LIVE_ORACLE=1, the oracle runs live."""
+    import numpy as np
     import oracle.flux_oracle as O
     m = _build(19, 38)
     inp = _inputs("cfg2", seed=11)
@@ -263,13 +280,29 @@ def test_full_depth_19_38_vs_oracle():
     sd = _LazyF32({k: v.detach().cpu() for k, v in m.state_dict().items()})
     del m
     torch.cuda.empty_cache()
+    probe = _weights_probe(sd)
+    fx = np.load(FULLDEPTH_FIXTURE) if os.path.exists(FULLDEPTH_FIXTURE) else None
+    live = fx is None or os.environ.get("VC_LIVE_ORACLE") == "1" or [int(v) for v in fx["probe"]] != probe \
+        or float(fx["x_sum"]) != inp["x"].double().sum().item()
     t0 = time.time()
-    want_bf16, want_fp32 = _oracle_pair(sd, O.FluxGeometry(), inp, t)
+    if live:
+        want_bf16, want_fp32 = _oracle_pair(sd, O.FluxGeometry(), inp, t)
+        how = f"oracle run live: {time.time() - t0:.0f} s on {torch.get_num_threads()} threads"
+        if os.environ.get("VC_SAVE_FULLDEPTH"):
+            assert torch.equal(want_bf16.to(torch.bfloat16).float(), want_bf16)     # bf16-mode outputs are bf16 values
+            np.savez_compressed(os.environ["VC_SAVE_FULLDEPTH"], want_bf16_bits=want_bf16.to(torch.bfloat16).view(torch.int16).numpy(),
+                                want_fp32=want_fp32.numpy(), probe=np.asarray(probe, np.int64),
+                                x_sum=np.float64(inp["x"].double().sum().item()), t=t.numpy(),
+                                oracle_seconds=time.time() - t0, threads=torch.get_num_threads())
+    else:
+        want_bf16 = torch.tensor(fx["want_bf16_bits"]).view(torch.bfloat16).float()
+        want_fp32 = torch.tensor(fx["want_fp32"])
+        how = f"oracle outputs from the committed fixture ({float(fx['oracle_seconds']):.0f} s on {int(fx['threads'])} threads when made)"
     floor = rel_l2(want_bf16, want_fp32)
     e16, e32 = rel_l2(got, want_bf16), rel_l2(got, want_fp32)
     from tests.helpers import parity_log
     parity_log(f"[full depth 19+38, cfg2] HIP vs bf16-merged oracle {e16:.3e}, vs fp32-ref oracle {e32:.3e}, "
-               f"oracle bf16-vs-fp32 floor {floor:.3e}  (oracle time {time.time() - t0:.0f} s on {torch.get_num_threads()} threads)")
+               f"oracle bf16-vs-fp32 floor {floor:.3e}  ({how})")
     assert torch.isfinite(got).all()
     assert e16 < 1.5 * floor
     assert e32 < 2.0 * floor

@@ -21,7 +21,7 @@ extern "C" {
 #define VC_ERR_HIP (-2)
 #define VC_ERR_STATE (-3)
 
-#define VC_ABI_VERSION 3
+#define VC_ABI_VERSION 4
 int vc_abi_version(void);
 const char* vc_last_error(void);
 /* sizeof(VcGemmProblem), sizeof(VcGemmArgs), sizeof(VcLnStream), sizeof(VcAttention), sizeof(VcFluxConfig),
@@ -37,6 +37,9 @@ int vc_device_info(int dev, char* name, int namelen, int* cu_count, int64_t* hbm
 #define VC_EPI_GELU 1      /* y = bf16(gelu_tanh(bf16(acc + b)))        layers.py:141-145,229  */
 #define VC_EPI_GATE_RES 2  /* y = bf16(res + bf16(gate*bf16(acc + b)))  layers.py:190-195,245  */
 #define VC_EPI_SILU 3      /* y = bf16(silu(bf16(acc + b)))             layers.py:55-60        */
+#define VC_EPI_QKV 4       /* BIAS, and columns >= vt_col0 go TRANSPOSED to vt instead of C:        */
+                           /* the "K H D" split of layers.py:166,236 with V laid out key-contiguous */
+                           /* for the attention kernel (what vc_qknorm_rope_vt's VC_QKN_VT part does)*/
 
 typedef struct VcGemmProblem {
   const void* A;    /* [M,K] bf16, row stride lda (elements) */
@@ -55,6 +58,14 @@ typedef struct VcGemmProblem {
   int32_t a_rpb, c_rpb;
   int32_t tiles_m, tiles_n, tile_start; /* filled by the launcher */
   int32_t _pad;
+  /* VC_EPI_QKV (vt may be NULL = plain BIAS): element (m, n >= vt_col0) is written to
+   * vt[(m / vt_rpb) * vt_bstride + (n - vt_col0) * vt_lpad + vt_row0 + m % vt_rpb], i.e. vt is [batch][N - vt_col0][vt_lpad]
+   * (= [B][H][128][Lpad] of vc_attention), vt_rpb the rows of this problem per batch element and vt_row0 where they start
+   * in the joint sequence (text rows 0, image rows T).  Fast when vt_col0 is a multiple of the tile width the launcher
+   * picks (2 * 3072 is, for every tile) and vt_rpb, vt_row0, vt_lpad are multiples of 8; correct otherwise. */
+  void* vt;
+  int64_t vt_bstride;
+  int32_t vt_col0, vt_rpb, vt_row0, vt_lpad;
 } VcGemmProblem;
 
 #define VC_GEMM_MAX_PROBLEMS 4
@@ -251,7 +262,8 @@ int vc_flux_destroy(void* handle);
  * which is within 1 ulp of torch's f32 exp).  Pointers must stay valid while bound. */
 int vc_flux_bind_weight(void* handle, const char* name, const void* w, const void* bias, int32_t rows, int32_t cols, int64_t ldw);
 int64_t vc_flux_mod_offset(void* handle, const char* module_name);
-/* knobs for tests and A/B runs: "attn_variant" (-1 = by size, the default), "tile_cfg" (0), "fuse_qnorm" (1) */
+/* knobs for tests and A/B runs: "attn_variant" (-1 = by size, the default), "tile_cfg" (0), "fuse_qnorm" (1: query
+ * QKNorm + RoPE inside the attention kernel), "fuse_vt" (1: V^T from the qkv GEMM's epilogue, VC_EPI_QKV) */
 int vc_flux_set_option(void* handle, const char* name, int32_t value);
 int64_t vc_flux_workspace_bytes(void* handle, int32_t B, int32_t T, int32_t N, int32_t max_steps);
 

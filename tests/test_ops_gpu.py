@@ -47,6 +47,43 @@ def test_gemm(hip, cfg, epi, shape):
     check(out, R.gemm_ref(a, w, bias, epi, res, gate))
 
 
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 19, 20, 21, 34, 36])
+@pytest.mark.parametrize("geom", [(2, 16, 24, 256), (1, 64, 320, 384), (2, 5, 27, 128), (1, 8, 200, 768)])
+def test_gemm_qkv_epilogue_writes_v_transposed(hip, cfg, geom):
+    """EPI_QKV: q | k columns as EPI_BIAS, the V third transposed into vt[b][h][d][l] (l = joint token index: text rows
+    first) and bit-identical to what the plain GEMM would have stored; the grouped two-stream launch of a
+    DoubleStreamBlock with batch-strided C rows.  Geometries cover V ranges that start on / off a tile edge of every tile
+    shape, row counts that are not multiples of 8 (element-wise path), two batch elements, and the L -> Lpad padding."""
+    B, T, N, D = geom
+    L, H = T + N, D // 128
+    Lp = (L + 63) // 64 * 64
+    xi, xt = rnd(B * N, D, seed=1), rnd(B * T, D, seed=2)
+    wi, wt = rnd(3 * D, D, scale=D ** -0.5, seed=3), rnd(3 * D, D, scale=D ** -0.5, seed=4)
+    bi, bt = rnd(3 * D, seed=5), rnd(3 * D, seed=6)
+
+    def run(epi, vt):
+        qkv = torch.full((B * L, 3 * D), float("nan"), dtype=torch.bfloat16, device=DEV)
+        kw = dict(c_bstride=L * 3 * D)
+        v1 = dict(vt=vt, vt_col0=2 * D, vt_rpb=N, vt_row0=T) if vt is not None else {}
+        v2 = dict(vt=vt, vt_col0=2 * D, vt_rpb=T, vt_row0=0) if vt is not None else {}
+        hip.gemm([hip.make_problem(xi, wi, bi, qkv[T:], M=B * N, c_rpb=N, **kw, **v1),
+                  hip.make_problem(xt, wt, bt, qkv[:T], M=B * T, c_rpb=T, **kw, **v2)], epi=epi, tile_cfg=cfg)
+        torch.cuda.synchronize()
+        return qkv
+    plain = run(hip.EPI_BIAS, None).reshape(B, L, 3 * D)
+    assert torch.isfinite(plain.float()).all()
+    vt = torch.full((B, H, 128, Lp), 7.0, dtype=torch.bfloat16, device=DEV)
+    fused = run(hip.EPI_QKV, vt).reshape(B, L, 3 * D)
+    assert torch.equal(fused[..., :2 * D], plain[..., :2 * D])                 # q | k untouched by the mode
+    want = plain[..., 2 * D:].reshape(B, L, H, 128).permute(0, 2, 3, 1)        # [B, H, 128, L]
+    assert torch.equal(vt[..., :L], want)
+    assert bool((vt[..., L:] == 7.0).all())                                    # padding columns are never written
+    assert bool(torch.isnan(fused[..., 2 * D:].float()).all())                 # and the V columns of C are not either
+    check(plain[0, T:], R.gemm_ref(xi[:N], wi, bi, 0, None, None))             # the plain GEMM itself vs f32 torch
+    # vt = NULL: the mode is plain EPI_BIAS
+    assert torch.equal(run(hip.EPI_QKV, None).reshape(B, L, 3 * D), plain)
+
+
 def test_gemm_transpose_detecting(hip):
     """A = I with an asymmetric W: a transposed C write cannot pass."""
     n = 128

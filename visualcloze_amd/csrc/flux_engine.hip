@@ -56,7 +56,7 @@ struct Flux : Buffers {
   std::vector<SingleW> sgl;
   int64_t final_mod = 0;
   // options
-  int attn_variant = -1, tile_cfg = 0, fuse_qnorm = 1, n_cu = 256;
+  int attn_variant = -1, tile_cfg = 0, fuse_qnorm = 1, fuse_vt = 1, n_cu = 256;
   // prepared geometry + workspace carve-up
   bool prepared = false;
   int B = 0, T = 0, N = 0, L = 0, Lp = 0, S = 0;
@@ -66,10 +66,10 @@ struct Flux : Buffers {
   // captured steps, most recently used first (a two-stage pipeline alternates between two geometries)
   hipGraphExec_t graph = nullptr;      // = graphs.front().second while a sample is in flight
   struct Key {
-    char* base; int B, T, N, S, ragged, gapped, variant, tile, fuse; hipStream_t s;
+    char* base; int B, T, N, S, ragged, gapped, variant, tile, fuse, fuse_vt; hipStream_t s;
     bool operator==(const Key& o) const {
       return base == o.base && B == o.B && T == o.T && N == o.N && S == o.S && ragged == o.ragged && gapped == o.gapped &&
-             variant == o.variant && tile == o.tile && fuse == o.fuse && s == o.s;
+             variant == o.variant && tile == o.tile && fuse == o.fuse && fuse_vt == o.fuse_vt && s == o.s;
     }
   } key{};
   std::vector<std::pair<Key, hipGraphExec_t>> graphs;
@@ -215,6 +215,12 @@ int resolve(Flux& f, Err e) {
 }
 
 // ---------------------------------------------------------------- launch helpers
+// qkv projections: with fuse_vt the V third leaves the GEMM transposed into VT (EPI_QKV) and the pre-pass is K only
+void with_vt(Flux& f, VcGemmProblem& p, int rows, int row0) {
+  if (!f.fuse_vt) return;
+  p.vt = f.VT; p.vt_bstride = (int64_t)f.H * 128 * f.Lp; p.vt_col0 = 2 * f.D; p.vt_rpb = rows; p.vt_row0 = row0; p.vt_lpad = f.Lp;
+}
+
 VcGemmProblem prob(const void* A, int64_t lda, const Lin& w, void* C, int64_t ldc, int M) {
   VcGemmProblem p;
   memset(&p, 0, sizeof(p));
@@ -264,7 +270,7 @@ int attention(Flux& f, const Ctx& c, const void* q1, const void* k1, const void*
   const bool fused_q = (variant & 8) && f.fuse_qnorm;
   const int64_t ld = 3 * f.D, ldo = f.D + f.mlp;
   TRY(vc_qknorm_rope_vt_launch(f.QKV, ld, f.L * ld, q1, k1, q2, k2, split, f.ROPE, (int64_t)f.L * 128, f.VT, f.B, f.L, f.Lp, f.H,
-                               fused_q ? (VC_QKN_K | VC_QKN_VT) : (VC_QKN_Q | VC_QKN_K | VC_QKN_VT), c.s, e.buf, e.len));
+                               VC_QKN_K | (fused_q ? 0 : VC_QKN_Q) | (f.fuse_vt ? 0 : VC_QKN_VT), c.s, e.buf, e.len));
   VcAttention a;
   memset(&a, 0, sizeof(a));
   a.qkv = f.QKV; a.ld = ld; a.bstride = f.L * ld;
@@ -290,7 +296,8 @@ int double_block(Flux& f, const Ctx& c, const DoubleW& w, Err e) {
     VcGemmProblem p[2] = {prob(XH_I, D, w.qkv[0], f.QKV + (int64_t)T * ldq, ldq, B * N), prob(XH_T, D, w.qkv[1], f.QKV, ldq, B * T)};
     p[0].c_rpb = N; p[1].c_rpb = T;
     p[0].c_bstride = p[1].c_bstride = (int64_t)L * ldq;
-    TRY(gemm(f, p, 2, VC_EPI_BIAS, nullptr, 0, c.s, e));
+    with_vt(f, p[0], N, T); with_vt(f, p[1], T, 0);
+    TRY(gemm(f, p, 2, f.fuse_vt ? VC_EPI_QKV : VC_EPI_BIAS, nullptr, 0, c.s, e));
   }
   TRY(attention(f, c, w.qs[1], w.ks[1], w.qs[0], w.ks[0], T, e));   // rows < T: the text stream's scales
   {  // x += gate * proj(attn): A rows are batch-strided views of CAT[:, :D]
@@ -321,7 +328,11 @@ int single_block(Flux& f, const Ctx& c, const SingleW& w, Err e) {
   const int M = f.B * f.L, D = f.D, mlp = f.mlp;
   const int64_t ldc = D + mlp;
   TRY(ln1(f, c, w.mod, e));
-  TRY(lin(f, w.qkv, f.XH, D, f.QKV, 3 * D, M, VC_EPI_BIAS, c.s, e));
+  {
+    VcGemmProblem p = prob(f.XH, D, w.qkv, f.QKV, 3 * D, M);
+    with_vt(f, p, f.L, 0);
+    TRY(gemm(f, &p, 1, f.fuse_vt ? VC_EPI_QKV : VC_EPI_BIAS, nullptr, 0, c.s, e));
+  }
   TRY(lin(f, w.mlp, f.XH, D, f.CAT + D, ldc, M, VC_EPI_GELU, c.s, e));
   TRY(attention(f, c, w.qs, w.ks, nullptr, nullptr, 0, e));
   VcGemmProblem p = prob(f.CAT, ldc, w.lin2, f.X, D, M);
@@ -420,7 +431,7 @@ void drop_graph(Flux& f) {
 
 // the hipGraph of ONE solver step: everything step-dependent (modulation rows, dt) is indexed on the device by STEP
 int step_graph(Flux& f, hipStream_t s, Err e) {
-  Flux::Key k{f.base, f.B, f.T, f.N, f.S, f.ragged, f.gapped, attention_variant(f), f.tile_cfg, f.fuse_qnorm, s};
+  Flux::Key k{f.base, f.B, f.T, f.N, f.S, f.ragged, f.gapped, attention_variant(f), f.tile_cfg, f.fuse_qnorm, f.fuse_vt, s};
   for (size_t i = 0; i < f.graphs.size(); ++i)
     if (f.graphs[i].first == k) {
       auto hit = f.graphs[i];
@@ -516,6 +527,7 @@ int vc_flux_set_option_impl(void* handle, const char* name, int32_t value, char*
   if (!strcmp(name, "attn_variant")) f.attn_variant = value;
   else if (!strcmp(name, "tile_cfg")) f.tile_cfg = value;
   else if (!strcmp(name, "fuse_qnorm")) f.fuse_qnorm = value != 0;
+  else if (!strcmp(name, "fuse_vt")) f.fuse_vt = value != 0;
   else FAIL(VC_ERR_ARG, "flux_set_option: unknown option '%s'", name);
   return VC_OK;
 }

@@ -6,6 +6,7 @@
 //   EPI_GELU      y = bf16(gelu_tanh(bf16(acc + b)))                  (mlp.0 + nn.GELU("tanh"))
 //   EPI_GATE_RES  y = bf16(res + bf16(gate * bf16(acc + b)))          (x + gate * proj(...), layers.py:190-195,245)
 //   EPI_SILU      y = bf16(silu(bf16(acc + b)))                       (MLPEmbedder in_layer + SiLU)
+//   EPI_QKV       EPI_BIAS, with the V column range written transposed to vt[b][h][d][l] (attention's B operand)
 // The bf16() rounding points are the ones the reference materialises under torch.autocast(bf16).
 //
 // Structure: BMxBNx64 block tile, WMxWN waves, v_mfma_f32_16x16x32_bf16, both operands K-contiguous.
@@ -418,6 +419,18 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
   // (the K loop ended on a barrier, so the staging buffers are free).  Rows are padded by 16 B: the 16 rows a
   // ds_write_b64 lane group touches then land on distinct bank pairs (2-way at worst).
   constexpr int EP_LD = BN * 2 + 16;
+  // EPI_QKV: a tile that lies wholly in the V column range goes through LDS TRANSPOSED ([BN][BM] + 16 B per row) and
+  // leaves as 16-B runs of 8 consecutive tokens per (head, dim) row of vt; a tile that straddles vt_col0 (or unaligned
+  // row geometry) takes the ordinary path and scatters its V elements one by one (test geometries only).
+  constexpr int EPT_LD = BM * 2 + 16;
+  int vkind = 0;
+  if constexpr (EPI == VC_EPI_QKV) {
+    if (P.vt) {
+      const bool aligned = ((P.vt_rpb | P.vt_row0 | P.vt_lpad | (int)(P.vt_bstride & 7)) & 7) == 0;
+      vkind = n0 >= P.vt_col0 ? (aligned ? 1 : 2) : (n0 + BN > P.vt_col0 ? 2 : 0);
+    }
+    vkind = __builtin_amdgcn_readfirstlane(vkind);
+  }
   const bf16_t* __restrict__ bias = (const bf16_t*)P.bias;
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
@@ -436,7 +449,12 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
       u32x2 o;
       o[0] = pack2bf(v[0], v[1]);
       o[1] = pack2bf(v[2], v[3]);
-      *(u32x2*)(smem + row * EP_LD + col * 2) = o;
+      if (EPI == VC_EPI_QKV && vkind == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) *(bf16_t*)(smem + (col + e) * EPT_LD + row * 2) = (bf16_t)(o[e >> 1] >> (16 * (e & 1)));
+      } else {
+        *(u32x2*)(smem + row * EP_LD + col * 2) = o;
+      }
     }
   }
   if constexpr (PREF) {   // LDS writes done; the residual prefetch stays in flight (__syncthreads would wait for it: vmcnt(0))
@@ -448,6 +466,32 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
   }
   VC_PHASE_STAMP(3);
 
+  if constexpr (EPI == VC_EPI_QKV) {
+    bf16_t* __restrict__ vt = (bf16_t*)P.vt;
+    auto vt_at = [&](int m, int n) -> bf16_t* {
+      const int b = m / P.vt_rpb;
+      return vt + (long)b * P.vt_bstride + (long)(n - P.vt_col0) * P.vt_lpad + P.vt_row0 + (m - b * P.vt_rpb);
+    };
+    if (vkind == 1) {      // transposed tile: a lane moves 8 consecutive tokens of one V column = 16 B of one vt row
+      constexpr int CPRT = BM / 8;
+#pragma unroll 4
+      for (int c = etid; c < BN * CPRT; c += NT) {
+        const int trow = c / CPRT, cc = c % CPRT;
+        const int n = n0 + trow, m = m0 + cc * 8;
+        if (n >= N || m >= M) continue;
+        const u32x4 tw = *(const u32x4*)(smem + trow * EPT_LD + cc * 16);
+        if (m + 8 <= M) {
+          *(u32x4*)vt_at(m, n) = tw;       // vt_rpb % 8 == 0 and m % 8 == 0: the 8 tokens share a batch element
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (m + e < M) *vt_at(m + e, n) = (bf16_t)(tw[e >> 1] >> (16 * (e & 1)));
+        }
+      }
+      VC_PHASE_STAMP(4);
+      return;
+    }
+  }
   // ---- pass 2: row-major, 16 B per lane, whole rows per wave-instruction -> coalesced HBM traffic ----
   bf16_t* __restrict__ C = (bf16_t*)P.C;
   const bf16_t* __restrict__ res = (const bf16_t*)P.res;
@@ -493,6 +537,13 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
         o[e] = pack2bf(sum[0], sum[1]);
       }
     }
+    if (EPI == VC_EPI_QKV && vkind == 2 && n >= P.vt_col0) {   // 8 V columns of one token: 8 rows of vt
+      const int b = m / P.vt_rpb;
+      bf16_t* d = (bf16_t*)P.vt + (long)b * P.vt_bstride + (long)(n - P.vt_col0) * P.vt_lpad + P.vt_row0 + (m - b * P.vt_rpb);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d[(long)e * P.vt_lpad] = (bf16_t)(o[e >> 1] >> (16 * (e & 1)));
+      continue;
+    }
     *(u32x4*)(C + crow + n) = o;
   }
   VC_PHASE_STAMP(4);
@@ -502,16 +553,20 @@ template <int BM, int BN, int WM, int WN, int PP>
 hipError_t launch_cfg(const VcGemmArgs& a, int total_tiles, hipStream_t s) {
   constexpr int NT = (WM * WN + (PP == 2 ? 4 : 0)) * 64;
   constexpr int LDS_STAGES = (PP == 2 ? 2 * BM + 3 * BN : 2 * (BM + BN)) * BK * 2, LDS_EPI = BM * (BN * 2 + 16);
-  constexpr int LDS = LDS_STAGES > LDS_EPI ? LDS_STAGES : LDS_EPI;
+  constexpr int LDS_EPIT = BN * (BM * 2 + 16);      // EPI_QKV stages V tiles transposed
+  constexpr int LDS0 = LDS_STAGES > LDS_EPI ? LDS_STAGES : LDS_EPI;
+  constexpr int LDS = LDS0 > LDS_EPIT ? LDS0 : LDS_EPIT;
+  static_assert(LDS <= 160 * 1024, "tile does not fit the 160 KB LDS of a gfx950 CU");
   void (*fn)(const VcGemmArgs) = nullptr;
   switch (a.epi) {
+    case VC_EPI_QKV: fn = gemm_bf16_kernel<BM, BN, WM, WN, VC_EPI_QKV, PP>; break;
     case VC_EPI_BIAS: fn = gemm_bf16_kernel<BM, BN, WM, WN, VC_EPI_BIAS, PP>; break;
     case VC_EPI_GELU: fn = gemm_bf16_kernel<BM, BN, WM, WN, VC_EPI_GELU, PP>; break;
     case VC_EPI_GATE_RES: fn = gemm_bf16_kernel<BM, BN, WM, WN, VC_EPI_GATE_RES, PP>; break;
     case VC_EPI_SILU: fn = gemm_bf16_kernel<BM, BN, WM, WN, VC_EPI_SILU, PP>; break;
     default: return hipErrorInvalidValue;
   }
-  static bool attr_done[4] = {false, false, false, false};
+  static bool attr_done[5] = {false, false, false, false, false};
   if (!attr_done[a.epi]) {
     hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return e;
@@ -587,7 +642,12 @@ int vc_gemm_launch(VcGemmArgs a, int tile_cfg, hipStream_t s, char* err, int err
       snprintf(err, errlen, "gemm: operand exceeds 32-bit element offsets"); return VC_ERR_ARG; }
     if (a.epi == VC_EPI_GATE_RES && (!p.res || !p.gate || p.rows_per_batch <= 0 || p.ldres % 8 || p.gate_bstride % 8 || a.gate_step_stride % 8)) {
       snprintf(err, errlen, "gemm: gate/residual epilogue needs res, gate, rows_per_batch"); return VC_ERR_ARG; }
+    if (a.epi == VC_EPI_QKV && p.vt && (p.vt_rpb <= 0 || p.vt_col0 < 0 || p.vt_col0 % 8 || p.vt_col0 >= p.N || p.vt_row0 < 0 ||
+                                        p.vt_lpad < p.vt_row0 + p.vt_rpb || p.vt_bstride < (int64_t)(p.N - p.vt_col0) * p.vt_lpad)) {
+      snprintf(err, errlen, "gemm: bad V^T description (vt_col0=%d vt_rpb=%d vt_row0=%d vt_lpad=%d vt_bstride=%ld)", p.vt_col0, p.vt_rpb,
+               p.vt_row0, p.vt_lpad, (long)p.vt_bstride); return VC_ERR_ARG; }
   }
+  if (a.epi < 0 || a.epi > VC_EPI_QKV) { snprintf(err, errlen, "gemm: unknown epilogue %d", a.epi); return VC_ERR_ARG; }
   // +16 selects the ping-pong main loop (8-wave tiles 256x256 / 256x192), +32 its loader-wave form (256x192 only)
   int pp = (tile_cfg >> 4) & 7;
   tile_cfg &= 15;

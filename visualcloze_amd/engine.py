@@ -123,6 +123,7 @@ class FluxEngine:
         self.n_cu = hip.device_cus(dev)
         self.attn_scratch = hip.attention_scratch(dev)
         self.fuse_qnorm = True     # variants 8 / 12: QKNorm + RoPE of the queries inside the attention kernel
+        self.fuse_vt = weights.ref is None   # V^T written by the qkv GEMM's epilogue (EPI_QKV); the pre-pass is then K only
         self.tile_cfg = 0
         self.stream = torch.cuda.Stream(device=dev)   # capture needs a non-default stream
         self._ref_scratch: Dict[tuple, torch.Tensor] = {}
@@ -201,7 +202,7 @@ class FluxEngine:
         """hipGraph of ONE solver step (Flux evaluation + Euler update + device step-counter increment).
         Everything step-dependent (modulation rows, dt) is indexed on the device by ws.STEP, so the same
         graph replays for every step of every sample batch with this geometry."""
-        key = (ws.ragged, ws.gapped, self.attn_variant, self.tile_cfg, self.fuse_qnorm)
+        key = (ws.ragged, ws.gapped, self.attn_variant, self.tile_cfg, self.fuse_qnorm, self.fuse_vt)
         if ws.graph is None or ws.graph_key != key:
             xs = ws.XS.clone()
             self.eval_once(ws, ws.STEP, euler=True, s=s)      # warm-up: sets func attributes outside capture
@@ -326,10 +327,20 @@ class FluxEngine:
         q1, k1, q2, k2 = scales
         variant = self.attention_variant(ws)
         fused_q = bool(variant & 8) and self.fuse_qnorm
+        parts = hip.QKN_K | (0 if fused_q else hip.QKN_Q) | (0 if self._vt_in_gemm() else hip.QKN_VT)
         hip.qknorm_rope_vt(ws.QKV, q1, k1, ws.ROPE, ws.VT, ws.L, self.H, stream=s, q_scale2=q2, k_scale2=k2, split=split, B=ws.B,
-                           parts=(hip.QKN_K | hip.QKN_VT) if fused_q else (hip.QKN_Q | hip.QKN_K | hip.QKN_VT))
+                           parts=parts)
         hip.attention(ws.QKV, ws.VT, c.ATT, ws.L, self.H, kv_len=c.kvl, variant=variant, stream=s, B=ws.B,
                       scratch=self.attn_scratch, q_norm=(q1, q2, split, ws.ROPE) if fused_q else None, kv_gap=c.kvgap)
+
+    def _vt_in_gemm(self) -> bool:
+        return self.fuse_vt and self.W.ref is None
+
+    def _qkv_epi(self, ws: Workspace, rows: int, row0: int):
+        """(epilogue, problem kwargs) of a qkv projection: with fuse_vt the V third goes straight to ws.VT, transposed"""
+        if not self._vt_in_gemm():
+            return hip.EPI_BIAS, {}
+        return hip.EPI_QKV, dict(vt=ws.VT, vt_col0=2 * self.D, vt_rpb=rows, vt_row0=row0)
 
     def double_block(self, c, i: int) -> None:
         """DoubleStreamBlock i (layers.py:158-196) on ws.XI / ws.XT, in place."""
@@ -338,8 +349,10 @@ class FluxEngine:
         pf = f"double_blocks.{i}"
         im, tm = pf + ".img_mod.lin", pf + ".txt_mod.lin"
         self._ln2(c, im, tm, 0)
-        self._gemm([self._prob(pf + ".img_attn.qkv", c.XH_I, ws.QKV[T:], **c.qkv_i),
-                    self._prob(pf + ".txt_attn.qkv", c.XH_T, ws.QKV[:T], **c.qkv_t)], s=s)
+        epi, kv_i = self._qkv_epi(ws, N, T)
+        _, kv_t = self._qkv_epi(ws, T, 0)
+        self._gemm([self._prob(pf + ".img_attn.qkv", c.XH_I, ws.QKV[T:], **c.qkv_i, **kv_i),
+                    self._prob(pf + ".txt_attn.qkv", c.XH_T, ws.QKV[:T], **c.qkv_t, **kv_t)], epi=epi, s=s)
         self._attention(c, (Wn[pf + ".txt_attn.norm.query_norm.scale"], Wn[pf + ".txt_attn.norm.key_norm.scale"],
                             Wn[pf + ".img_attn.norm.query_norm.scale"], Wn[pf + ".img_attn.norm.key_norm.scale"]), T)
         self._gated(c, (pf + ".img_attn.proj", pf + ".txt_attn.proj"), (c.ATT[T:], c.ATT[:T]), (ws.XI, ws.XT),
@@ -364,7 +377,8 @@ class FluxEngine:
         pf = f"single_blocks.{i}"
         mn = pf + ".modulation.lin"
         self._ln(c, ws.X, mn, 0, ws.XH, ws.L)
-        self._lin(pf + ".linear1.qkv", ws.XH, ws.QKV, s=s)
+        epi, kv = self._qkv_epi(ws, ws.L, 0)
+        self._lin(pf + ".linear1.qkv", ws.XH, ws.QKV, epi=epi, s=s, **kv)
         self._lin(pf + ".linear1.mlp", ws.XH, ws.CAT[:, D:], epi=hip.EPI_GELU, s=s)
         self._attention(c, (Wn[pf + ".norm.query_norm.scale"], Wn[pf + ".norm.key_norm.scale"], None, None), 0)
         self._gated(c, (pf + ".linear2",), (ws.CAT,), (ws.X,), (self._mod(ws, mn, 2),), (ws.L,), ({},))

@@ -16,9 +16,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VC_HIP_LIB") or os.path.join(_HERE, "lib", "libvcloze_hip.so")   # VC_HIP_LIB: profiling build
 CSRC = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 3                # VC_ABI_VERSION of include/vcloze_hip.h
+ABI_VERSION = 4                # VC_ABI_VERSION of include/vcloze_hip.h
 GEMM_MAX_PROBLEMS = 4          # VC_GEMM_MAX_PROBLEMS: grouped problems per vc_gemm launch
-EPI_BIAS, EPI_GELU, EPI_GATE_RES, EPI_SILU = 0, 1, 2, 3
+EPI_BIAS, EPI_GELU, EPI_GATE_RES, EPI_SILU, EPI_QKV = 0, 1, 2, 3, 4
 
 
 class VclozeHipError(RuntimeError):
@@ -34,6 +34,8 @@ class GemmProblem(C.Structure):
         ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("rows_per_batch", C.c_int32),
         ("a_rpb", C.c_int32), ("c_rpb", C.c_int32),
         ("tiles_m", C.c_int32), ("tiles_n", C.c_int32), ("tile_start", C.c_int32), ("_pad", C.c_int32),
+        ("vt", C.c_void_p), ("vt_bstride", C.c_int64),
+        ("vt_col0", C.c_int32), ("vt_rpb", C.c_int32), ("vt_row0", C.c_int32), ("vt_lpad", C.c_int32),
     ]
 
 
@@ -212,9 +214,11 @@ def _bf16(t: torch.Tensor, name: str) -> None:
 # op wrappers (2-D row-major views; the last dim must be contiguous)
 # ------------------------------------------------------------------------------------------------
 def make_problem(a, w, bias, out, res=None, gate=None, rows_per_batch=None, gate_bstride=0, M=None,
-                 a_rpb=0, a_bstride=0, c_rpb=0, c_bstride=0) -> GemmProblem:
+                 a_rpb=0, a_bstride=0, c_rpb=0, c_bstride=0, vt=None, vt_col0=0, vt_rpb=0, vt_row0=0) -> GemmProblem:
     """`M` + (a_rpb, a_bstride) / (c_rpb, c_bstride) describe batch-strided rows: `a` / `out` are then views of the
-    FIRST batch element's rows (row m of the problem lives at (m // rpb) * bstride + (m % rpb) * ld)."""
+    FIRST batch element's rows (row m of the problem lives at (m // rpb) * bstride + (m % rpb) * ld).
+    EPI_QKV: `vt` [B, H, 128, Lpad] receives the columns >= vt_col0 transposed; this problem's rows are tokens
+    vt_row0 .. vt_row0 + vt_rpb of each batch element's joint sequence."""
     for n, t in (("A", a), ("W", w), ("C", out)):
         _bf16(t, n)
         if t.dim() != 2 or t.stride(1) != 1:
@@ -240,7 +244,13 @@ def make_problem(a, w, bias, out, res=None, gate=None, rows_per_batch=None, gate
     if gate is not None:
         _bf16(gate, "gate")
         p.gate, p.gate_bstride = gate.data_ptr(), gate_bstride
-    p._keep = (a, w, bias, out, res, gate)   # the struct carries raw pointers: keep the operands alive with it
+    if vt is not None:
+        _bf16(vt, "vt")
+        if vt.dim() != 4 or not vt.is_contiguous():
+            raise VclozeHipError("gemm vt: contiguous [B, H, 128, Lpad] expected")
+        p.vt, p.vt_bstride, p.vt_lpad = vt.data_ptr(), vt.stride(0), vt.shape[-1]
+        p.vt_col0, p.vt_rpb, p.vt_row0 = vt_col0, vt_rpb or M, vt_row0
+    p._keep = (a, w, bias, out, res, gate, vt)   # the struct carries raw pointers: keep the operands alive with it
     return p
 
 

@@ -379,7 +379,7 @@ class Flux(nn.Module):
         if self._handle is None or self._handle.W is not eng.W:
             from .handle import FluxHandle
             self._handle = FluxHandle(self.params, eng.W, eng.dev)
-        self._handle.set_options(eng.attn_variant, eng.tile_cfg, eng.fuse_qnorm)
+        self._handle.set_options(eng.attn_variant, eng.tile_cfg, eng.fuse_qnorm, eng.fuse_vt)
         return self._handle
 
     # ------------------------------------------------------------------ the B1 boundary

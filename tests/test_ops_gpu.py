@@ -226,6 +226,34 @@ def test_qknorm_rope_vt_and_attention(hip, variant, L, H, extra, kv_len, split):
         assert float(out[kv_len:].float().abs().sum()) == 0.0           # pad_input semantics (math.py:96)
 
 
+@pytest.mark.parametrize("parts", [1, 2, 3])
+@pytest.mark.parametrize("L,H,extra,split,B", [(64, 2, 0, 0, 1), (40, 3, 0, 16, 1), (333, 9, 256, 128, 1), (1, 1, 0, 0, 1),
+                                               (300, 24, 0, 44, 2), (1664, 10, 0, 512, 1)])
+def test_qknorm_rope_rows_only_equals_full_prepass_bitwise(hip, parts, L, H, extra, split, B):
+    """Without the V^T part (it comes from the qkv GEMM's epilogue) the q / k rows go through a kernel that reads each
+    token's (cos, sin) row once for 8 heads: same arithmetic in the same order as the full pre-pass -> the same bits in the
+    selected rows, everything else (unselected q / k, V, trailing columns, vt) untouched."""
+    ld = 3 * H * 128 + extra
+    qkv = rnd(B * L, ld, seed=7)
+    qs, ks = (1 + 0.1 * rnd(128, seed=8)).to(torch.bfloat16), (1 + 0.1 * rnd(128, seed=9)).to(torch.bfloat16)
+    qs2, ks2 = (1 + 0.1 * rnd(128, seed=10)).to(torch.bfloat16), (1 + 0.1 * rnd(128, seed=11)).to(torch.bfloat16)
+    rope = torch.stack([rope_table(L)] + [rope_table(L).flip(0)] * (B - 1)).contiguous() if B > 1 else rope_table(L)
+    Lpad = (L + 63) // 64 * 64
+    vt = torch.full((B, H, 128, Lpad), 3.0, dtype=torch.bfloat16, device=DEV)
+    full, rows = qkv.clone(), qkv.clone()
+    hip.qknorm_rope_vt(full, qs, ks, rope, vt.clone(), L, H, q_scale2=qs2, k_scale2=ks2, split=split, B=B)
+    hip.qknorm_rope_vt(rows, qs, ks, rope, vt, L, H, q_scale2=qs2, k_scale2=ks2, split=split, B=B, parts=parts)
+    torch.cuda.synchronize()
+    D = H * 128
+    want = qkv.clone()
+    if parts & 1:
+        want[:, :D] = full[:, :D]
+    if parts & 2:
+        want[:, D:2 * D] = full[:, D:2 * D]
+    assert torch.equal(rows, want)
+    assert bool((vt == 3.0).all())
+
+
 @pytest.mark.parametrize("variant", [8, 12])
 @pytest.mark.parametrize("L,H,extra,kv_len,split,B", [(64, 2, 0, None, 0, 1), (40, 2, 0, None, 16, 1), (200, 3, 256, None, 0, 1),
                                                       (333, 2, 0, 301, 128, 1), (1, 1, 0, None, 0, 1), (1664, 4, 0, None, 512, 1),

@@ -170,6 +170,61 @@ __global__ __launch_bounds__(256) void qknorm_rope_vt_kernel(bf16_t* __restrict_
   }
 }
 
+// QKNorm + RoPE of the q and / or k rows WITHOUT the V^T phase (V^T comes from the qkv GEMM's epilogue, VC_EPI_QKV): a
+// thread owns (token, 8 of the 128 dims) and walks HG heads with them, so the (cos, sin) row of the token is read once
+// instead of once per head (the f32 table is twice the bytes of the bf16 row it rotates) and HG 16-B loads are in flight
+// per lane.  Same arithmetic, in the same order, as phase 1 of qknorm_rope_vt_kernel: bit-identical results.
+// grid (ceil(L/16), ceil(H/HG), B), 256 threads
+template <int HG>
+__global__ __launch_bounds__(256) void qknorm_rope_rows_kernel(bf16_t* __restrict__ qkv, long ld, long bstride,
+                                                               const bf16_t* __restrict__ q_scale, const bf16_t* __restrict__ k_scale,
+                                                               const bf16_t* __restrict__ q_scale2, const bf16_t* __restrict__ k_scale2,
+                                                               int split, const float* __restrict__ rope, long rope_bstride, int L,
+                                                               int H, int parts) {
+  const int tid = threadIdx.x;
+  const int tok = blockIdx.x * 16 + (tid >> 4), sub = tid & 15, h0 = blockIdx.y * HG, b = blockIdx.z;
+  if (tok >= L) return;   // whole 16-lane groups leave together; the reductions below stay inside a group
+  const float* rp = rope + (long)b * rope_bstride + (long)tok * 128 + sub * 8;
+  const f32x4 c0 = *(const f32x4*)rp;
+  const f32x4 c1 = *(const f32x4*)(rp + 4);
+  const float cs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+  bf16_t* row = qkv + (long)b * bstride + (long)tok * ld + sub * 8;
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {      // 0 = q, 1 = k
+    if (!(parts & (1 << which))) continue;
+    const bf16_t* sc = (tok < split ? (which ? k_scale : q_scale) : (which ? k_scale2 : q_scale2)) + sub * 8;
+    const u32x4 sw = *(const u32x4*)sc;
+    float g[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { g[2 * e] = lo_bf(sw[e]); g[2 * e + 1] = hi_bf(sw[e]); }
+    bf16_t* base = row + which * (H * 128) + h0 * 128;
+    u32x4 w[HG];
+#pragma unroll
+    for (int hh = 0; hh < HG; ++hh) w[hh] = (h0 + hh < H) ? *(const u32x4*)(base + hh * 128) : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int hh = 0; hh < HG; ++hh) {
+      float x[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { x[2 * e] = lo_bf(w[hh][e]); x[2 * e + 1] = hi_bf(w[hh][e]); }
+      float ss = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ss += x[e] * x[e];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) ss += __shfl_xor(ss, o, 64);
+      const float rrms = 1.0f / sqrtf(ss * (1.0f / 128.0f) + 1e-6f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = rbf(rbf(x[e] * rrms) * g[e]);
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float co = cs[2 * e], si = cs[2 * e + 1];
+        o[e] = pack2bf(co * x[2 * e] - si * x[2 * e + 1], si * x[2 * e] + co * x[2 * e + 1]);
+      }
+      if (h0 + hh < H) *(u32x4*)(base + hh * 128) = o;
+    }
+  }
+}
+
 }  // namespace
 
 int vc_ln_modulate2_launch(const VcLnStream* a, const VcLnStream* b, int64_t mod_bstride, int32_t D, const int32_t* step_ptr,
@@ -216,6 +271,15 @@ int vc_qknorm_rope_vt_launch(void* qkv, int64_t ld, int64_t bstride, const void*
   if (!q_scale2 || !k_scale2) { q_scale2 = q_scale; k_scale2 = k_scale; split = L; }
   if (B <= 0 || L <= 0 || H <= 0) { snprintf(err, errlen, "qknorm_rope_vt: empty problem"); return VC_ERR_ARG; }
   if (Lpad < L || Lpad % 64 || ld % 8 || bstride % 8) { snprintf(err, errlen, "qknorm_rope_vt: Lpad=%d must be a multiple of 64 >= L=%d; ld, bstride multiples of 8", Lpad, L); return VC_ERR_ARG; }
+  if (!(parts & VC_QKN_VT)) {     // rows only: one (cos, sin) read per token for 8 heads
+    constexpr int HG = 8;
+    hipLaunchKernelGGL(qknorm_rope_rows_kernel<HG>, dim3((L + 15) / 16, (H + HG - 1) / HG, B), dim3(256), 0, s, (bf16_t*)qkv, (long)ld,
+                       (long)bstride, (const bf16_t*)q_scale, (const bf16_t*)k_scale, (const bf16_t*)q_scale2, (const bf16_t*)k_scale2,
+                       split, rope, (long)rope_bstride, L, H, parts);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(err, errlen, "qknorm_rope rows launch: %s", hipGetErrorString(e)); return VC_ERR_HIP; }
+    return VC_OK;
+  }
   const dim3 grid((L + 63) / 64, H, B), block(256);
   hipLaunchKernelGGL(qknorm_rope_vt_kernel, grid, block, 0, s, (bf16_t*)qkv, (long)ld, (long)bstride,
                      (const bf16_t*)q_scale, (const bf16_t*)k_scale, (const bf16_t*)q_scale2, (const bf16_t*)k_scale2, split,

@@ -6,7 +6,7 @@ from visualcloze_amd import hip
 dev = "cuda:0"
 hip.lib()
 LIBDIR = os.path.dirname(hip.LIB_PATH)
-L, H = 3968, 24
+L, H = int(os.environ.get("VC_QKN_L", "3968")), 24
 Lp = (L + 63) // 64 * 64
 qkv = (torch.randn(L, 3 * H * 128, device=dev)).to(torch.bfloat16)
 qs, ks = torch.ones(128, dtype=torch.bfloat16, device=dev), torch.ones(128, dtype=torch.bfloat16, device=dev)
@@ -32,4 +32,5 @@ for r in range(R + 1):
         for _ in range(n): run(l)
         e1.record(); torch.cuda.synchronize()
         if r > 0: tot[v] += e0.elapsed_time(e1) * 1e3 / n
-print(" | ".join(f"{v} {tot[v]/R:6.1f} us {146.3e6/(tot[v]/R)/1e6:5.2f} TB/s" for v in libs))
+nbytes = L * H * 128 * 2 * (2 * bin(PARTS & 3).count("1") + 2 * (PARTS >> 2 & 1)) + L * 512   # rows in + out, V in + V^T out, table
+print(f"L={L} parts={PARTS}: " + " | ".join(f"{v} {tot[v]/R:6.1f} us {nbytes / (tot[v]/R) / 1e6:5.2f} TB/s" for v in libs))

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_vt_kernel(bf16_t* __restrict_
 
 // QKNorm + RoPE of the q and / or k rows WITHOUT the V^T phase (V^T comes from the qkv GEMM's epilogue, VC_EPI_QKV): a
 // thread owns (token, 8 of the 128 dims) and walks HG heads with them, so the (cos, sin) row of the token is read once
-// instead of once per head (the f32 table is twice the bytes of the bf16 row it rotates) and HG 16-B loads are in flight
+// per HG heads instead of once per head (the f32 table is twice the bytes of the bf16 row it rotates) and HG 16-B loads are in flight
 // per lane.  Same arithmetic, in the same order, as phase 1 of qknorm_rope_vt_kernel: bit-identical results.
 // grid (ceil(L/16), ceil(H/HG), B), 256 threads
 template <int HG>
@@ -271,8 +271,12 @@ int vc_qknorm_rope_vt_launch(void* qkv, int64_t ld, int64_t bstride, const void*
   if (!q_scale2 || !k_scale2) { q_scale2 = q_scale; k_scale2 = k_scale; split = L; }
   if (B <= 0 || L <= 0 || H <= 0) { snprintf(err, errlen, "qknorm_rope_vt: empty problem"); return VC_ERR_ARG; }
   if (Lpad < L || Lpad % 64 || ld % 8 || bstride % 8) { snprintf(err, errlen, "qknorm_rope_vt: Lpad=%d must be a multiple of 64 >= L=%d; ld, bstride multiples of 8", Lpad, L); return VC_ERR_ARG; }
-  if (!(parts & VC_QKN_VT)) {     // rows only: one (cos, sin) read per token for 8 heads
-    constexpr int HG = 8;
+#ifndef VC_QKN_HG
+#define VC_QKN_HG 2
+#endif
+#ifndef VC_QKN_TILE_ONLY          // analysis builds (tools/qkn_ab.py): the 64-token tile kernel for every `parts`
+  if (!(parts & VC_QKN_VT)) {     // rows only: one (cos, sin) read per token for VC_QKN_HG heads
+    constexpr int HG = VC_QKN_HG;
     hipLaunchKernelGGL(qknorm_rope_rows_kernel<HG>, dim3((L + 15) / 16, (H + HG - 1) / HG, B), dim3(256), 0, s, (bf16_t*)qkv, (long)ld,
                        (long)bstride, (const bf16_t*)q_scale, (const bf16_t*)k_scale, (const bf16_t*)q_scale2, (const bf16_t*)k_scale2,
                        split, rope, (long)rope_bstride, L, H, parts);
@@ -280,6 +284,7 @@ int vc_qknorm_rope_vt_launch(void* qkv, int64_t ld, int64_t bstride, const void*
     if (e != hipSuccess) { snprintf(err, errlen, "qknorm_rope rows launch: %s", hipGetErrorString(e)); return VC_ERR_HIP; }
     return VC_OK;
   }
+#endif
   const dim3 grid((L + 63) / 64, H, B), block(256);
   hipLaunchKernelGGL(qknorm_rope_vt_kernel, grid, block, 0, s, (bf16_t*)qkv, (long)ld, (long)bstride,
                      (const bf16_t*)q_scale, (const bf16_t*)k_scale, (const bf16_t*)q_scale2, (const bf16_t*)k_scale2, split,

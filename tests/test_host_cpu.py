@@ -24,8 +24,15 @@ def test_abi_exports_every_declared_symbol():
 
 def test_struct_layout_matches_header():
     from visualcloze_amd import hip
-    assert ctypes.sizeof(hip.GemmProblem) == 6 * 8 + 7 * 8 + 10 * 4
+    assert ctypes.sizeof(hip.GemmProblem) == 7 * 8 + 8 * 8 + 14 * 4       # 7 pointers, 8 int64, 14 int32 (incl. the V^T fields)
     assert ctypes.sizeof(hip.GemmArgs) == 4 * ctypes.sizeof(hip.GemmProblem) + 8 + 8 + 8 + 8
+    assert ctypes.sizeof(hip.FluxConfig) == 14 * 4
+    assert ctypes.sizeof(hip.FluxInputs) == 4 * 4 + 7 * 8 + 2 * 4
+    # the library reports the same sizes (and hip.lib() refuses to load one that does not)
+    sizes = (ctypes.c_int32 * 6)()
+    hip.lib().vc_struct_sizes(sizes)
+    assert list(sizes) == [ctypes.sizeof(c) for c in (hip.GemmProblem, hip.GemmArgs, hip.LnStream, hip.Attention, hip.FluxConfig,
+                                                       hip.FluxInputs)]
 
 
 def test_no_gpu_fails_loudly():

@@ -57,7 +57,7 @@ typedef struct VcGemmProblem {
   int32_t rows_per_batch; /* GATE_RES: batch index of row m is m / rows_per_batch */
   int32_t a_rpb, c_rpb;
   int32_t tiles_m, tiles_n, tile_start; /* filled by the launcher */
-  int32_t _pad;
+  int32_t m_begin;                      /* filled by the launcher (first row of a split launch, see vc_gemm); pass 0 */
   /* VC_EPI_QKV (vt may be NULL = plain BIAS): element (m, n >= vt_col0) is written to
    * vt[(m / vt_rpb) * vt_bstride + (n - vt_col0) * vt_lpad + vt_row0 + m % vt_rpb], i.e. vt is [batch][N - vt_col0][vt_lpad]
    * (= [B][H][128][Lpad] of vc_attention), vt_rpb the rows of this problem per batch element and vt_row0 where they start
@@ -81,7 +81,13 @@ typedef struct VcGemmArgs {
 /* Replaces torch.nn.functional.linear (+ fused neighbours) on the hot path.
  * tile_cfg: 0 = chosen by the launcher's cost model (what the product path passes); a fixed tile for tests and A/B runs:
  * 1 = 128x128, 2 = 256x128, 3 = 256x256, 4 = 256x192, 5 = 256x288, +16 = ping-pong main loop (3, 4, 5),
- * +32 = ping-pong with loader waves (2, 4). */
+ * +32 = ping-pong with loader waves (2, 4).
+ * With tile_cfg 0 the call may become TWO launches on `stream`: when the 256x192 tiles of the problems are far from a whole
+ * number of rounds of the 256 CUs, the rows of problem 0 are cut at a multiple of 256 so that the first launch is exact
+ * rounds and the remainder runs on the tile shape that suits it (block-round quantisation: e.g. M = 6656, N = 3072 is
+ * 416 tiles = 2 rounds at 81 % fill, or 256 tiles + 240 narrower ones).  Results do not depend on the cut.
+ * VC_GEMM_NO_SPLIT (64) as tile_cfg keeps it one launch; (k << 8) forces the cut at row k * 256 (tests). */
+#define VC_GEMM_NO_SPLIT 64
 int vc_gemm(const VcGemmArgs* args, int tile_cfg, void* stream);
 
 /* LayerNorm(eps=1e-6, no affine) + AdaLN modulate: y = bf16((1+scale)*LN(x) + shift).

@@ -84,6 +84,49 @@ def test_gemm_qkv_epilogue_writes_v_transposed(hip, cfg, geom):
     assert torch.equal(run(hip.EPI_QKV, None).reshape(B, L, 3 * D), plain)
 
 
+@pytest.mark.parametrize("epi", [0, 2, 4])
+@pytest.mark.parametrize("cut", [0, 1, 2, 3, 4])
+def test_gemm_split_launch_against_block_round_quantisation(hip, epi, cut):
+    """tile_cfg 0 may cut problem 0's rows at a multiple of 256 and run the two parts as two launches on different tile
+    shapes (vc_gemm, header).  Forced cuts (k << 8) at every position - including the whole of problem 0 (cut 3 = 700 rows
+    rounded up) and beyond it - on a grouped two-stream launch with batch-strided C rows, the in-place gated residual and
+    the V^T epilogue: same result as the single launch (GEMM_NO_SPLIT) up to the bias-first / bias-last f32 summation
+    order of the two tile families, and the torch reference within bf16 tolerance.  cut 0 = the launcher's own choice."""
+    B, T, N, D = 1, 136, 700, 384
+    L, H = T + N, D // 128
+    NO = 3 * D if epi == 4 else D
+    xi, xt = rnd(B * N, D, seed=1), rnd(B * T, D, seed=2)
+    wi, wt = rnd(NO, D, scale=D ** -0.5, seed=3), rnd(NO, D, scale=D ** -0.5, seed=4)
+    bi, bt = rnd(NO, seed=5), rnd(NO, seed=6)
+    gi, gt = rnd(NO, seed=7), rnd(NO, seed=8)
+    x0 = rnd(B * L, NO, seed=9)
+    Lp = (L + 63) // 64 * 64
+
+    def run(tile_cfg):
+        x = x0.clone()
+        vt = torch.zeros(B, H, 128, Lp, dtype=torch.bfloat16, device=DEV)
+        kw = dict(c_bstride=L * NO)
+        ri = dict(res=x[T:], gate=gi) if epi == 2 else {}
+        rt = dict(res=x[:T], gate=gt) if epi == 2 else {}
+        vi = dict(vt=vt, vt_col0=2 * D, vt_rpb=N, vt_row0=T) if epi == 4 else {}
+        vv = dict(vt=vt, vt_col0=2 * D, vt_rpb=T, vt_row0=0) if epi == 4 else {}
+        hip.gemm([hip.make_problem(xi, wi, bi, x[T:], M=B * N, c_rpb=N, rows_per_batch=N, **kw, **ri, **vi),
+                  hip.make_problem(xt, wt, bt, x[:T], M=B * T, c_rpb=T, rows_per_batch=T, **kw, **rt, **vv)], epi=epi, tile_cfg=tile_cfg)
+        torch.cuda.synchronize()
+        return x, vt
+    one, vt1 = run(hip.GEMM_NO_SPLIT)
+    two, vt2 = run(cut << 8)
+    cols = 2 * D if epi == 4 else NO
+    ref = torch.cat([R.gemm_ref(xt, wt, bt, 2 if epi == 2 else 0, x0[:T], gt), R.gemm_ref(xi, wi, bi, 2 if epi == 2 else 0, x0[T:], gi)])
+    check(two[:, :cols], ref[:, :cols])
+    check(one[:, :cols], ref[:, :cols])
+    assert (two[:, :cols] != one[:, :cols]).float().mean().item() < 2e-3
+    if epi == 4:
+        check(vt2[0, :, :, :L].permute(2, 0, 1).reshape(L, D), ref[:, 2 * D:])
+        assert (vt2 != vt1).float().mean().item() < 2e-3
+        assert float(vt2[..., L:].float().abs().sum()) == 0.0
+
+
 def test_gemm_transpose_detecting(hip):
     """A = I with an asymmetric W: a transposed C write cannot pass."""
     n = 128

@@ -71,7 +71,7 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
   const int gsz = min(P.tiles_m - first_m, GROUP_M);
   const int tm = first_m + (id % in_group) % gsz;
   const int tn = (id % in_group) / gsz;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = P.m_begin + tm * BM, n0 = tn * BN;     // m_begin: rows below it belong to the other launch of a split call
   const int M = P.M, N = P.N, K = P.K;
 
   const bf16_t* __restrict__ Ab = (const bf16_t*)P.A;
@@ -625,12 +625,78 @@ int vc_conv3x3_launch(const void* x, const void* w, const void* bias, void* out,
   return VC_OK;
 }
 
+namespace {
+
+constexpr int cfg_bm[6] = {0, 128, 256, 256, 256, 256}, cfg_bn[6] = {0, 128, 128, 256, 192, 288};
+
+// Cost model fitted on MI355X (M=3968 FLUX shapes): time = block-rounds on 256 CUs x (tile area x (K + fixed
+// prologue/epilogue charge) / streaming efficiency of that tile).  Candidates: 128x128 simple loop (2 blocks per
+// CU; small or skinny problems), 256x192 with loader waves (1 block per CU), which beat the 256x256 / 256x192
+// ping-pong and the 256x288 tiles on every FLUX shape in an interleaved A/B (tools/gemm_ab.py; those stay
+// selectable by number), and its 256x128 sibling.  For M <= 4096, 256x192 gives N=3072 / 9216 / 12288 exactly
+// 1 / 3 / 4 rounds.
+struct TilePlan { int tile_cfg, pp; double cost; };
+constexpr int N_CAND = 3;
+constexpr int cand[N_CAND] = {1, 4, 2};
+constexpr int cand_pp[N_CAND] = {0, 2, 2};        // 256x128 with loaders: more blocks when M is short (L = 1664: 168 vs 112)
+constexpr double cand_eff[N_CAND] = {0.55, 0.94, 0.84}, cand_ovh[N_CAND] = {500.0, 350.0, 350.0};
+
+inline long tiles_of(const VcGemmArgs& a, int c) {
+  long tiles = 0;
+  for (int i = 0; i < a.nprob; ++i) {
+    const int rows = a.p[i].M - a.p[i].m_begin;
+    if (rows > 0) tiles += (long)((rows + cfg_bm[c] - 1) / cfg_bm[c]) * ((a.p[i].N + cfg_bn[c] - 1) / cfg_bn[c]);
+  }
+  return tiles;
+}
+TilePlan best_tile(const VcGemmArgs& a) {
+  TilePlan best{0, 0, 1e300};
+  for (int ci = 0; ci < N_CAND; ++ci) {
+    const int c = cand[ci];
+    const int per_cu = (c == 1) ? 2 : 1;
+    const long rounds = (tiles_of(a, c) + 256L * per_cu - 1) / (256L * per_cu);
+    const double t = rounds * (per_cu * (double)cfg_bm[c] * cfg_bn[c] * ((double)a.p[0].K + cand_ovh[ci]) / cand_eff[ci]);
+    if (t < best.cost) best = TilePlan{c, cand_pp[ci], t};
+  }
+  return best;
+}
+
+int launch_tiles(VcGemmArgs a, int tile_cfg, int pp, hipStream_t s, char* err, int errlen) {
+  if (tile_cfg < 1 || tile_cfg > 5 || pp > 2 || (pp == 1 && tile_cfg < 3) || (pp == 2 && tile_cfg != 4 && tile_cfg != 2)) { snprintf(err, errlen, "gemm: bad tile_cfg %d", tile_cfg); return VC_ERR_ARG; }
+  const int bm = cfg_bm[tile_cfg], bn = cfg_bn[tile_cfg];
+  int total = 0, np = 0;
+  for (int i = 0; i < a.nprob; ++i) {       // problems left without rows by a split are dropped from the grid
+    if (a.p[i].M - a.p[i].m_begin <= 0) continue;
+    a.p[np] = a.p[i];
+    a.p[np].tiles_m = (a.p[np].M - a.p[np].m_begin + bm - 1) / bm;
+    a.p[np].tiles_n = (a.p[np].N + bn - 1) / bn;
+    a.p[np].tile_start = total;
+    total += a.p[np].tiles_m * a.p[np].tiles_n;
+    ++np;
+  }
+  if (np == 0) return VC_OK;
+  a.nprob = np;
+  hipError_t e;
+  switch (tile_cfg) {
+    case 1: e = launch_cfg<128, 128, 2, 2, 0>(a, total, s); break;
+    case 2: e = pp == 2 ? launch_cfg<256, 128, 4, 2, 2>(a, total, s) : launch_cfg<256, 128, 4, 2, 0>(a, total, s); break;
+    case 3: e = pp ? launch_cfg<256, 256, 2, 4, 1>(a, total, s) : launch_cfg<256, 256, 2, 4, 0>(a, total, s); break;
+    case 4: e = pp == 2 ? launch_cfg<256, 192, 4, 2, 2>(a, total, s) : pp ? launch_cfg<256, 192, 4, 2, 1>(a, total, s) : launch_cfg<256, 192, 4, 2, 0>(a, total, s); break;
+    default: e = pp ? launch_cfg<256, 288, 4, 2, 1>(a, total, s) : launch_cfg<256, 288, 4, 2, 0>(a, total, s); break;
+  }
+  if (e != hipSuccess) { snprintf(err, errlen, "gemm launch: %s", hipGetErrorString(e)); return VC_ERR_HIP; }
+  return VC_OK;
+}
+
+}  // namespace
+
 // tile_cfg: 0 = auto, 1 = 128x128 (4 waves), 2 = 256x128, 3 = 256x256, 4 = 256x192, 5 = 256x288 (8 waves each);
-// +16 = ping-pong main loop (3, 4, 5), +32 = ping-pong with loader waves (2, 4)
+// +16 = ping-pong main loop (3, 4, 5), +32 = ping-pong with loader waves (2, 4); VC_GEMM_NO_SPLIT / (k << 8): see the header
 int vc_gemm_launch(VcGemmArgs a, int tile_cfg, hipStream_t s, char* err, int errlen) {
   if (a.nprob < 1 || a.nprob > VC_GEMM_MAX_PROBLEMS) { snprintf(err, errlen, "gemm: nprob must be 1..%d", VC_GEMM_MAX_PROBLEMS); return VC_ERR_ARG; }
   for (int i = 0; i < a.nprob; ++i) {
-    const VcGemmProblem& p = a.p[i];
+    VcGemmProblem& p = a.p[i];
+    p.m_begin = 0;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) { snprintf(err, errlen, "gemm: empty problem %d (M=%d N=%d K=%d)", i, p.M, p.N, p.K); return VC_ERR_ARG; }
     if (p.K % BK) { snprintf(err, errlen, "gemm: K=%d must be a multiple of %d", p.K, BK); return VC_ERR_ARG; }
     if (p.N % 8 || p.ldc % 8 || p.lda % 8) { snprintf(err, errlen, "gemm: need N, ldc, lda multiples of 8 (N=%d ldc=%ld lda=%ld)", p.N, (long)p.ldc, (long)p.lda); return VC_ERR_ARG; }
@@ -648,49 +714,48 @@ int vc_gemm_launch(VcGemmArgs a, int tile_cfg, hipStream_t s, char* err, int err
                p.vt_row0, p.vt_lpad, (long)p.vt_bstride); return VC_ERR_ARG; }
   }
   if (a.epi < 0 || a.epi > VC_EPI_QKV) { snprintf(err, errlen, "gemm: unknown epilogue %d", a.epi); return VC_ERR_ARG; }
-  // +16 selects the ping-pong main loop (8-wave tiles 256x256 / 256x192), +32 its loader-wave form (256x192 only)
-  int pp = (tile_cfg >> 4) & 7;
-  tile_cfg &= 15;
-  static const int cfg_bm[6] = {0, 128, 256, 256, 256, 256}, cfg_bn[6] = {0, 128, 128, 256, 192, 288};
-  if (tile_cfg == 0) {
-    // Cost model fitted on MI355X (M=3968 FLUX shapes): time = block-rounds on 256 CUs x (tile area x (K + fixed
-    // prologue/epilogue charge) / streaming efficiency of that tile).  Candidates: 128x128 simple loop (2 blocks per
-    // CU; small or skinny problems), 256x192 with loader waves (1 block per CU), which beat the 256x256 / 256x192
-    // ping-pong and the 256x288 tiles on every FLUX shape in an interleaved A/B (tools/gemm_ab.py; those stay
-    // selectable by number), and its 256x128 sibling.  For M <= 4096, 256x192 gives N=3072 / 9216 / 12288 exactly
-    // 1 / 3 / 4 rounds.
-    static const int cand[3] = {1, 4, 2};
-    static const int cand_pp[3] = {0, 2, 2};        // 256x128 with loaders: more blocks when M is short (L = 1664: 168 vs 112)
-    static const double eff[3] = {0.55, 0.94, 0.84}, ovh[3] = {500.0, 350.0, 350.0};
-    double best = 1e300;
-    for (int ci = 0; ci < 3; ++ci) {
-      const int c = cand[ci];
-      long tiles = 0;
-      for (int i = 0; i < a.nprob; ++i)
-        tiles += (long)((a.p[i].M + cfg_bm[c] - 1) / cfg_bm[c]) * ((a.p[i].N + cfg_bn[c] - 1) / cfg_bn[c]);
-      const int per_cu = (c == 1) ? 2 : 1;
-      const long rounds = (tiles + 256L * per_cu - 1) / (256L * per_cu);
-      const double t = rounds * (per_cu * (double)cfg_bm[c] * cfg_bn[c] * ((double)a.p[0].K + ovh[ci]) / eff[ci]);
-      if (t < best) { best = t; tile_cfg = c; pp = cand_pp[ci]; }
+  const int force_cut = tile_cfg >> 8;                 // tests: cut problem 0 at row force_cut * 256
+  const bool no_split = (tile_cfg & VC_GEMM_NO_SPLIT) != 0;
+  tile_cfg &= 63;
+  if (tile_cfg != 0) return launch_tiles(a, tile_cfg & 15, (tile_cfg >> 4) & 3, s, err, errlen);
+  const TilePlan whole = best_tile(a);
+  // Block-round quantisation: cut problem 0's rows where the 256x192 tiles above the cut are (nearly) whole rounds of the 256
+  // CUs and price the remainder with the tile that suits it.  The two launches follow each other on the stream (the first
+  // has a flat tail by construction); a cut is taken when the model says it saves >= 10 % and both launches fill their rounds.
+  // The model over-credits by an order of magnitude: under the board's power limit a partly filled round runs at a higher
+  // clock, so quantisation costs far less than its fill factor.  Interleaved A/B, steps/s with / without cuts: L = 6656 (the
+  // N = 3072 launches: 416 tiles -> 256 + 240, model -12.7 % per launch) 9.846 / 9.804 = +0.4 %; L = 7424 (N = 12288 launches
+  // cut at 6144 rows, model -6.3 %) 8.683 / 8.693 = -0.1 % - hence the 10 % bar.
+  int cut = 0;
+  TilePlan rest_plan{0, 0, 0};
+  if (!no_split || force_cut > 0) {
+    double best = force_cut > 0 ? 1e300 : 0.90 * whole.cost;
+    const int tn = (a.p[0].N + cfg_bn[4] - 1) / cfg_bn[4];
+    const int mt_all = (a.p[0].M + 255) / 256;
+    for (int mt = 1; mt <= mt_all; ++mt) {
+      if (force_cut > 0 && mt != force_cut) continue;
+      const int rows = mt * 256 < a.p[0].M ? mt * 256 : a.p[0].M;
+      if (rows == a.p[0].M && a.nprob == 1) break;            // nothing left for the second launch
+      const long tiles1 = (long)mt * tn, rounds1 = (tiles1 + 255) / 256;
+      if (force_cut == 0 && tiles1 < 0.97 * 256.0 * rounds1) continue;
+      const double t1 = rounds1 * ((double)cfg_bm[4] * cfg_bn[4] * ((double)a.p[0].K + cand_ovh[1]) / cand_eff[1]);
+      VcGemmArgs rest = a;
+      rest.p[0].m_begin = rows;
+      const TilePlan rp = best_tile(rest);
+      // the remainder must fill its own rounds too: a half-empty second launch loses more than the model credits it with
+      // (measured: L = 4608 cut into 4096 + 512 rows, 144 - 192 tiles in the second launch: -0.7 % steps/s)
+      const int per_cu = rp.tile_cfg == 1 ? 2 : 1;
+      const long tiles2 = tiles_of(rest, rp.tile_cfg), slots2 = (tiles2 + 256L * per_cu - 1) / (256L * per_cu) * 256L * per_cu;
+      if (force_cut == 0 && tiles2 < 0.9 * slots2) continue;
+      if (t1 + rp.cost < best) { best = t1 + rp.cost; cut = rows; rest_plan = rp; }
     }
   }
-  if (tile_cfg < 1 || tile_cfg > 5 || pp > 2 || (pp == 1 && tile_cfg < 3) || (pp == 2 && tile_cfg != 4 && tile_cfg != 2)) { snprintf(err, errlen, "gemm: bad tile_cfg %d", tile_cfg); return VC_ERR_ARG; }
-  const int bm = cfg_bm[tile_cfg], bn = cfg_bn[tile_cfg];
-  int total = 0;
-  for (int i = 0; i < a.nprob; ++i) {
-    a.p[i].tiles_m = (a.p[i].M + bm - 1) / bm;
-    a.p[i].tiles_n = (a.p[i].N + bn - 1) / bn;
-    a.p[i].tile_start = total;
-    total += a.p[i].tiles_m * a.p[i].tiles_n;
-  }
-  hipError_t e;
-  switch (tile_cfg) {
-    case 1: e = launch_cfg<128, 128, 2, 2, 0>(a, total, s); break;
-    case 2: e = pp == 2 ? launch_cfg<256, 128, 4, 2, 2>(a, total, s) : launch_cfg<256, 128, 4, 2, 0>(a, total, s); break;
-    case 3: e = pp ? launch_cfg<256, 256, 2, 4, 1>(a, total, s) : launch_cfg<256, 256, 2, 4, 0>(a, total, s); break;
-    case 4: e = pp == 2 ? launch_cfg<256, 192, 4, 2, 2>(a, total, s) : pp ? launch_cfg<256, 192, 4, 2, 1>(a, total, s) : launch_cfg<256, 192, 4, 2, 0>(a, total, s); break;
-    default: e = pp ? launch_cfg<256, 288, 4, 2, 1>(a, total, s) : launch_cfg<256, 288, 4, 2, 0>(a, total, s); break;
-  }
-  if (e != hipSuccess) { snprintf(err, errlen, "gemm launch: %s", hipGetErrorString(e)); return VC_ERR_HIP; }
-  return VC_OK;
+  if (cut == 0) return launch_tiles(a, whole.tile_cfg, whole.pp, s, err, errlen);
+  VcGemmArgs first = a;
+  first.nprob = 1;
+  first.p[0].M = cut;                                          // rows [0, cut) of problem 0 on the 256x192 loader-wave tile
+  int rc = launch_tiles(first, 4, 2, s, err, errlen);
+  if (rc != VC_OK) return rc;
+  a.p[0].m_begin = cut;
+  return launch_tiles(a, rest_plan.tile_cfg, rest_plan.pp, s, err, errlen);
 }

@@ -19,6 +19,7 @@ CSRC = os.path.join(_HERE, "csrc")
 ABI_VERSION = 4                # VC_ABI_VERSION of include/vcloze_hip.h
 GEMM_MAX_PROBLEMS = 4          # VC_GEMM_MAX_PROBLEMS: grouped problems per vc_gemm launch
 EPI_BIAS, EPI_GELU, EPI_GATE_RES, EPI_SILU, EPI_QKV = 0, 1, 2, 3, 4
+GEMM_NO_SPLIT = 64             # VC_GEMM_NO_SPLIT: tile_cfg value that keeps an auto-tiled vc_gemm one launch
 
 
 class VclozeHipError(RuntimeError):
@@ -33,7 +34,7 @@ class GemmProblem(C.Structure):
         ("a_bstride", C.c_int64), ("c_bstride", C.c_int64),
         ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("rows_per_batch", C.c_int32),
         ("a_rpb", C.c_int32), ("c_rpb", C.c_int32),
-        ("tiles_m", C.c_int32), ("tiles_n", C.c_int32), ("tile_start", C.c_int32), ("_pad", C.c_int32),
+        ("tiles_m", C.c_int32), ("tiles_n", C.c_int32), ("tile_start", C.c_int32), ("m_begin", C.c_int32),
         ("vt", C.c_void_p), ("vt_bstride", C.c_int64),
         ("vt_col0", C.c_int32), ("vt_rpb", C.c_int32), ("vt_row0", C.c_int32), ("vt_lpad", C.c_int32),
     ]

@@ -4,6 +4,8 @@
 //   shape: v_mfma_f32_16x16x32_bf16 (the GEMM's) vs v_mfma_f32_32x32x16_bf16 (attention's): same FLOPs per pass, the
 //          32x32 form reads half the operand registers per FLOP
 //   data:  zeros / random bf16 in [-2, 2) / the same random fragment for every MFMA (accumulators toggle, operands do not)
+//   order: of the NA x NB (a_i, b_j) products inside a K-step: i-major (b changes at every MFMA, a every NB-th), serpentine
+//          (j runs back and forth: one operand is shared by EVERY pair of consecutive MFMAs), diagonal (both change always)
 // Build: hipcc --offload-arch=gfx950 -O3 tools/ubench/mfma_power.hip -o tools/ubench/mfma_power.bin
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -24,7 +26,14 @@ __device__ inline bf16x8 frag(unsigned seed, int data) {
   return __builtin_bit_cast(bf16x8, u);
 }
 
-template <int SHAPE>   // 0: 16x16x32, 1: 32x32x16
+template <int ORDER, int NA, int NB>
+__device__ constexpr int pair_i(int q) { return ORDER == 2 ? q % NA : q / NB; }
+template <int ORDER, int NA, int NB>
+__device__ constexpr int pair_j(int q) {
+  return ORDER == 0 ? q % NB : ORDER == 1 ? (((q / NB) & 1) ? NB - 1 - q % NB : q % NB) : (q % NA + q / NA) % NB;
+}
+
+template <int SHAPE, int ORDER>   // SHAPE 0: 16x16x32, 1: 32x32x16
 __global__ __launch_bounds__(512) void k(float* sink, int iters, int data, int waves_per_simd) {
   const int wave = threadIdx.x >> 6;
   if (wave >= 4 * waves_per_simd) return;
@@ -40,9 +49,11 @@ __global__ __launch_bounds__(512) void k(float* sink, int iters, int data, int w
 #pragma unroll
       for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int i = 0; i < NA; ++i)
-#pragma unroll
-          for (int j = 0; j < NB; ++j) c[i * NB + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], c[i * NB + j], 0, 0, 0);
+        for (int q = 0; q < NA * NB; ++q) {
+          constexpr int dummy = 0; (void)dummy;
+          const int i = pair_i<ORDER, NA, NB>(q), j = pair_j<ORDER, NA, NB>(q);
+          c[i * NB + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], c[i * NB + j], 0, 0, 0);
+        }
       if ((it & 63) == 63)      // keep the accumulators bounded (values, not zeros)
 #pragma unroll
         for (int q = 0; q < NA * NB; ++q) c[q] *= 0.5f;
@@ -54,9 +65,10 @@ __global__ __launch_bounds__(512) void k(float* sink, int iters, int data, int w
 #pragma unroll
       for (int r = 0; r < 4; ++r)       // 32 x 16x16x32 = the FLOPs of 16 x 32x32x16
 #pragma unroll
-        for (int i = 0; i < NA; ++i)
-#pragma unroll
-          for (int j = 0; j < NB; ++j) c[(r & 1) * NA * NB + i * NB + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], c[(r & 1) * NA * NB + i * NB + j], 0, 0, 0);
+        for (int q = 0; q < NA * NB; ++q) {
+          const int i = pair_i<ORDER, NA, NB>(q), j = pair_j<ORDER, NA, NB>(q);
+          c[(r & 1) * NA * NB + i * NB + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], c[(r & 1) * NA * NB + i * NB + j], 0, 0, 0);
+        }
       if ((it & 63) == 63)
 #pragma unroll
         for (int q = 0; q < NA * NB * 2; ++q) c[q] *= 0.5f;
@@ -71,13 +83,20 @@ int main() {
   hipMalloc(&sink, 64);
   const char* shapes[2] = {"16x16x32", "32x32x16"};
   const char* datas[3] = {"zero operands", "random operands", "one random fragment pair (operands constant)"};
+  const char* orders[3] = {"i-major", "serpentine", "diagonal"};
   const int iters = 20000;                       // 16 x 32768 FLOP x iters per wave
   for (int wps = 1; wps <= 2; ++wps)
     for (int data = 0; data < 3; ++data)
+      for (int order = 0; order < (data == 1 ? 3 : 1); ++order)
       for (int shape = 0; shape < 2; ++shape) {
         auto launch = [&]() {
-          if (shape == 0) hipLaunchKernelGGL(k<0>, dim3(256), dim3(512), 0, 0, sink, iters, data, wps);
-          else hipLaunchKernelGGL(k<1>, dim3(256), dim3(512), 0, 0, sink, iters, data, wps);
+          const dim3 g(256), b(512);
+          if (shape == 0 && order == 0) hipLaunchKernelGGL((k<0, 0>), g, b, 0, 0, sink, iters, data, wps);
+          if (shape == 0 && order == 1) hipLaunchKernelGGL((k<0, 1>), g, b, 0, 0, sink, iters, data, wps);
+          if (shape == 0 && order == 2) hipLaunchKernelGGL((k<0, 2>), g, b, 0, 0, sink, iters, data, wps);
+          if (shape == 1 && order == 0) hipLaunchKernelGGL((k<1, 0>), g, b, 0, 0, sink, iters, data, wps);
+          if (shape == 1 && order == 1) hipLaunchKernelGGL((k<1, 1>), g, b, 0, 0, sink, iters, data, wps);
+          if (shape == 1 && order == 2) hipLaunchKernelGGL((k<1, 2>), g, b, 0, 0, sink, iters, data, wps);
         };
         const double flop = 256.0 * 4 * wps * (double)iters * 16.0 * 32768.0;
         double last = 0;
@@ -93,7 +112,8 @@ int main() {
           hipEventDestroy(e0); hipEventDestroy(e1);
           ++n;
         }
-        printf("%d wave(s)/SIMD  %-9s %-46s: %7.0f TFLOP/s sustained (after %d x 4 launches)\n", wps, shapes[shape], datas[data], last, n);
+        printf("%d wave(s)/SIMD  %-9s %-46s %-10s: %7.0f TFLOP/s sustained (after %d x 4 launches)\n", wps, shapes[shape], datas[data],
+               data == 1 ? orders[order] : "", last, n);
         fflush(stdout);
       }
   return 0;

@@ -181,4 +181,15 @@ def test_handle_error_behaviour(model):
         fh.prepare(kw["txt"], kw["y"], None, False, kw["img_ids"], kw["txt_ids"], 2)
     with pytest.raises(hip.VclozeHipError, match="kv_len"):
         fh.prepare(kw["txt"], kw["y"], kw["guidance"], False, kw["img_ids"], kw["txt_ids"], 2, kv_len=[41])
+    # re-binding a weight invalidates the prepared state (and every captured step): forward refuses until prepared again
+    fh.prepare(kw["txt"], kw["y"], kw["guidance"], False, kw["img_ids"], kw["txt_ids"], 2)
+    W = m.engine().W
+    fh._bind("img_in", W.w["img_in"], W.b["img_in"], *W.w["img_in"].shape)
+    img = torch.cat((inp["x"], inp["cond"]), -1).to(DEV, torch.bfloat16)
+    out = torch.empty(1, 24, 64, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(hip.VclozeHipError, match="vc_flux_prepare first"):
+        fh.forward(img, torch.tensor([0.5]), False, out)
+    fh.prepare(kw["txt"], kw["y"], kw["guidance"], False, kw["img_ids"], kw["txt_ids"], 2)
+    fh.forward(img, torch.tensor([0.5]), False, out)
     torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()

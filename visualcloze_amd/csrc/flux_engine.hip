@@ -509,7 +509,8 @@ int vc_flux_bind_weight_impl(void* handle, const char* name, const void* w, cons
   l.w = w; l.b = bias; l.N = rows; l.K = cols; l.ldw = ldw;
   f.bound[name] = l;
   f.resolved = false;
-  drop_graph(f);      // a captured step holds the old pointers
+  f.prepared = false;   // the resolved per-block tables are rebuilt by the next vc_flux_prepare
+  drop_graph(f);        // a captured step holds the old pointers
   return VC_OK;
 }
 

@@ -2,10 +2,15 @@
 (models/model.py:85-124) and, for the fused sampler, the per-sample precomputation + hipGraph of one
 Euler step (transport/integrators.py:106-120).
 
+This is the Python-ordered twin of `csrc/flux_engine.hip` (the plan behind the handle API `vc_flux_*`, which is what
+`Flux.forward`, the fused sampler and bench.py run): same kernels, same order, same operands - bit-identical results
+(tests/test_handle_gpu.py).  It stays for the un-merged LoRA parity mode (`lora_mode="ref"`), per-block taps and A/B runs.
+
 Python here only ORDERS launches (once, under stream capture, for the sampler path); all arithmetic runs in
 libvcloze_hip.so.  A per-GPU batch of B samples with the same (T, N) runs as ONE launch sequence: GEMM rows of all
 samples are stacked (M = B*rows), modulation vectors / gates / RoPE tables / kv_len are indexed per sample
-inside the kernels, attention gets a batch grid dimension.  Ragged batches = per-sample kv_len (prefix masks).
+inside the kernels, attention gets a batch grid dimension.  Ragged batches = per-sample kv_len (+ one masked gap per
+sample for masks with holes, model.MaskLayout).
 
 HBM layout per geometry (B samples, T text tokens, N image tokens, L = T+N, D hidden, H heads), bf16 unless noted:
   XI   [B*N, D]      image residual stream of the DoubleStream blocks (samples stacked)
@@ -13,7 +18,8 @@ HBM layout per geometry (B samples, T text tokens, N image tokens, L = T+N, D hi
   X    [B*L, D]      joint residual stream of the SingleStream blocks: per sample text rows first, then image rows
                      (= the reference's cat((txt, img), 1)); filled from XT/XI once per evaluation
   XH   [B*L, D]      LayerNorm+modulate output (GEMM A operand); XH[:B*N] / XH[B*N:] serve the two streams
-  QKV  [B*L, 3D]     "B L (K H D)" rows in joint order; q,k are QK-normed + RoPE'd in place
+  QKV  [B*L, 3D]     "B L (K H D)" rows in joint order; k is QK-normed + RoPE'd in place (q inside the attention kernel
+                     with variants 8 / 12); the V third is not materialised when the qkv GEMM writes V^T itself (fuse_vt)
   VT   [B, H, 128, Lp]  V transposed per head, Lp = L rounded up to 64 (attention B operand is key-contiguous)
   CAT  [B*L, D+4D]   attn | gelu(mlp) = linear2's input (SingleStreamBlock); CAT[:, :D] is also the DoubleStream
                      attention output (joint order), whose rows the proj GEMMs read batch-strided

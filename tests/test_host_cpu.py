@@ -19,6 +19,11 @@ def test_abi_exports_every_declared_symbol():
     assert declared == set(hip.SYMBOLS), declared ^ set(hip.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
+    # ... and nothing else: every exported vc_* symbol of the product library is declared in the header
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--defined-only", hip.LIB_PATH], capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in nm.splitlines() if " T " in ln and ln.split()[-1].startswith("vc_")}
+    assert exported == declared, exported ^ declared
     assert hip.lib().vc_abi_version() == hip.ABI_VERSION
 
 

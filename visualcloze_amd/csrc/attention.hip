@@ -378,7 +378,9 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const AttnArgs a, int G
 
 
 static uint64_t* g_attn_debug_ts = nullptr;
-extern "C" void vc_debug_set_attn_ts(void* p) { g_attn_debug_ts = (uint64_t*)p; }   // tools/ only; not in the ABI header
+#ifdef VC_ATTN_TIMESTAMPS   // profiling builds only (`make debug`, tools/attn_ts.py): the product library exports the header's symbols and nothing else
+extern "C" void vc_debug_set_attn_ts(void* p) { g_attn_debug_ts = (uint64_t*)p; }
+#endif
 
 static int attn_cu_count() {
   static int n_cu = 0;

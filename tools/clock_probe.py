@@ -46,8 +46,16 @@ def loop(name, fn, seconds=4.0):
 
 qz, vz = torch.zeros_like(qkv), torch.zeros_like(vt)
 print("idle:", smi(), flush=True)
-loop("attention variant 12, ZERO operands (same instruction stream, no toggling)", lambda: hip.attention(qz, vz, o, L, H, variant=12))
-loop("attention variant 3, ZERO operands", lambda: hip.attention(qz, vz, o, L, H, variant=3))
-loop("attention variant 12", lambda: hip.attention(qkv, vt, o, L, H, variant=12))
-loop("attention variant 3", lambda: hip.attention(qkv, vt, o, L, H, variant=3))
+if os.environ.get("VC_PROBE", "all") == "all":
+    loop("attention variant 12, ZERO operands (same instruction stream, no toggling)", lambda: hip.attention(qz, vz, o, L, H, variant=12))
+    loop("attention variant 3, ZERO operands", lambda: hip.attention(qz, vz, o, L, H, variant=3))
+    loop("attention variant 12", lambda: hip.attention(qkv, vt, o, L, H, variant=12))
+    loop("attention variant 3", lambda: hip.attention(qkv, vt, o, L, H, variant=3))
 loop("GEMM GATE_RES 3968x3072x12288", lambda: hip.gemm(prob, epi=hip.EPI_GATE_RES))
+az, wz, xz = torch.zeros_like(a4), torch.zeros_like(w4), torch.zeros_like(x)
+probz = hip.make_problem(az, wz, b, xz, res=xz, gate=gate)
+loop("GEMM GATE_RES 3968x3072x12288, ZERO operands", lambda: hip.gemm(probz, epi=hip.EPI_GATE_RES))
+a1, w1 = torch.randn(L, D, device=dev).to(torch.bfloat16), (torch.randn(3 * D, D, device=dev) * D ** -0.5).to(torch.bfloat16)
+y1, b1 = torch.empty(L, 3 * D, dtype=torch.bfloat16, device=dev), torch.zeros(3 * D, dtype=torch.bfloat16, device=dev)
+loop("GEMM BIAS (qkv) 3968x9216x3072", lambda: hip.gemm(hip.make_problem(a1, w1, b1, y1)))
+loop("GEMM BIAS (qkv) 3968x9216x3072, ZERO operands", lambda: hip.gemm(hip.make_problem(torch.zeros_like(a1), torch.zeros_like(w1), b1, y1)))

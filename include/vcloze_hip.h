@@ -89,6 +89,10 @@ typedef struct VcGemmArgs {
  * VC_GEMM_NO_SPLIT (64) as tile_cfg keeps it one launch; (k << 8) forces the cut at row k * 256 (tests). */
 #define VC_GEMM_NO_SPLIT 64
 int vc_gemm(const VcGemmArgs* args, int tile_cfg, void* stream);
+/* The plan vc_gemm would execute for these arguments, without launching anything (works without a GPU): out[0] = first row
+ * of the second launch (0 = a single launch), out[1], out[2] = tile number (1..5 as above) and main-loop form (0 plain,
+ * 1 ping-pong, 2 loader waves) of the first or only launch, out[3], out[4] = of the second, out[5] = tiles of both. */
+int vc_gemm_plan(const VcGemmArgs* args, int tile_cfg, int32_t out[6]);
 
 /* LayerNorm(eps=1e-6, no affine) + AdaLN modulate: y = bf16((1+scale)*LN(x) + shift).
  * Replaces layers.py:163-164,191,195,234 / 257.  x,y: [rows, D] bf16 (row strides ldx/ldy);

@@ -176,3 +176,48 @@ def test_upsampling_host_glue():
     assert upsampling_size((1024, 1024)) == (1024, 1024)
     im = to_uint8_image(torch.tensor([0.0, 0.999, 1.0]).reshape(3, 1, 1).expand(3, 2, 4))
     assert im.size == (4, 2) and im.mode == "RGB" and im.getpixel((3, 1)) == (0, 254, 255)
+
+
+def test_gemm_launch_plans_for_the_flux_shapes():
+    """vc_gemm_plan = the tile choice and the optional row cut of vc_gemm, without a launch (no GPU needed): pins the cost
+    model on the shapes of every BASELINE geometry.  256x192 + loader waves (tile 4, form 2) wherever it fills whole rounds
+    (cfg 2: 256 / 768 / 1024 tiles = 1 / 3 / 4 rounds), 256x128 for the short cfg 1, and ONE cut: the N = 3072 launches at
+    L = 6656 (416 tiles = 1.6 rounds -> 256 tiles + 240 narrower ones)."""
+    import ctypes as C
+    from visualcloze_amd import hip
+    L = hip.lib()
+
+    def plan(Ms, N, K, epi=0, tile_cfg=0):
+        a = hip.GemmArgs()
+        a.nprob, a.epi = len(Ms), epi
+        for i, M in enumerate(Ms):
+            p = a.p[i]
+            p.A = p.W = p.C = p.res = p.gate = 0x1000          # never dereferenced by the planner
+            p.lda, p.ldw, p.ldc, p.ldres = K, K, N, N
+            p.M, p.N, p.K, p.rows_per_batch = M, N, K, M
+        out = (C.c_int32 * 6)()
+        rc = L.vc_gemm_plan(C.byref(a), tile_cfg, out)
+        assert rc == 0, L.vc_last_error()
+        return list(out)
+    T = 512
+    # cfg 2 (N_img = 3456): exact rounds of the 256x192 loader-wave tile, never cut
+    assert plan([3456, T], 3072, 3072, 2) == [0, 4, 2, 0, 0, 256]
+    assert plan([3456, T], 9216, 3072) == [0, 4, 2, 0, 0, 768]
+    assert plan([3968], 12288, 3072, 1) == [0, 4, 2, 0, 0, 1024]
+    assert plan([3968], 3072, 15360, 2) == [0, 4, 2, 0, 0, 256]
+    # cfg 1 (N_img = 1152): the 256x128 sibling for N = 3072 (168 tiles instead of 112)
+    assert plan([1152, T], 3072, 3072, 2)[:3] == [0, 2, 2]
+    # cfg 3 (N_img = 6144): N = 3072 is cut at 4096 rows -> 256 tiles of 256x192 + (8 + 2) x 24 = 240 tiles of 256x128
+    assert plan([6144, T], 3072, 12288, 2) == [4096, 4, 2, 2, 2, 496]
+    assert plan([6656], 3072, 15360, 2) == [4096, 4, 2, 2, 2, 496]
+    assert plan([6144, T], 3072, 12288, 2, hip.GEMM_NO_SPLIT) == [0, 4, 2, 0, 0, 416]
+    assert plan([6144, T], 9216, 3072) == [0, 4, 2, 0, 0, 1248]          # 4.9 rounds: nothing to gain
+    # cfg 5 (N_img = 6912) and the SDEdit stage (4096): cuts the model rates below 10 %, or with a half-empty remainder, are not taken
+    assert plan([6912, T], 12288, 3072, 1)[0] == 0 and plan([7424], 3072, 15360, 2)[0] == 0
+    assert plan([4096, T], 9216, 3072)[0] == 0 and plan([4608], 3072, 15360, 2)[:3] == [0, 2, 2]
+    # a fixed tile is taken literally; a forced cut is obeyed
+    assert plan([3968], 3072, 3072, 0, 1)[:3] == [0, 1, 0] and plan([3968], 3072, 3072, 0, 36)[:3] == [0, 4, 2]
+    assert plan([3968], 3072, 3072, 0, 3 << 8)[0] == 768
+    # argument errors come back as codes, with a message
+    a = hip.GemmArgs(); a.nprob = 1; a.p[0].M, a.p[0].N, a.p[0].K = 8, 8, 60
+    assert L.vc_gemm_plan(C.byref(a), 0, (C.c_int32 * 6)()) == -1 and b"multiple of 64" in L.vc_last_error()

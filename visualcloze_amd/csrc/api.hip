@@ -40,6 +40,10 @@ int vc_gemm(const VcGemmArgs* args, int tile_cfg, void* stream) {
   if (!args) { snprintf(g_err, sizeof(g_err), "gemm: null args"); return VC_ERR_ARG; }
   return vc_gemm_launch(*args, tile_cfg, S(stream), ERRBUF);
 }
+int vc_gemm_plan(const VcGemmArgs* args, int tile_cfg, int32_t out[6]) {
+  if (!args || !out) { snprintf(g_err, sizeof(g_err), "gemm_plan: null argument"); return VC_ERR_ARG; }
+  return vc_gemm_plan_impl(*args, tile_cfg, out, ERRBUF);
+}
 int vc_ln_modulate(const void* x, int64_t ldx, void* y, int64_t ldy, const void* shift, const void* scale,
                    int64_t mod_bstride, int32_t rows, int32_t D, int32_t rows_per_batch, const int32_t* step_ptr,
                    int64_t mod_step_stride, void* stream) {

@@ -690,9 +690,7 @@ int launch_tiles(VcGemmArgs a, int tile_cfg, int pp, hipStream_t s, char* err, i
 
 }  // namespace
 
-// tile_cfg: 0 = auto, 1 = 128x128 (4 waves), 2 = 256x128, 3 = 256x256, 4 = 256x192, 5 = 256x288 (8 waves each);
-// +16 = ping-pong main loop (3, 4, 5), +32 = ping-pong with loader waves (2, 4); VC_GEMM_NO_SPLIT / (k << 8): see the header
-int vc_gemm_launch(VcGemmArgs a, int tile_cfg, hipStream_t s, char* err, int errlen) {
+static int validate_gemm(VcGemmArgs& a, char* err, int errlen) {
   if (a.nprob < 1 || a.nprob > VC_GEMM_MAX_PROBLEMS) { snprintf(err, errlen, "gemm: nprob must be 1..%d", VC_GEMM_MAX_PROBLEMS); return VC_ERR_ARG; }
   for (int i = 0; i < a.nprob; ++i) {
     VcGemmProblem& p = a.p[i];
@@ -714,10 +712,16 @@ int vc_gemm_launch(VcGemmArgs a, int tile_cfg, hipStream_t s, char* err, int err
                p.vt_row0, p.vt_lpad, (long)p.vt_bstride); return VC_ERR_ARG; }
   }
   if (a.epi < 0 || a.epi > VC_EPI_QKV) { snprintf(err, errlen, "gemm: unknown epilogue %d", a.epi); return VC_ERR_ARG; }
+  return VC_OK;
+}
+
+// The launch plan of one vc_gemm call: cut = first row of the second launch (0 = one launch); tile / pp of the two launches.
+struct GemmPlan { int cut, tile1, pp1, tile2, pp2; };
+static GemmPlan plan_gemm(const VcGemmArgs& a, int tile_cfg) {
   const int force_cut = tile_cfg >> 8;                 // tests: cut problem 0 at row force_cut * 256
   const bool no_split = (tile_cfg & VC_GEMM_NO_SPLIT) != 0;
   tile_cfg &= 63;
-  if (tile_cfg != 0) return launch_tiles(a, tile_cfg & 15, (tile_cfg >> 4) & 3, s, err, errlen);
+  if (tile_cfg != 0) return GemmPlan{0, tile_cfg & 15, (tile_cfg >> 4) & 3, 0, 0};
   const TilePlan whole = best_tile(a);
   // Block-round quantisation: cut problem 0's rows where the 256x192 tiles above the cut are (nearly) whole rounds of the 256
   // CUs and price the remainder with the tile that suits it.  The two launches follow each other on the stream (the first
@@ -750,12 +754,35 @@ int vc_gemm_launch(VcGemmArgs a, int tile_cfg, hipStream_t s, char* err, int err
       if (t1 + rp.cost < best) { best = t1 + rp.cost; cut = rows; rest_plan = rp; }
     }
   }
-  if (cut == 0) return launch_tiles(a, whole.tile_cfg, whole.pp, s, err, errlen);
+  if (cut == 0) return GemmPlan{0, whole.tile_cfg, whole.pp, 0, 0};
+  return GemmPlan{cut, 4, 2, rest_plan.tile_cfg, rest_plan.pp};
+}
+
+// tile_cfg: 0 = auto, 1 = 128x128 (4 waves), 2 = 256x128, 3 = 256x256, 4 = 256x192, 5 = 256x288 (8 waves each);
+// +16 = ping-pong main loop (3, 4, 5), +32 = ping-pong with loader waves (2, 4); VC_GEMM_NO_SPLIT / (k << 8): see the header
+int vc_gemm_launch(VcGemmArgs a, int tile_cfg, hipStream_t s, char* err, int errlen) {
+  int rc = validate_gemm(a, err, errlen);
+  if (rc != VC_OK) return rc;
+  const GemmPlan pl = plan_gemm(a, tile_cfg);
+  if (pl.cut == 0) return launch_tiles(a, pl.tile1, pl.pp1, s, err, errlen);
   VcGemmArgs first = a;
   first.nprob = 1;
-  first.p[0].M = cut;                                          // rows [0, cut) of problem 0 on the 256x192 loader-wave tile
-  int rc = launch_tiles(first, 4, 2, s, err, errlen);
+  first.p[0].M = pl.cut;                                       // rows [0, cut) of problem 0 on the 256x192 loader-wave tile
+  rc = launch_tiles(first, pl.tile1, pl.pp1, s, err, errlen);
   if (rc != VC_OK) return rc;
-  a.p[0].m_begin = cut;
-  return launch_tiles(a, rest_plan.tile_cfg, rest_plan.pp, s, err, errlen);
+  a.p[0].m_begin = pl.cut;
+  return launch_tiles(a, pl.tile2, pl.pp2, s, err, errlen);
+}
+
+// the plan without the launch: out = {cut row, tile / loader mode of the first (or only) launch, of the second, tiles of both}
+int vc_gemm_plan_impl(VcGemmArgs a, int tile_cfg, int32_t out[6], char* err, int errlen) {
+  const int rc = validate_gemm(a, err, errlen);
+  if (rc != VC_OK) return rc;
+  const GemmPlan pl = plan_gemm(a, tile_cfg);
+  if (pl.tile1 < 1 || pl.tile1 > 5) { snprintf(err, errlen, "gemm: bad tile_cfg %d", pl.tile1); return VC_ERR_ARG; }
+  out[0] = pl.cut; out[1] = pl.tile1; out[2] = pl.pp1; out[3] = pl.tile2; out[4] = pl.pp2;
+  VcGemmArgs first = a, rest = a;
+  if (pl.cut) { first.nprob = 1; first.p[0].M = pl.cut; rest.p[0].m_begin = pl.cut; }
+  out[5] = (int32_t)(tiles_of(first, pl.tile1) + (pl.cut ? tiles_of(rest, pl.tile2) : 0));
+  return VC_OK;
 }

@@ -87,6 +87,7 @@ SYMBOLS = {
     "vc_device_count": (C.c_int, []),
     "vc_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "vc_gemm": (C.c_int, [C.POINTER(GemmArgs), C.c_int, _vp]),
+    "vc_gemm_plan": (C.c_int, [C.POINTER(GemmArgs), C.c_int, C.POINTER(C.c_int32)]),
     "vc_ln_modulate": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp]),
     "vc_ln_modulate2": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i64, _vp]),
     "vc_qknorm_rope_vt": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),

@@ -193,3 +193,29 @@ def test_handle_error_behaviour(model):
     fh.forward(img, torch.tensor([0.5]), False, out)
     torch.cuda.synchronize()
     assert torch.isfinite(out.float()).all()
+
+
+def test_step_graph_cache_eviction_and_recapture(model):
+    """The handle keeps the captured step of the 4 most recent geometries (a two-stage pipeline alternates between two);
+    cycling through 6 geometries twice evicts and re-captures every one of them - the second pass must reproduce the
+    first bit for bit, and so must a pass through the Python-ordered plan."""
+    from tests.procedural import tiny_inputs
+    from visualcloze_amd.transport import Sampler, create_transport
+    m, _ = model
+    fn = Sampler(create_transport()).sample_ode(sampling_method="euler", num_steps=3, do_shift=True, time_shifting_factor=1)
+    geoms = [((4, 12), (4, 12)), ((4, 12),), ((4, 8), (4, 8)), ((2, 12), (2, 12), (2, 12)), ((4, 16),), ((6, 12), (6, 12))]
+    cases = []
+    for i, rows in enumerate(geoms):
+        inp = tiny_inputs(B=1, rows_hw=rows, seed=20 + i)
+        cases.append((inp["x"].to(DEV, torch.bfloat16), _kw(inp)))
+    first = [fn(x, m.forward, kw) for x, kw in cases]
+    second = [fn(x, m.forward, kw) for x, kw in cases]
+    m.use_handle = False
+    try:
+        third = [fn(x, m.forward, kw) for x, kw in cases]
+    finally:
+        m.use_handle = True
+    torch.cuda.synchronize()
+    for a, b, c in zip(first, second, third):
+        assert torch.isfinite(a.float()).all() and torch.equal(a, b) and torch.equal(a, c)
+    assert len({tuple(a.shape) for a in first}) >= 4

@@ -217,7 +217,10 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
 #pragma unroll
           for (int i = 0; i < B_IT; ++i) stage_w_piece(d, d * BK, i);
         }
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      // the first barrier needs A(0) and W(0) only: W(1) - the last B_IT pieces issued - keeps flying, exactly as W(t+2)
+      // does in the steady state (it is waited for by the vmcnt(B_IT) that ends K-tile 0, one tile before its first reader)
+      if (nk > 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(B_IT) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       bar();
       int wsd = WD;                                     // W slot of tile kt+WD
       for (int kt = 0; kt < nk; ++kt) {

@@ -50,7 +50,6 @@ __global__ __launch_bounds__(512) void k(float* sink, int iters, int data, int w
       for (int r = 0; r < 2; ++r)
 #pragma unroll
         for (int q = 0; q < NA * NB; ++q) {
-          constexpr int dummy = 0; (void)dummy;
           const int i = pair_i<ORDER, NA, NB>(q), j = pair_j<ORDER, NA, NB>(q);
           c[i * NB + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], c[i * NB + j], 0, 0, 0);
         }

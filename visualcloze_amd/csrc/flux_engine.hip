@@ -62,7 +62,6 @@ struct Flux : Buffers {
   int B = 0, T = 0, N = 0, L = 0, Lp = 0, S = 0;
   bool ragged = false, gapped = false;
   char* base = nullptr;
-  int64_t ws_bytes = 0;
   // captured steps, most recently used first (a two-stage pipeline alternates between two geometries)
   hipGraphExec_t graph = nullptr;      // = graphs.front().second while a sample is in flight
   struct Key {
@@ -552,7 +551,7 @@ int vc_flux_prepare_impl(void* handle, const VcFluxInputs* in, void* workspace, 
   f.prepared = false;
   const int64_t need = carve(f, f, (char*)workspace, B, T, N, S);
   if (workspace_bytes < need) FAIL(VC_ERR_ARG, "flux_prepare: workspace of %lld bytes, %lld needed", (long long)workspace_bytes, (long long)need);
-  f.base = (char*)workspace; f.ws_bytes = workspace_bytes;
+  f.base = (char*)workspace;
   f.B = B; f.T = T; f.N = N; f.L = T + N; f.Lp = (f.L + 63) / 64 * 64; f.S = S;
   const int L = f.L, D = f.D;
   // masks

@@ -21,7 +21,7 @@ extern "C" {
 #define VC_ERR_HIP (-2)
 #define VC_ERR_STATE (-3)
 
-#define VC_ABI_VERSION 4
+#define VC_ABI_VERSION 5
 int vc_abi_version(void);
 const char* vc_last_error(void);
 /* sizeof(VcGemmProblem), sizeof(VcGemmArgs), sizeof(VcLnStream), sizeof(VcAttention), sizeof(VcFluxConfig),
@@ -180,6 +180,10 @@ int vc_concat_cols(const void* x, int32_t cx, const void* cond, int32_t cc, void
 /* Euler update of the fixed-grid solver: x = bf16(x + bf16(bf16(dt) * (-v))), dt = dts[*step_ptr] (f32 table;
  * torch casts the 0-dim f32 dt to the bf16 common dtype before the multiply, transport/integrators.py:119). */
 int vc_euler_step(void* x, const void* v, const float* dts, const int32_t* step_ptr, int64_t n, void* stream);
+/* The same update for an f32 ODE state (the solver keeps the caller's state dtype, integrators.py:119): x32 = x32 +
+ * f32(bf16(bf16(dt) * (-v))) - torch's promotion of f32 + (0-dim f32 * bf16) - and shadow = bf16(x32), what img_in's Linear
+ * reads under autocast.  v == NULL: refresh the shadow only. */
+int vc_euler_step_f32(float* x32, void* shadow, const void* v, const float* dts, const int32_t* step_ptr, int64_t n, void* stream);
 int vc_step_advance(int32_t* step_ptr, void* stream);
 /* SDEdit start state x0 = noise*(1-s) + latent*s with the reference's bf16 roundings (visualcloze.py:221) */
 int vc_sdedit_mix(const void* noise, const void* latent, float strength, void* out, int64_t n, void* stream);
@@ -295,10 +299,12 @@ typedef struct VcFluxInputs {   /* everything of model_kwargs that does not chan
 int vc_flux_prepare(void* handle, const VcFluxInputs* in, void* workspace, int64_t workspace_bytes, void* stream);
 /* ONE evaluation: out [B, N, out_channels] = Flux(img [B, N, in_channels]; timesteps HOST [B]) */
 int vc_flux_forward(void* handle, const void* img, const float* timesteps, int32_t timesteps_is_bf16, void* out, void* stream);
-/* The loop.  x [B, N, out_channels] bf16: in = x(t_grid[0]), out = x(t_grid[n_points-1]); cond [B, N, in - out channels];
- * t_grid HOST f32 [n_points] (n_points - 1 <= max_steps evaluations); state_is_bf16: the caller's ODE state is bf16, so the
- * model sees 1 - bf16(t_i) (torchdiffeq hands the drift t.to(y.dtype)), dt stays t[i+1] - t[i] in f32; trajectory: NULL or
- * [n_points - 1][B][N][out_channels] receiving the state after every step.  One captured hipGraph per step (re-captured only
+/* The loop.  x [B, N, out_channels]: in = x(t_grid[0]), out = x(t_grid[n_points-1]); cond [B, N, in - out channels] bf16;
+ * t_grid HOST f32 [n_points] (n_points - 1 <= max_steps evaluations); state_is_bf16 != 0: x, x_out and trajectory are bf16 -
+ * the pipeline's state dtype, visualcloze.py:399 - and the model sees 1 - bf16(t_i) (torchdiffeq hands the drift
+ * t.to(y.dtype)); state_is_bf16 == 0: x, x_out and trajectory are F32, the state is stepped in f32 (integrators.py:119 keeps
+ * the caller's dtype; the velocity and dt * velocity stay bf16 as under autocast) and the model sees 1 - t_i; dt is
+ * t[i+1] - t[i] in f32 either way; trajectory: NULL or [n_points - 1][B][N][out_channels] receiving the state after every step.  One captured hipGraph per step (re-captured only
  * when geometry, masks' kind, workspace or options change); with stream == NULL the steps are launched uncaptured.
  * begin / steps / end expose the same loop piecewise (bench.py times single steps): sample_euler = begin; steps(n-1); end. */
 int vc_flux_sample_euler(void* handle, void* x, const void* cond, const float* t_grid, int32_t n_points, int32_t state_is_bf16,

@@ -340,22 +340,24 @@ def time_grid(num_steps: int, n_tokens: int, do_shift: bool = True, time_shiftin
     return t
 
 
-def sample_euler(model_fn, x: Tensor, cond: Optional[Tensor], t: Tensor, P: Prec = Prec()):
+def sample_euler(model_fn, x: Tensor, cond: Optional[Tensor], t: Tensor, P: Prec = Prec(), state_f32: bool = False):
     """`Sampler.sample_ode(...)(x, model, kwargs)` with method="euler": returns the list of states.
-    model_fn(x_cat, timesteps) -> velocity;  drift = -model(x || cond, 1 - t)."""
+    model_fn(x_cat, timesteps) -> velocity;  drift = -model(x || cond, 1 - t).
+    state_f32 (bf16 mode only): the caller's state is f32 and STAYS f32 (transport/integrators.py:119: odeint keeps y's
+    dtype) - the model sees 1 - t_i unrounded and bf16(x) (img_in's autocast), only dt * f is rounded to bf16."""
     states = [x]
     B = x.shape[0]
     evals = []
     for i in range(len(t) - 1):
         # torchdiffeq's _PerturbFunc hands the drift t.to(y.dtype): a bf16 state sees bf16(t_i) (dt stays f32-derived)
-        ti = torch.ones(B) * P.r(t[i])
+        ti = torch.ones(B) * (t[i] if state_f32 else P.r(t[i]))
         tm = torch.ones_like(ti) * (1 - ti)
         xin = torch.cat((x, cond), dim=-1) if cond is not None else x
         v = model_fn(xin, tm)
         assert v.shape == x.shape, "Output shape from ODE solver must match input shape"
         dt = t[i + 1] - t[i]
         # bf16 mode: torch casts the 0-dim f32 dt to the common dtype (bf16) before multiplying a bf16 tensor
-        x = P.r(x + P.r(P.r(dt) * (-v)))
+        x = x + P.r(P.r(dt) * (-v)) if state_f32 else P.r(x + P.r(P.r(dt) * (-v)))
         states.append(x)
         evals.append(float(tm[0]))
     return states, evals

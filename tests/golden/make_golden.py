@@ -183,6 +183,12 @@ def main():
         out["flux_general_txt_mask"], out["flux_general_img_mask"] = inp3["txt_mask"].numpy(), inp3["img_mask"].numpy()
         out["flux_general"] = fwd(inp3, torch.tensor([0.9, 0.25])).numpy()
 
+        inp4 = tiny_inputs(B=2, seed=13)  # sample 1 has NO text at all (txt_mask all zeros): keys 0 .. T-1 masked
+        inp4["txt_mask"][1] = 0
+        inp4["img_mask"][0, [0, 3]] = 0
+        out["flux_notext_txt_mask"], out["flux_notext_img_mask"] = inp4["txt_mask"].numpy(), inp4["img_mask"].numpy()
+        out["flux_notext"] = fwd(inp4, torch.tensor([0.8, 0.3])).numpy()
+
         # ---------------- sampler: time grids + trajectories ----------------
         sampler = Sampler(create_transport("Linear", "velocity", do_shift=True))
         for n_tok in (1152, 3456, 6144, 6912):
@@ -240,6 +246,14 @@ def main():
         assert trajb.dtype == torch.bfloat16
         out["traj_bf16_model_t"] = np.array(seen, dtype=np.float64)
         out["traj_bf16_states"] = trajb.float().numpy()
+        # an F32 state through the same bf16 model (a caller that does not cast its noise): the solver keeps the state's
+        # dtype (integrators.py:119), the model sees 1 - t_i unrounded, only dt * f is bf16
+        seen = []
+        with torch.autocast("cpu", torch.bfloat16):
+            trajf = fn(inp["x"].float(), mb_fwd, kwb)
+        assert trajf.dtype == torch.float32
+        out["traj_f32state_model_t"] = np.array(seen, dtype=np.float64)
+        out["traj_f32state_states"] = trajf.numpy()
 
     # ---------------- latent-grid packer: the tensor part of prepare_modified (models/sampling.py:37-118) -------------
     # models.sampling imports cv2 / models.util (imwatermark) through image_embedders: stub those two modules.

@@ -156,6 +156,27 @@ def test_forward_general_masks_vs_golden(golden, variant):
         assert rel_l2(got[b], torch.tensor(golden["flux_general"])[b]) < TOL_GOLDEN
 
 
+@pytest.mark.parametrize("variant", [3, 12])
+def test_forward_sample_without_text_vs_reference(golden, variant):
+    """txt_mask all zeros for one sample (n_txt = 0): MaskLayout emits the gap (0, T) - a masked range that starts at key 0 -
+    and the reference's varlen attention attends over the image keys only (math.py:9-60).  Against the oracle, whose mask
+    handling is pinned to the reference's own general-mask run (`flux_general`)."""
+    from tests.helpers import parity_log, tiny_model
+    from tests.procedural import tiny_inputs
+    m, sd = tiny_model()
+    m.engine().attn_variant = variant
+    inp = tiny_inputs(B=2, seed=13)
+    inp["txt_mask"][1] = 0
+    inp["img_mask"][0, [0, 3]] = 0
+    assert torch.equal(inp["txt_mask"], torch.tensor(golden["flux_notext_txt_mask"]))
+    t = torch.tensor([0.8, 0.3])
+    got = _fwd(m, inp, t).float().cpu()
+    assert torch.isfinite(got).all()
+    err, err_ref = rel_l2(got, _oracle(sd, inp, t)), rel_l2(got, torch.tensor(golden["flux_notext"]))
+    parity_log(f"[tiny, one sample without text, variant {variant}] HIP vs bf16 oracle {err:.3e}, vs reference fp32 {err_ref:.3e}")
+    assert err < TOL_ORACLE and err_ref < TOL_GOLDEN
+
+
 def test_sampler_general_masks_vs_oracle():
     """The fused sampler keeps the state in kernel row order across the steps and scatters back at the end: against the
     oracle's bf16 sampler on masks with holes in both streams, and against host-driven stepping through Flux.forward."""
@@ -264,6 +285,37 @@ def test_fused_sampler_vs_golden_trajectory(model, golden):
     refb = golden["traj_bf16_states"]
     for i in range(1, refb.shape[0]):
         assert rel_l2(trb[i], refb[i]) < 2 * TOL_GOLDEN
+
+
+def test_fused_sampler_f32_state_stays_f32(model, golden):
+    """transport/integrators.py:119: odeint keeps the caller's state dtype.  An f32 state is stepped IN f32 by the fused
+    loop (vc_flux_sample_euler with state_is_bf16 = 0: f32 master state, bf16 shadow for img_in, Flux times unrounded):
+    bit-equal to host-driven stepping through Flux.forward with torch's own promotion rules, f32 out, and within the bf16
+    bound of the reference's own f32-state run (`traj_f32state_states`)."""
+    from tests.helpers import parity_log
+    from tests.procedural import tiny_inputs
+    from visualcloze_amd.transport import Sampler, create_transport
+    m, _ = model
+    inp = tiny_inputs(B=1)
+    fn = Sampler(create_transport()).sample_ode(sampling_method="euler", num_steps=5, do_shift=True, time_shifting_factor=1,
+                                                return_trajectory=True)
+    kw = dict(_kw(inp), guidance=inp["guidance"].to("cuda", torch.bfloat16))
+    x32 = inp["x"].to("cuda", torch.float32)
+    tr = fn(x32, m.forward, kw)
+    assert tr.dtype == torch.float32 and torch.equal(tr[0], x32)
+    eager = fn(x32, lambda x, **k: m.forward(x, **k), kw)               # foreign-callable path: x + dt * (-v) in torch
+    assert eager.dtype == torch.float32
+    assert torch.equal(tr, eager)
+    assert not torch.equal(tr[-1].to(torch.bfloat16).float(), tr[-1])    # finer than bf16: no per-step rounding of the state
+    ref = golden["traj_f32state_states"]
+    errs = [rel_l2(tr[i], ref[i]) for i in range(1, ref.shape[0])]
+    parity_log(f"[tiny, f32 ODE state] fused sampler vs reference f32-state run, per step {['%.2e' % e for e in errs]}")
+    assert max(errs) < 2 * TOL_GOLDEN
+    last = fn(x32, m.forward, kw)                                       # and without the trajectory buffer
+    assert torch.equal(last[-1], tr[-1])
+    with pytest.raises(Exception):                                      # the C handle refuses a state of the wrong dtype
+        h = m.handle()
+        h.sample_euler(x32.contiguous(), kw["cond"], torch.linspace(0, 1, 3), True, m.engine().stream.cuda_stream)
 
 
 def test_fused_sampler_sdedit_grid(model, golden):

@@ -340,6 +340,34 @@ def test_attention_with_in_kernel_query_norm(hip, variant, L, H, extra, kv_len, 
         hip.attention(w2, vt, o2, L, H, variant=3, B=B, q_norm=(qs, qs2, split, rope))
 
 
+@pytest.mark.parametrize("variant", [0, 3, 8, 12])
+@pytest.mark.parametrize("L,lo,hi,kv", [(320, 0, 128, 320), (320, 0, 100, 300), (200, 0, 64, 200), (512, 0, 192, 470), (96, 0, 64, 96)])
+def test_attention_leading_keys_masked(hip, variant, L, lo, hi, kv):
+    """A masked range that STARTS AT KEY 0 and covers whole 64-key tiles: what model.MaskLayout emits for a sample whose
+    txt_mask is all zeros (gap = (0, T)).  The online softmax then meets tiles without a single live key before its first
+    live one (running max still at its floor); the reference (math.py:9-60) simply attends over the remaining keys and
+    zeroes the masked query rows."""
+    H = 2
+    qkv = rnd(L, 3 * H * 128, seed=31)
+    vt = torch.zeros(1, H, 128, (L + 63) // 64 * 64, dtype=torch.bfloat16, device=DEV)
+    x = qkv.float().reshape(L, 3, H, 128)
+    vt[0, :, :, :L] = x[:, 2].permute(1, 2, 0).to(torch.bfloat16)
+    out = torch.full((L, H * 128), float("nan"), dtype=torch.bfloat16, device=DEV)
+    kvl = torch.tensor([kv], dtype=torch.int32, device=DEV)
+    gap = torch.tensor([[lo, hi]], dtype=torch.int32, device=DEV)
+    hip.attention(qkv, vt, out, L, H, kv_len=kvl, variant=variant, kv_gap=gap)
+    torch.cuda.synchronize()
+    live = torch.ones(L, dtype=torch.bool, device=DEV)
+    live[kv:] = False
+    live[lo:hi] = False
+    s = torch.einsum("qhd,khd->hqk", x[:, 0], x[:, 1]) * 128 ** -0.5
+    s[:, :, ~live] = float("-inf")
+    o = torch.einsum("hqk,khd->qhd", torch.softmax(s, -1), x[:, 2]).reshape(L, H * 128)
+    o[~live] = 0
+    check(out, R.rb(o))
+    assert float(out[~live].float().abs().sum()) == 0.0
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 7, 8, 12])
 def test_attention_softmax_rescale_branch(hip, variant):
     """Force the online-softmax running max to jump late (a spiked key in the LAST tile) and early."""

@@ -95,6 +95,10 @@ def test_flux_forward(golden, tiny_sd):
     inp3 = tiny_inputs(B=2, seed=7)                                # non-prefix masks in both streams
     inp3["txt_mask"], inp3["img_mask"] = torch.tensor(golden["flux_general_txt_mask"]), torch.tensor(golden["flux_general_img_mask"])
     close(_fwd(tiny_sd, inp3, torch.tensor(golden["flux_b2_t"]), F32), golden["flux_general"])
+    inp4 = tiny_inputs(B=2, seed=13)                               # sample 1 without any text (txt_mask all zeros)
+    inp4["txt_mask"], inp4["img_mask"] = torch.tensor(golden["flux_notext_txt_mask"]), torch.tensor(golden["flux_notext_img_mask"])
+    assert int(inp4["txt_mask"][1].sum()) == 0
+    close(_fwd(tiny_sd, inp4, torch.tensor([0.8, 0.3]), F32), golden["flux_notext"])
 
 
 def test_errors(tiny_sd):
@@ -173,5 +177,26 @@ def test_bf16_state_sampler_model_times_and_trajectory(golden, tiny_sd):
     states, evals = O.sample_euler(model_fn, P.r(inp["x"]), P.r(inp["cond"]), t, P)
     assert np.array_equal(np.array(evals, dtype=np.float64), seen)
     ref = torch.tensor(golden["traj_bf16_states"])
+    for i in range(1, 5):
+        assert ((states[i] - ref[i]).norm() / ref[i].norm()).item() < 5e-2
+
+
+def test_f32_state_sampler_keeps_the_state_in_f32(golden, tiny_sd):
+    """An f32 state through the bf16 model (transport/integrators.py:119: odeint keeps y's dtype): the reference's own run
+    records UNROUNDED Flux timesteps 1 - t_i and an f32 trajectory; the oracle's state_f32 mode reproduces the times
+    exactly and tracks the states within bf16 noise."""
+    inp = tiny_inputs(B=1)
+    P = O.Prec("bf16", "ref")
+    seen = golden["traj_f32state_model_t"]
+    t = O.time_grid(5, inp["x"].shape[1], True, 1)
+    assert np.array_equal((1 - t[:-1]).double().numpy(), seen)
+
+    def model_fn(xin, tm):
+        return O.flux_forward(tiny_sd, G, xin, inp["img_ids"], inp["txt"], inp["txt_ids"], tm, inp["y"], inp["txt_mask"],
+                              inp["img_mask"], inp["guidance"], P=P)
+    states, evals = O.sample_euler(model_fn, inp["x"], P.r(inp["cond"]), t, P, state_f32=True)
+    assert np.array_equal(np.array(evals, dtype=np.float64), seen)
+    ref = torch.tensor(golden["traj_f32state_states"])
+    assert not torch.equal(P.r(states[-1]), states[-1])                    # the state really is finer than bf16
     for i in range(1, 5):
         assert ((states[i] - ref[i]).norm() / ref[i].norm()).item() < 5e-2

@@ -43,6 +43,23 @@ WORKER = textwrap.dedent("""
             assert torch.equal(out[i], exp), i
     else:
         assert out is None
+    # a job that mixes grid sizes cannot use the padded tensor collective: falls back to gather_object, same contract
+    het = [torch.full((2 + i, 3), float(i)) for i in mine]
+    out = par.gather_latents(het, 5)
+    if r == 0:
+        assert [tuple(o.shape) for o in out] == [(2 + i, 3) for i in range(5)] and all(float(out[i][0, 0]) == i for i in range(5))
+    else:
+        assert out is None
+    # mixed dtypes on ONE rank only (rank 1 uniform) -> still the fallback everywhere
+    mix = [torch.full((2,), float(i)).to(torch.bfloat16 if (r == 0 and i == 2) else torch.float32) for i in mine]
+    out = par.gather_latents(mix, 5)
+    if r == 0:
+        assert out[2].dtype == torch.bfloat16 and out[1].dtype == torch.float32 and all(float(out[i][0]) == i for i in range(5))
+    # bf16 latents (the pipeline's state dtype) through the tensor path
+    lb = [torch.full((3,), float(i)).to(torch.bfloat16) for i in mine]
+    out = par.gather_latents(lb, 5)
+    if r == 0:
+        assert all(o.dtype == torch.bfloat16 and float(o[0]) == i for i, o in enumerate(out))
     t = par.max_over_ranks(1.0 + r)
     assert t == 2.0
     par.barrier()
@@ -151,3 +168,30 @@ def test_single_process_degenerates():
     assert par.max_over_ranks(1.5) == 1.5
     import torch
     assert par.broadcast_weights(torch.nn.Linear(2, 2)) == 0.0
+    lat = par.gather_latents([torch.ones(2, 3), torch.zeros(2, 3)], 2)
+    assert len(lat) == 2 and all(t.device.type == "cpu" for t in lat)
+
+
+def test_forced_world1_collectives_gloo(tmp_path):
+    """force=True runs the real collectives in a world of ONE process (what the one-GPU RCCL smoke test does with the
+    "nccl" backend): bucketed flat-buffer broadcast, latent gather, max over ranks."""
+    import subprocess
+    code = textwrap.dedent("""
+        import os, sys, torch
+        sys.path.insert(0, %r)
+        from visualcloze_amd import parallel as par
+        par.init_distributed("gloo", force=True)
+        assert torch.distributed.is_initialized() and par.world() == 1
+        m = torch.nn.Sequential(*[torch.nn.Linear(64, 64) for _ in range(6)])
+        before = torch.cat([p.reshape(-1) for p in m.parameters()]).clone()
+        assert par.broadcast_weights(m, bucket_bytes=40000, force=True) > 0.0
+        assert torch.equal(before, torch.cat([p.reshape(-1) for p in m.parameters()]))
+        out = par.gather_latents([torch.arange(6.).reshape(2, 3)], 1, force=True)
+        assert len(out) == 1 and torch.equal(out[0], torch.arange(6.).reshape(2, 3))
+        assert par.max_over_ranks(2.5, force=True) == 2.5
+        torch.distributed.destroy_process_group()
+        print("ok")
+    """) % REPO
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr

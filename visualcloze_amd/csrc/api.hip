@@ -91,6 +91,9 @@ int vc_concat_cols(const void* x, int32_t cx, const void* cond, int32_t cc, void
 int vc_euler_step(void* x, const void* v, const float* dts, const int32_t* step_ptr, int64_t n, void* stream) {
   return vc_euler_launch(x, v, dts, step_ptr, n, S(stream), ERRBUF);
 }
+int vc_euler_step_f32(float* x32, void* shadow, const void* v, const float* dts, const int32_t* step_ptr, int64_t n, void* stream) {
+  return vc_euler_f32_launch(x32, shadow, v, dts, step_ptr, n, S(stream), ERRBUF);
+}
 int vc_step_advance(int32_t* step_ptr, void* stream) { return vc_step_advance_launch(step_ptr, S(stream), ERRBUF); }
 
 int vc_sdedit_mix(const void* noise, const void* latent, float strength, void* out, int64_t n, void* stream) {

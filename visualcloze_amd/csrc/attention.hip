@@ -168,7 +168,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs a) 
   for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
+  // the running max starts at a FINITE floor: a tile whose keys are all masked (a gap that begins at key 0, i.e. a sample
+  // without text) then gives m_cand - m_run = 0 and p = 2^(-inf + 1e30) = 0 instead of the NaN of (-inf) - (-inf)
+  float m_run = -1e30f, l_run = 0.f;
   const float c_scale = 0.08838834764831845f * 1.4426950408889634f;  // 128^-0.5 * log2(e)
 
 #ifdef VC_ATTN_TIMESTAMPS
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnArgs a) 
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     // Deferred rescale: keep the running max (and skip the 64-multiply rescale of O) while no row of this wave grows
     // its max by more than 2^8 - P then stays <= 256, which bf16 (relative precision) and the f32 sums absorb; the
-    // branch is wave-uniform.  m_run = -inf on the first tile forces the rescale path there.
+    // branch is wave-uniform.  m_run = -1e30 until the first unmasked key forces the rescale path there.
     const float m_cand = fmaxf(m_run, mx * c_scale);
     float alpha = 1.0f;
     if (!__all(m_cand - m_run <= 8.0f)) {
@@ -382,14 +384,7 @@ static uint64_t* g_attn_debug_ts = nullptr;
 extern "C" void vc_debug_set_attn_ts(void* p) { g_attn_debug_ts = (uint64_t*)p; }
 #endif
 
-static int attn_cu_count() {
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
-  }
-  return n_cu;
-}
+static int attn_cu_count() { return vc_cu_count(); }
 
 int64_t vc_attention_scratch_bytes_impl() {
   return std::max((int64_t)2 * attn_cu_count() * 2 * PART_FLOATS * (int64_t)sizeof(float), vc_attention64_scratch_bytes_impl(attn_cu_count()));
@@ -428,8 +423,8 @@ int vc_attention_launch(const VcAttention& A, hipStream_t s, char* err, int errl
   const int n_cu = attn_cu_count();
   if (variant == 1) {  // 4 waves x 32 queries
     a.qblocks = (L + 127) / 128;
-    static bool done = false;
-    if (!done) { e = hipFuncSetAttribute((const void*)attn_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) goto fail; done = true; }
+    static VcOncePerDevice done;
+    if (done.need()) { e = hipFuncSetAttribute((const void*)attn_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) goto fail; done.mark(); }
     a.items = a.qblocks * H * B;
     const int G = 2 * n_cu;
     const int nkt = (L + KVB - 1) / KVB;
@@ -446,8 +441,8 @@ int vc_attention_launch(const VcAttention& A, hipStream_t s, char* err, int errl
     }
   } else {  // 8 waves x 32 queries
     a.qblocks = (L + 255) / 256;
-    static bool done8 = false;
-    if (!done8) { e = hipFuncSetAttribute((const void*)attn_fwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) goto fail; done8 = true; }
+    static VcOncePerDevice done8;
+    if (done8.need()) { e = hipFuncSetAttribute((const void*)attn_fwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); if (e != hipSuccess) goto fail; done8.mark(); }
     a.items = a.qblocks * H * B;
     hipLaunchKernelGGL(attn_fwd_kernel<8>, dim3(std::min(a.items, persist ? n_cu : a.items)), dim3(512), lds, s, a);
   }

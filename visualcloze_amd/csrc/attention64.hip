@@ -652,12 +652,12 @@ int vc_attention64_launch(const VcAttention& A, bool tail_split, int n_cu, uint6
   a.qblocks = (L + QB - 1) / QB;
   a.items = a.qblocks * H * B;
   a.full_rounds = -1; a.tail_items = 0; a.tail_units = 0; a.part = (float*)scratch;
-  static bool done = false;
+  static VcOncePerDevice done;
   hipError_t e;
-  if (!done) {
+  if (done.need()) {
     e = hipFuncSetAttribute((const void*)attn64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
     if (e != hipSuccess) { snprintf(err, errlen, "attention64 attribute: %s", hipGetErrorString(e)); return VC_ERR_HIP; }
-    done = true;
+    done.mark();
   }
   const int G = n_cu;
   const int nkt = (L + KVB - 1) / KVB;

@@ -55,6 +55,22 @@ __global__ void euler_kernel(bf16_t* __restrict__ x, const bf16_t* __restrict__ 
   x[i] = f2bf(bf2f(x[i]) + dy);
 }
 
+// The same update for a caller whose ODE state is f32 (integrators.py:119 keeps the state's dtype): y1 = y0 + dt * f0 with
+// f0 bf16 is f32(y0) + f32(bf16(bf16(dt) * f0)) in torch's type promotion; the bf16 shadow is what img_in reads next
+// (its Linear rounds the f32 input to bf16 under autocast, visualcloze.py:363).  v == nullptr: refresh the shadow only.
+__global__ void euler_f32_kernel(float* __restrict__ x32, bf16_t* __restrict__ shadow, const bf16_t* __restrict__ v,
+                                 const float* __restrict__ dts, const int* __restrict__ step_ptr, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float x = x32[i];
+  if (v) {
+    const float dt = rbf(dts[step_ptr ? *step_ptr : 0]);
+    x += rbf(dt * (-bf2f(v[i])));
+    x32[i] = x;
+  }
+  shadow[i] = f2bf(x);
+}
+
 // SDEdit start state (visualcloze.py:221): x0 = bf16(bf16(noise*(1-s)) + bf16(latent*s)), s a python float
 __global__ void sdedit_mix_kernel(const bf16_t* __restrict__ noise, const bf16_t* __restrict__ latent, float s,
                                   bf16_t* __restrict__ out, long n) {
@@ -138,6 +154,13 @@ int vc_euler_launch(void* x, const void* v, const float* dts, const int32_t* ste
   if (!x || !v || !dts || n <= 0) { snprintf(err, errlen, "euler_step: bad args"); return VC_ERR_ARG; }
   hipLaunchKernelGGL(euler_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (bf16_t*)x, (const bf16_t*)v, dts, step_ptr, (long)n);
   VC_CHECK_LAUNCH("euler_step");
+}
+int vc_euler_f32_launch(float* x32, void* shadow, const void* v, const float* dts, const int32_t* step_ptr, int64_t n, hipStream_t s,
+                        char* err, int errlen) {
+  if (!x32 || !shadow || (v && !dts) || n <= 0) { snprintf(err, errlen, "euler_step_f32: bad args"); return VC_ERR_ARG; }
+  hipLaunchKernelGGL(euler_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x32, (bf16_t*)shadow, (const bf16_t*)v, dts,
+                     step_ptr, (long)n);
+  VC_CHECK_LAUNCH("euler_step_f32");
 }
 int vc_step_advance_launch(int32_t* step_ptr, hipStream_t s, char* err, int errlen) {
   if (!step_ptr) { snprintf(err, errlen, "step_advance: null"); return VC_ERR_ARG; }

@@ -37,7 +37,7 @@ struct Err {
 
 struct Buffers {   // the workspace carve-up
   bf16_t *XI, *XT, *X, *XH, *QKV, *VT, *CAT, *HID, *TXT0, *XIN, *V, *XS, *COND, *MOD, *TEMB, *H1, *TVEC, *GVEC, *YVEC, *VEC, *GE, *GH, *YH;
-  float *ROPE, *TS, *DTS, *G32, *FREQS;
+  float *ROPE, *TS, *DTS, *G32, *FREQS, *XS32;
   int32_t *STEP, *KVLEN, *KVGAP;
   void* ATT_SCRATCH = nullptr;
   int64_t att_scratch_bytes = 0;
@@ -65,15 +65,16 @@ struct Flux : Buffers {
   // captured steps, most recently used first (a two-stage pipeline alternates between two geometries)
   hipGraphExec_t graph = nullptr;      // = graphs.front().second while a sample is in flight
   struct Key {
-    char* base; int B, T, N, S, ragged, gapped, variant, tile, fuse, fuse_vt; hipStream_t s;
+    char* base; int B, T, N, S, ragged, gapped, variant, tile, fuse, fuse_vt, state_f32; hipStream_t s;
     bool operator==(const Key& o) const {
       return base == o.base && B == o.B && T == o.T && N == o.N && S == o.S && ragged == o.ragged && gapped == o.gapped &&
-             variant == o.variant && tile == o.tile && fuse == o.fuse && fuse_vt == o.fuse_vt && s == o.s;
+             variant == o.variant && tile == o.tile && fuse == o.fuse && fuse_vt == o.fuse_vt && state_f32 == o.state_f32 && s == o.s;
     }
   } key{};
   std::vector<std::pair<Key, hipGraphExec_t>> graphs;
   // sampling state
   int steps_total = 0, steps_done = 0;
+  bool state_f32 = false;              // the sample in flight steps an f32 state (XS32; XS is its bf16 shadow)
   // host staging (pinned), reused once the copies that read it have completed
   char* pinned = nullptr;
   size_t pinned_bytes = 0, pinned_used = 0;
@@ -129,6 +130,7 @@ int64_t carve(Buffers& f, const Flux& g, char* base, int B, int T, int N, int S)
   f.ROPE = c.take<float>(B * L * 128);
   f.TS = c.take<float>((int64_t)S * B);      f.DTS = c.take<float>(S);
   f.G32 = c.take<float>(B);                  f.FREQS = c.take<float>(128);
+  f.XS32 = c.take<float>(B * N * out_ch);    // f32 master copy of the ODE state (state_is_bf16 == 0)
   f.STEP = c.take<int32_t>(1);               f.KVLEN = c.take<int32_t>(B);  f.KVGAP = c.take<int32_t>(2 * B);
   f.att_scratch_bytes = vc_attention_scratch_bytes_impl();
   f.ATT_SCRATCH = c.take<char>(f.att_scratch_bytes);
@@ -364,7 +366,8 @@ int evaluate(Flux& f, const int32_t* step_ptr, bool concat, const void* img_rows
   p.a_rpb = N; p.a_bstride = (int64_t)L * D;
   TRY(gemm(f, &p, 1, VC_EPI_BIAS, nullptr, 0, s, e));
   if (euler) {
-    TRY(vc_euler_launch(f.XS, f.V, f.DTS, step_ptr, (int64_t)B * N * out_ch, s, e.buf, e.len));
+    if (f.state_f32) TRY(vc_euler_f32_launch(f.XS32, f.XS, f.V, f.DTS, step_ptr, (int64_t)B * N * out_ch, s, e.buf, e.len));
+    else TRY(vc_euler_launch(f.XS, f.V, f.DTS, step_ptr, (int64_t)B * N * out_ch, s, e.buf, e.len));
     TRY(vc_step_advance_launch((int32_t*)step_ptr, s, e.buf, e.len));
   }
   return VC_OK;
@@ -430,7 +433,7 @@ void drop_graph(Flux& f) {
 
 // the hipGraph of ONE solver step: everything step-dependent (modulation rows, dt) is indexed on the device by STEP
 int step_graph(Flux& f, hipStream_t s, Err e) {
-  Flux::Key k{f.base, f.B, f.T, f.N, f.S, f.ragged, f.gapped, attention_variant(f), f.tile_cfg, f.fuse_qnorm, f.fuse_vt, s};
+  Flux::Key k{f.base, f.B, f.T, f.N, f.S, f.ragged, f.gapped, attention_variant(f), f.tile_cfg, f.fuse_qnorm, f.fuse_vt, f.state_f32, s};
   for (size_t i = 0; i < f.graphs.size(); ++i)
     if (f.graphs[i].first == k) {
       auto hit = f.graphs[i];
@@ -678,7 +681,13 @@ int vc_flux_sample_begin_impl(void* handle, const void* x, const void* cond, con
   TRY(stage_end(f, s, e));
   TRY(time_precompute(f, S, 0, s, e));
   const int64_t n = (int64_t)B * f.N;
-  TRY(d2d(f.XS, x, n * f.cfg.out_channels * 2, s, e));
+  f.state_f32 = !state_is_bf16;
+  if (f.state_f32) {
+    TRY(d2d(f.XS32, x, n * f.cfg.out_channels * 4, s, e));
+    TRY(vc_euler_f32_launch(f.XS32, f.XS, nullptr, nullptr, nullptr, n * f.cfg.out_channels, s, e.buf, e.len));   // XS = bf16(XS32)
+  } else {
+    TRY(d2d(f.XS, x, n * f.cfg.out_channels * 2, s, e));
+  }
   TRY(d2d(f.COND, cond, n * (f.cfg.in_channels - f.cfg.out_channels) * 2, s, e));
   HIP(hipMemsetAsync(f.STEP, 0, sizeof(int32_t), s), "hipMemsetAsync");
   if (s) TRY(step_graph(f, s, e));
@@ -692,11 +701,12 @@ int vc_flux_sample_steps_impl(void* handle, int32_t n_steps, void* trajectory, h
   if (n_steps < 0 || f.steps_done + n_steps > f.steps_total)
     FAIL(VC_ERR_ARG, "flux_sample_steps: %d more steps after %d of %d", n_steps, f.steps_done, f.steps_total);
   if (s && (!f.graph || f.key.s != s)) FAIL(VC_ERR_STATE, "flux_sample_steps: the step was captured on another stream");
-  const int64_t state_bytes = (int64_t)f.B * f.N * f.cfg.out_channels * 2;
+  const int64_t state_bytes = (int64_t)f.B * f.N * f.cfg.out_channels * (f.state_f32 ? 4 : 2);
+  const void* state = f.state_f32 ? (const void*)f.XS32 : (const void*)f.XS;
   for (int i = 0; i < n_steps; ++i) {
     if (s) HIP(hipGraphLaunch(f.graph, s), "hipGraphLaunch");
     else TRY(evaluate(f, f.STEP, true, nullptr, nullptr, true, s, e));
-    if (trajectory) TRY(d2d((char*)trajectory + (int64_t)i * state_bytes, f.XS, state_bytes, s, e));
+    if (trajectory) TRY(d2d((char*)trajectory + (int64_t)i * state_bytes, state, state_bytes, s, e));
     ++f.steps_done;
   }
   return VC_OK;
@@ -706,5 +716,6 @@ int vc_flux_sample_end_impl(void* handle, void* x_out, hipStream_t s, char* err,
   H(handle);
   if (!f.prepared || f.steps_total == 0) FAIL(VC_ERR_STATE, "flux_sample_end: no sample in flight");
   if (!x_out) FAIL(VC_ERR_ARG, "flux_sample_end: null output");
+  if (f.state_f32) return d2d(x_out, f.XS32, (int64_t)f.B * f.N * f.cfg.out_channels * 4, s, e);
   return d2d(x_out, f.XS, (int64_t)f.B * f.N * f.cfg.out_channels * 2, s, e);
 }

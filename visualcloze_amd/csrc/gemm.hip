@@ -569,11 +569,11 @@ hipError_t launch_cfg(const VcGemmArgs& a, int total_tiles, hipStream_t s) {
     case VC_EPI_SILU: fn = gemm_bf16_kernel<BM, BN, WM, WN, VC_EPI_SILU, PP>; break;
     default: return hipErrorInvalidValue;
   }
-  static bool attr_done[5] = {false, false, false, false, false};
-  if (!attr_done[a.epi]) {
+  static VcOncePerDevice attr_done[5];
+  if (attr_done[a.epi].need()) {
     hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return e;
-    attr_done[a.epi] = true;
+    attr_done[a.epi].mark();
   }
   hipLaunchKernelGGL(fn, dim3(total_tiles), dim3(NT), LDS, s, a);
   return hipGetLastError();
@@ -588,12 +588,12 @@ hipError_t launch_conv(const VcGemmArgs& a, int total_tiles, hipStream_t s) {
   constexpr int LDS = LDS_STAGES > LDS_EPI ? LDS_STAGES : LDS_EPI;
   void (*fn)(const VcGemmArgs) = a.epi == VC_EPI_GATE_RES ? gemm_bf16_kernel<BM, BN, 4, 2, VC_EPI_GATE_RES, 2, true>
                                                           : gemm_bf16_kernel<BM, BN, 4, 2, VC_EPI_BIAS, 2, true>;
-  static bool attr_done[2] = {false, false};
+  static VcOncePerDevice attr_done[2];
   const int k = a.epi == VC_EPI_GATE_RES ? 1 : 0;
-  if (!attr_done[k]) {
+  if (attr_done[k].need()) {
     hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return e;
-    attr_done[k] = true;
+    attr_done[k].mark();
   }
   hipLaunchKernelGGL(fn, dim3(total_tiles), dim3(NT), LDS, s, a);
   return hipGetLastError();
@@ -657,7 +657,8 @@ TilePlan best_tile(const VcGemmArgs& a) {
   for (int ci = 0; ci < N_CAND; ++ci) {
     const int c = cand[ci];
     const int per_cu = (c == 1) ? 2 : 1;
-    const long rounds = (tiles_of(a, c) + 256L * per_cu - 1) / (256L * per_cu);
+    const long n_cu = vc_cu_count();
+    const long rounds = (tiles_of(a, c) + n_cu * per_cu - 1) / (n_cu * per_cu);
     const double t = rounds * (per_cu * (double)cfg_bm[c] * cfg_bn[c] * ((double)a.p[0].K + cand_ovh[ci]) / cand_eff[ci]);
     if (t < best.cost) best = TilePlan{c, cand_pp[ci], t};
   }
@@ -743,8 +744,9 @@ static GemmPlan plan_gemm(const VcGemmArgs& a, int tile_cfg) {
       if (force_cut > 0 && mt != force_cut) continue;
       const int rows = mt * 256 < a.p[0].M ? mt * 256 : a.p[0].M;
       if (rows == a.p[0].M && a.nprob == 1) break;            // nothing left for the second launch
-      const long tiles1 = (long)mt * tn, rounds1 = (tiles1 + 255) / 256;
-      if (force_cut == 0 && tiles1 < 0.97 * 256.0 * rounds1) continue;
+      const long n_cu = vc_cu_count();
+      const long tiles1 = (long)mt * tn, rounds1 = (tiles1 + n_cu - 1) / n_cu;
+      if (force_cut == 0 && tiles1 < 0.97 * (double)n_cu * rounds1) continue;
       const double t1 = rounds1 * ((double)cfg_bm[4] * cfg_bn[4] * ((double)a.p[0].K + cand_ovh[1]) / cand_eff[1]);
       VcGemmArgs rest = a;
       rest.p[0].m_begin = rows;
@@ -752,7 +754,7 @@ static GemmPlan plan_gemm(const VcGemmArgs& a, int tile_cfg) {
       // the remainder must fill its own rounds too: a half-empty second launch loses more than the model credits it with
       // (measured: L = 4608 cut into 4096 + 512 rows, 144 - 192 tiles in the second launch: -0.7 % steps/s)
       const int per_cu = rp.tile_cfg == 1 ? 2 : 1;
-      const long tiles2 = tiles_of(rest, rp.tile_cfg), slots2 = (tiles2 + 256L * per_cu - 1) / (256L * per_cu) * 256L * per_cu;
+      const long tiles2 = tiles_of(rest, rp.tile_cfg), slots2 = (tiles2 + n_cu * per_cu - 1) / (n_cu * per_cu) * n_cu * per_cu;
       if (force_cut == 0 && tiles2 < 0.9 * slots2) continue;
       if (t1 + rp.cost < best) { best = t1 + rp.cost; cut = rows; rest_plan = rp; }
     }

@@ -4,6 +4,28 @@
 #include <stdio.h>
 #include "../../include/vcloze_hip.h"
 
+// One-time per-(kernel, device) setup (hipFuncSetAttribute) and per-device properties: the handle API is a public C ABI, a host
+// may drive several GPUs from one process, so nothing of this may be remembered per process only.
+constexpr int VC_MAX_DEVICES = 64;
+inline int vc_device_index() {
+  int d = 0;
+  (void)hipGetDevice(&d);
+  return d >= 0 && d < VC_MAX_DEVICES ? d : 0;
+}
+struct VcOncePerDevice {
+  bool done[VC_MAX_DEVICES] = {};
+  bool need() const { return !done[vc_device_index()]; }
+  void mark() { done[vc_device_index()] = true; }
+};
+inline int vc_cu_count() {          // compute units of the CURRENT device
+  static int n[VC_MAX_DEVICES] = {};
+  const int d = vc_device_index();
+  if (n[d] == 0) {
+    hipDeviceProp_t p;
+    n[d] = hipGetDeviceProperties(&p, d) == hipSuccess && p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+  }
+  return n[d];
+}
 int vc_gemm_launch(VcGemmArgs a, int tile_cfg, hipStream_t s, char* err, int errlen);
 int vc_gemm_plan_impl(VcGemmArgs a, int tile_cfg, int32_t out[6], char* err, int errlen);
 int vc_attention_launch(const VcAttention& a, hipStream_t s, char* err, int errlen);
@@ -28,6 +50,8 @@ int vc_gate_residual_launch(const void* y, int64_t ldy, const void* res, int64_t
 int vc_add3_launch(const void* a, const void* b, const void* c, void* y, int64_t n, int64_t bn, int64_t cn, hipStream_t s, char* err, int errlen);
 int vc_concat_cols_launch(const void* x, int cx, const void* cond, int cc, void* out, int64_t rows, hipStream_t s, char* err, int errlen);
 int vc_euler_launch(void* x, const void* v, const float* dts, const int32_t* step_ptr, int64_t n, hipStream_t s, char* err, int errlen);
+int vc_euler_f32_launch(float* x32, void* shadow, const void* v, const float* dts, const int32_t* step_ptr, int64_t n, hipStream_t s,
+                        char* err, int errlen);
 int vc_step_advance_launch(int32_t* step_ptr, hipStream_t s, char* err, int errlen);
 int vc_pack_latent_launch(const void* in, void* out, int C, int h, int w, int64_t ld, int col0, hipStream_t s, char* err, int errlen);
 int vc_pack_mask_launch(const void* in, void* out, int H, int W, int64_t ld, int col0, hipStream_t s, char* err, int errlen);

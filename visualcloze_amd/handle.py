@@ -130,8 +130,15 @@ class FluxHandle:
         hip._check(hip.lib().vc_flux_forward(self.h, img.data_ptr(), _fp(t), int(bool(timesteps_is_bf16)), out.data_ptr(),
                                              stream if stream is not None else hip.cur_stream()), "vc_flux_forward")
 
+    @staticmethod
+    def _state(x, state_is_bf16, what):
+        import torch
+        want = torch.bfloat16 if state_is_bf16 else torch.float32     # the ABI takes the state in the caller's dtype
+        if x.dtype != want:
+            raise hip.VclozeHipError(f"{what}: state_is_bf16={bool(state_is_bf16)} needs a {want} state tensor, got {x.dtype}")
+
     def sample_begin(self, x, cond, t_grid, state_is_bf16: bool, stream) -> None:
-        hip._bf16(x, "x"); hip._bf16(cond, "cond")
+        self._state(x, state_is_bf16, "vc_flux_sample_begin"); hip._bf16(cond, "cond")
         if not (x.is_contiguous() and cond.is_contiguous()):
             raise hip.VclozeHipError("vc_flux_sample: contiguous x / cond expected")
         t = _f32(t_grid).reshape(-1)
@@ -145,8 +152,11 @@ class FluxHandle:
         hip._check(hip.lib().vc_flux_sample_end(self.h, x_out.data_ptr(), stream), "vc_flux_sample_end")
 
     def sample_euler(self, x, cond, t_grid, state_is_bf16: bool, stream, trajectory=None) -> None:
-        """x [B,N,C] bf16 in place: x(t_grid[0]) -> x(t_grid[-1]); trajectory: optional [S,B,N,C] bf16 buffer"""
-        hip._bf16(x, "x"); hip._bf16(cond, "cond")
+        """x [B,N,C] in place (bf16, or f32 with state_is_bf16 False): x(t_grid[0]) -> x(t_grid[-1]); trajectory: optional
+        [S,B,N,C] buffer of the state's dtype"""
+        self._state(x, state_is_bf16, "vc_flux_sample_euler"); hip._bf16(cond, "cond")
+        if trajectory is not None:
+            self._state(trajectory, state_is_bf16, "vc_flux_sample_euler (trajectory)")
         if not (x.is_contiguous() and cond.is_contiguous()) or (trajectory is not None and not trajectory.is_contiguous()):
             raise hip.VclozeHipError("vc_flux_sample_euler: contiguous x / cond / trajectory expected")
         t = _f32(t_grid).reshape(-1)

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VC_HIP_LIB") or os.path.join(_HERE, "lib", "libvcloze_hip.so")   # VC_HIP_LIB: profiling build
 CSRC = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 4                # VC_ABI_VERSION of include/vcloze_hip.h
+ABI_VERSION = 5                # VC_ABI_VERSION of include/vcloze_hip.h
 GEMM_MAX_PROBLEMS = 4          # VC_GEMM_MAX_PROBLEMS: grouped problems per vc_gemm launch
 EPI_BIAS, EPI_GELU, EPI_GATE_RES, EPI_SILU, EPI_QKV = 0, 1, 2, 3, 4
 GEMM_NO_SPLIT = 64             # VC_GEMM_NO_SPLIT: tile_cfg value that keeps an auto-tiled vc_gemm one launch
@@ -101,6 +101,7 @@ SYMBOLS = {
     "vc_copy": (C.c_int, [_vp, _vp, _i64, _vp]),
     "vc_concat_cols": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i64, _vp]),
     "vc_euler_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
+    "vc_euler_step_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "vc_step_advance": (C.c_int, [_vp, _vp]),
     "vc_sdedit_mix": (C.c_int, [_vp, _vp, C.c_float, _vp, _i64, _vp]),
     "vc_pack_latent": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _i32, _vp]),
@@ -414,6 +415,12 @@ def concat_cols(x, cond, out, stream=None):
     _check(lib().vc_concat_cols(x.data_ptr(), x.shape[1], cond.data_ptr(), cond.shape[1], out.data_ptr(), rows,
                                 stream if stream is not None else cur_stream()), "vc_concat_cols")
     return out
+
+
+def euler_step_f32(x32, shadow, v, dts, step_ptr=None, stream=None):
+    """f32 master state: x32 += f32(bf16(bf16(dt) * (-v))); shadow = bf16(x32).  v None: refresh the shadow only."""
+    _check(lib().vc_euler_step_f32(x32.data_ptr(), shadow.data_ptr(), _p(v), _p(dts), _p(step_ptr), x32.numel(),
+                                   stream if stream is not None else cur_stream()), "vc_euler_step_f32")
 
 
 def euler_step(x, v, dts, step_ptr=None, stream=None):

@@ -276,16 +276,32 @@ class Flux(nn.Module):
 
     @staticmethod
     @torch.no_grad()
-    def merged_linear(m: "Linear"):
+    def merged_linear(m: "Linear", consume: bool = False, out: Optional[Tensor] = None):
         """(W', b') of one Linear as the engine executes it: bf16(W + s*B@A), bf16(b + s*b_B) - LinearLora
-        (models/modules/lora.py:92-98) with its LoRA pair folded in, exact in f32 and rounded to bf16 once."""
-        W32 = m.weight.detach().float()
+        (models/modules/lora.py:92-98) with its LoRA pair folded in, exact in f32 and rounded to bf16 once.
+        `out`: write W' into this [out, in] bf16 view instead of a new tensor (the stacked modulation matrix).
+        `consume`: the module gives its storage away - W' overwrites m.weight's own memory (when that is a contiguous bf16
+        tensor) and every parameter of the Linear is left EMPTY, so that preparing a sampling-only rank never holds the
+        un-merged and the merged set at once (26.3 GB peak instead of 56.7)."""
+        W = m.weight.detach()
+        W32 = W.float()
         B32 = None if m.bias is None else m.bias.detach().float()
         if m.rank:
-            W32 = W32 + m.scale * (m.lora_B.weight.detach().float() @ m.lora_A.weight.detach().float())
+            W32 += m.scale * (m.lora_B.weight.detach().float() @ m.lora_A.weight.detach().float())
             if m.lora_B.bias is not None:
                 B32 = (B32 if B32 is not None else 0) + m.scale * m.lora_B.bias.detach().float()
-        return W32.to(torch.bfloat16).contiguous(), None if B32 is None else B32.to(torch.bfloat16).contiguous()
+        if out is None and consume and W.dtype == torch.bfloat16 and W.is_contiguous():
+            out = W
+        if out is None:
+            out = W32.to(torch.bfloat16).contiguous()
+        else:
+            out.copy_(W32)
+        del W32
+        bias = None if B32 is None else B32.to(torch.bfloat16).contiguous()
+        if consume:
+            for p in m.parameters():
+                p.data = torch.empty(0, dtype=p.dtype, device=p.device)
+        return out, bias
 
     @torch.no_grad()
     def prepare(self, free_parameters: bool = False) -> FluxEngine:
@@ -304,9 +320,29 @@ class Flux(nn.Module):
             raise ValueError(f"lora_mode must be 'merged' or 'ref', got {self.lora_mode!r}")
         w, b, ref = {}, {}, ({} if self.lora_mode == "ref" else None)
         bf = lambda t: None if t is None else t.detach().to(torch.bfloat16).contiguous()  # noqa: E731
-        for name, m in self._linears():
+        # all modulation projections are stacked: one GEMM yields every shift/scale/gate of a step.  Their merged rows
+        # are written straight into the stacked matrix (no 6.5 GB concatenation copy).
+        mods: List[str] = []
+        for i in range(self.params.depth):
+            mods += [f"double_blocks.{i}.img_mod.lin", f"double_blocks.{i}.txt_mod.lin"]
+        mods += [f"single_blocks.{i}.modulation.lin" for i in range(self.params.depth_single_blocks)]
+        mods.append("final_layer.adaLN_modulation.1")
+        lin = dict(self._linears())
+        off, o = {}, 0
+        for n in mods:
+            off[n] = o
+            o += lin[n].out_features
+        mod_w = torch.empty(o, self.hidden_size, dtype=torch.bfloat16, device=dev)
+        mod_b = torch.zeros(o, dtype=torch.bfloat16, device=dev)
+        consume = free_parameters and ref is None
+        for name, m in lin.items():
             if ref is None:
-                w[name], b[name] = self.merged_linear(m)
+                if name in off:
+                    _, bb = self.merged_linear(m, consume, out=mod_w[off[name]:off[name] + m.out_features])
+                    if bb is not None:
+                        mod_b[off[name]:off[name] + m.out_features] = bb
+                else:
+                    w[name], b[name] = self.merged_linear(m, consume)
                 continue
             w[name], b[name] = bf(m.weight), bf(m.bias)
             A = B = bB = sc = None
@@ -321,7 +357,12 @@ class Flux(nn.Module):
             ref[name] = RefLinear(w[name], b[name], A, B, bB, sc)
         for name, p in self.named_parameters():
             if name.endswith("norm.scale"):
-                w[name] = p.detach().to(torch.bfloat16).contiguous()
+                w[name] = p.detach().to(torch.bfloat16).contiguous().clone()
+        if ref is not None:              # parity mode: the modulation Linears were collected un-stacked above
+            for n in mods:
+                mod_w[off[n]:off[n] + w[n].shape[0]] = w[n]
+                if b[n] is not None:
+                    mod_b[off[n]:off[n] + w[n].shape[0]] = b[n]
         D = self.hidden_size
         for i in range(self.params.depth_single_blocks):
             n = f"single_blocks.{i}.linear1"
@@ -333,18 +374,9 @@ class Flux(nn.Module):
                 for sfx, sl in ((".qkv", slice(0, 3 * D)), (".mlp", slice(3 * D, None))):
                     ref[n + sfx] = RefLinear(r.w[sl], r.b[sl], r.A, None if r.B is None else r.B[sl],
                                              None if r.bB is None else r.bB[sl], None if r.scale is None else r.scale[sl])
-        # all modulation projections stacked: one GEMM yields every shift/scale/gate of a step
-        mods: List[str] = []
-        for i in range(self.params.depth):
-            mods += [f"double_blocks.{i}.img_mod.lin", f"double_blocks.{i}.txt_mod.lin"]
-        mods += [f"single_blocks.{i}.modulation.lin" for i in range(self.params.depth_single_blocks)]
-        mods.append("final_layer.adaLN_modulation.1")
-        off, o = {}, 0
         for n in mods:
-            off[n] = o
-            o += w[n].shape[0]
-        mod_w = torch.cat([w.pop(n) for n in mods], dim=0).contiguous()
-        mod_b = torch.cat([b.pop(n) for n in mods], dim=0).contiguous()
+            w.pop(n, None)
+            b.pop(n, None)
         half = 128
         freqs = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half).to(dev)
         pw = PreparedWeights(w=w, b=b, mod_w=mod_w, mod_b=mod_b, mod_off=off, n_mod=o, temb_freqs=freqs, ref=ref)
@@ -360,7 +392,13 @@ class Flux(nn.Module):
 
     def invalidate_engine(self) -> None:
         """Forget the prepared (merged, bf16) weights; the next forward / sample re-prepares.  Call after writing the
-        parameters through a path that does not bump `_version` (`.data`, dist.broadcast)."""
+        parameters through a path that does not bump `_version` (`.data`, dist.broadcast).  Refused on a model whose
+        parameters were released by prepare(free_parameters=True): the engine then holds the ONLY copy of the weights and
+        dropping it would leave the module unusable (its parameters are empty, load_state_dict cannot fill them)."""
+        if getattr(self, "_params_freed", False):
+            raise hip.VclozeHipError("invalidate_engine: this model's parameters were released by prepare(free_parameters="
+                                     "True); the prepared engine is the only copy of the weights - build a new model to "
+                                     "load other weights")
         self._engine = None
         self._handle = None
         self._fingerprint = None

@@ -20,9 +20,10 @@ def env_rank_world():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
 
-def init_distributed(backend: Optional[str] = None, device: Optional[torch.device] = None) -> None:
-    """Rendezvous from MASTER_ADDR/MASTER_PORT (use 127.0.0.1 on one node)."""
-    if dist.is_initialized() or int(os.environ.get("WORLD_SIZE", 1)) == 1:
+def init_distributed(backend: Optional[str] = None, device: Optional[torch.device] = None, force: bool = False) -> None:
+    """Rendezvous from MASTER_ADDR/MASTER_PORT (use 127.0.0.1 on one node).  A single-process job skips the process group
+    unless `force` (the one-GPU RCCL smoke test creates a world-1 communicator on purpose)."""
+    if dist.is_initialized() or (int(os.environ.get("WORLD_SIZE", 1)) == 1 and not force):
         return
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver
     backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
@@ -73,12 +74,17 @@ def rank() -> int:
     return dist.get_rank() if dist.is_initialized() else 0
 
 
-def broadcast_weights(module: torch.nn.Module, src: int = 0, bucket_bytes: int = 1 << 30) -> float:
+def broadcast_weights(module: torch.nn.Module, src: int = 0, bucket_bytes: int = 1 << 30, force: bool = False) -> float:
     """One-time broadcast of every parameter from `src` (the frozen FLUX + LoRA weights, 26.3 GB bf16 at full
     size).  Parameters are coalesced into ~1 GiB flat buckets: xGMI is point-to-point, so a few large
-    transfers per link beat a thousand small ones.  Returns the seconds spent."""
-    if world() == 1:
+    transfers per link beat a thousand small ones.  Returns the seconds spent.  `force`: run the collectives even in a
+    world of one (exercises communicator creation and the bucket code on one GPU)."""
+    if world() == 1 and not (force and dist.is_initialized()):
         return 0.0
+    for m in module.modules():
+        if getattr(m, "_params_freed", False):
+            raise RuntimeError("broadcast_weights: this module's parameters were released by prepare(free_parameters=True) - "
+                               "broadcast BEFORE preparing a sampling-only rank")
     t0 = time.time()
     params = [p.data for p in module.parameters()]
     i = 0
@@ -122,35 +128,61 @@ def sample_seed(base_seed: int, global_index: int) -> int:
     return int(base_seed) + int(global_index)
 
 
-def max_over_ranks(seconds: float, device: Optional[torch.device] = None) -> float:
-    if world() == 1:
+def max_over_ranks(seconds: float, device: Optional[torch.device] = None, force: bool = False) -> float:
+    if world() == 1 and not (force and dist.is_initialized()):
         return seconds
     t = torch.tensor([seconds], dtype=torch.float64, device=device or "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
-def gather_latents(local: Sequence[torch.Tensor], n_samples: int) -> Optional[List[torch.Tensor]]:
-    """Collect the final latents (0.44 MB per sample at cfg 2) on rank 0 in global sample order."""
-    if world() == 1:
-        return list(local)
-    # one tensor collective, no pickling: every rank contributes ceil(n / world) slots of the common latent shape
-    # (ranks with one sample fewer pad with zeros); NCCL/RCCL gathers device tensors, gloo host tensors
+def gather_latents(local: Sequence[torch.Tensor], n_samples: int, force: bool = False) -> Optional[List[torch.Tensor]]:
+    """Collect the final latents (0.44 MB per sample at cfg 2) on rank 0 in global sample order, as HOST tensors (in a
+    world of one too).  Every sample of the job normally has one shape and dtype - then ONE padded tensor collective moves
+    them (no pickling; RCCL gathers device tensors, gloo host tensors); a job that mixes grid sizes or dtypes falls back to
+    `gather_object`."""
+    if any(t.shape != local[0].shape or t.dtype != local[0].dtype for t in local[1:]):
+        uniform_here = 0
+    else:
+        uniform_here = 1
+    if world() == 1 and not (force and dist.is_initialized()):
+        return [t.detach().cpu() for t in local]
     w, r = world(), rank()
     slots = (n_samples + w - 1) // w
     on_gpu = dist.get_backend() == "nccl"
     dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
     ref = local[0] if local else None
     dtypes = [torch.float32, torch.bfloat16, torch.float16, torch.float64]
-    meta = torch.zeros(10, dtype=torch.int64)
-    if ref is not None:
-        meta[0] = ref.dim()
-        meta[1:1 + ref.dim()] = torch.tensor(ref.shape)
-        meta[9] = dtypes.index(ref.dtype)
-    meta = meta.to(dev)
+    # (ndim, shape[8], dtype) per rank, reduced with MAX and, negated, with MIN: equal on every rank that has a sample
+    # <=> MAX == -MAX(-x) over those ranks; ranks without a sample contribute the neutral element to both
+    BIG = 1 << 40
+    hi = torch.full((11,), -BIG, dtype=torch.int64)
+    lo = torch.full((11,), -BIG, dtype=torch.int64)
+    if ref is not None and ref.dtype in dtypes and ref.dim() <= 8:
+        v = torch.zeros(11, dtype=torch.int64)
+        v[0] = ref.dim()
+        v[1:1 + ref.dim()] = torch.tensor(ref.shape, dtype=torch.int64)
+        v[9] = dtypes.index(ref.dtype)
+        v[10] = uniform_here
+        hi, lo = v.clone(), -v
+    elif ref is not None:
+        hi[10], lo[10] = 0, 0                            # a dtype / rank the tensor path does not cover
+    meta = torch.stack((hi, lo)).to(dev)
     dist.all_reduce(meta, op=dist.ReduceOp.MAX)         # ranks without a sample learn the shape
-    shp = [int(v) for v in meta[1:1 + int(meta[0])].tolist()]
-    dtype = dtypes[int(meta[9])]
+    hi, lo = meta[0].cpu(), -meta[1].cpu()
+    uniform = bool((hi[:10] == lo[:10]).all()) and int(lo[10]) == 1 and int(hi[0]) >= 0
+    if not uniform:
+        objs = [None] * w if r == 0 else None
+        dist.gather_object([t.detach().cpu() for t in local], objs, dst=0)
+        if r != 0:
+            return None
+        out: List[Optional[torch.Tensor]] = [None] * n_samples
+        for rr in range(w):
+            for i, k in enumerate(shard_indices(n_samples, rr, w)):
+                out[k] = objs[rr][i]
+        return out  # type: ignore[return-value]
+    shp = [int(v) for v in hi[1:1 + int(hi[0])].tolist()]
+    dtype = dtypes[int(hi[9])]
     buf = torch.zeros(slots, *shp, dtype=dtype, device=dev)
     for i, t in enumerate(local):
         buf[i].copy_(t)
@@ -158,7 +190,7 @@ def gather_latents(local: Sequence[torch.Tensor], n_samples: int) -> Optional[Li
     dist.gather(buf, parts, dst=0)
     if r != 0:
         return None
-    out: List[Optional[torch.Tensor]] = [None] * n_samples
+    out = [None] * n_samples
     for rr in range(w):
         for i, k in enumerate(shard_indices(n_samples, rr, w)):
             out[k] = parts[rr][i].cpu()

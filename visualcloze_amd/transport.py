@@ -82,11 +82,21 @@ class Sampler:
             t = solver_time_grid(num_steps, x.shape[1], t0, t1, do_shift, time_shifting_factor)
             from .model import Flux
             owner = getattr(model, "__self__", None)
-            if isinstance(owner, Flux) and getattr(model, "__name__", "") == "forward":
+            if isinstance(owner, Flux) and getattr(model, "__name__", "") == "forward" and _fusable(owner, x):
                 return _sample_fused(owner, x, dict(model_kwargs), t, return_trajectory)
             return _sample_foreign(model, x, dict(model_kwargs), t, return_trajectory)
 
         return _sample
+
+
+def _fusable(flux, x: torch.Tensor) -> bool:
+    """The fused loop steps a bf16 state (the pipeline's, visualcloze.py:399) or - through the C handle - an f32 one IN f32
+    (integrators.py:119 keeps the caller's state dtype).  Anything else (f16 / f64 states, an f32 state in the un-merged LoRA
+    parity mode whose plan is ordered from Python) is stepped eagerly through Flux.forward with torch's own promotion rules:
+    never a silent per-step rounding of the caller's state."""
+    if x.dtype == torch.bfloat16:
+        return True
+    return x.dtype == torch.float32 and flux.handle() is not None
 
 
 def _solver_t_as_state(t: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
@@ -136,7 +146,8 @@ def _sample_fused(flux, x, kw, t, return_trajectory):
     eval_t = model_times(t32, x)                   # Flux sees 1 - t (transport.py:384), t in the state's dtype
     dts = (t32[1:] - t32[:-1]).contiguous()        # torchdiffeq fixed grid: dt = t1 - t0
     bf = lambda a: a.to(dev, torch.bfloat16).contiguous()  # noqa: E731
-    out = torch.empty(B, N, C, dtype=torch.bfloat16, device=dev)
+    sdt = x.dtype                                  # bf16, or f32 (handle path only): the state is stepped in ITS dtype
+    out = torch.empty(B, N, C, dtype=sdt, device=dev)
     traj = []
     gbf16 = guidance is not None and guidance.dtype == torch.bfloat16
     from .model import MaskLayout, per_sample
@@ -144,9 +155,9 @@ def _sample_fused(flux, x, kw, t, return_trajectory):
     lay = MaskLayout(kw.get("txt_mask"), kw.get("img_mask"), B, T, N)
     st = eng.stream
     st.wait_stream(torch.cuda.current_stream())
-    # the C handle runs the whole trajectory of a chunk in ONE call (vc_flux_sample_euler); states in other dtypes than
-    # bf16 / f32 (whose t rounding the ABI does not express) and the un-merged LoRA mode use the Python-ordered plan
-    h = flux.handle() if x.dtype in (torch.bfloat16, torch.float32) else None
+    # the C handle runs the whole trajectory of a chunk in ONE call (vc_flux_sample_euler); the un-merged LoRA mode uses the
+    # Python-ordered plan (bf16 states only: _fusable)
+    h = flux.handle()
     with torch.cuda.stream(st):
         s = st.cuda_stream
         for b0 in range(0, B, eng.MAX_BATCH):        # a chunk of samples advances together, one graph replay per step
@@ -155,8 +166,8 @@ def _sample_fused(flux, x, kw, t, return_trajectory):
             if h is not None:
                 h.prepare(bf(lay.txt_rows(txt, sl)), bf(y[sl]), None if guidance is None else guidance[sl], gbf16,
                           lay.img_rows(kw["img_ids"], sl), lay.txt_rows(kw["txt_ids"], sl), S, lay.kv_len(sl), lay.kv_gap(sl), stream=s)
-                xs = lay.img_rows(x, sl).to(dev, torch.bfloat16, copy=True).contiguous()   # updated in place: never the caller's
-                tj = torch.empty(S, bs, N, C, dtype=torch.bfloat16, device=dev) if return_trajectory else None
+                xs = lay.img_rows(x, sl).to(dev, sdt, copy=True).contiguous()   # updated in place: never the caller's
+                tj = torch.empty(S, bs, N, C, dtype=sdt, device=dev) if return_trajectory else None
                 h.sample_euler(xs, bf(lay.img_rows(cond, sl)), t32, x.dtype == torch.bfloat16, s, trajectory=tj)
                 if return_trajectory:
                     traj.append(torch.stack([lay.img_rows_back(tj[i], sl) for i in range(S)]))
@@ -181,6 +192,5 @@ def _sample_fused(flux, x, kw, t, return_trajectory):
             out[sl].copy_(lay.img_rows_back(ws.XS.reshape(bs, N, C), sl))
     torch.cuda.current_stream().wait_stream(st)
     if return_trajectory:
-        full = torch.cat((x.to(dev, torch.bfloat16)[None], torch.cat(traj, dim=1)), dim=0)
-        return full.to(x.dtype)
-    return out[None].to(x.dtype)
+        return torch.cat((x.to(dev)[None], torch.cat(traj, dim=1).to(sdt)), dim=0)
+    return out[None]

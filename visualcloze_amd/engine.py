@@ -336,8 +336,16 @@ class FluxEngine:
         parts = hip.QKN_K | (0 if fused_q else hip.QKN_Q) | (0 if self._vt_in_gemm() else hip.QKN_VT)
         hip.qknorm_rope_vt(ws.QKV, q1, k1, ws.ROPE, ws.VT, ws.L, self.H, stream=s, q_scale2=q2, k_scale2=k2, split=split, B=ws.B,
                            parts=parts)
+        ev = getattr(self, "attn_events", None)     # bench.py: HIP events around the attention launch(es) IN SITU
+        if ev is not None:
+            e0 = hip.Event()
+            e0.record(s)
         hip.attention(ws.QKV, ws.VT, c.ATT, ws.L, self.H, kv_len=c.kvl, variant=variant, stream=s, B=ws.B,
                       scratch=self.attn_scratch, q_norm=(q1, q2, split, ws.ROPE) if fused_q else None, kv_gap=c.kvgap)
+        if ev is not None:
+            e1 = hip.Event()
+            e1.record(s)
+            ev.append((e0, e1))
 
     def _vt_in_gemm(self) -> bool:
         return self.fuse_vt and self.W.ref is None

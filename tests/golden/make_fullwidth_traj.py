@@ -1,0 +1,107 @@
+"""Full-WIDTH trajectory fixtures (test infrastructure): the CPU oracle's fixed-grid Euler trajectories at BASELINE sizes,
+D = 3072 / H = 24 / T = 512 with 1 DoubleStreamBlock + 1 SingleStreamBlock and LoRA r256, PROCEDURAL weights and inputs
+(tests/procedural.py: closed form, no RNG, bit-identical on every machine):
+
+    cfg2    384-grid 2x3   N = 3456  L = 3968   30 solver points = 29 evaluations, shifted grid      (transport.py:361-410)
+    sdedit  1024^2 target  N = 4096  L = 4608   10 points from strength 0.4, no shift = 9 evaluations (visualcloze.py:184-234)
+
+For each: the bf16 / merged-LoRA oracle (same rounding points as the HIP path; bf16 state as visualcloze.py:399) and the
+fp32 / un-merged oracle (exact reference semantics) -> tests/golden/fullwidth_traj.npz: final latents, a few intermediate
+states, the oracle's own bf16-vs-fp32 deviation per saved state.  The oracle is pinned to the reference by
+tests/test_oracle_golden.py; this script only RUNS it (about 25 min on 8 cores).
+
+    python tests/golden/make_fullwidth_traj.py [--only cfg2|sdedit] [--evals K]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+
+import oracle.flux_oracle as O  # noqa: E402
+from tests.procedural import procedural_param, ptensor  # noqa: E402
+
+T = 512
+CASES = {
+    "cfg2": dict(rows=2, row_latent=(48, 144), points=30, do_shift=True, strength=None, keep=(1, 10, 20, 29)),
+    "sdedit": dict(rows=1, row_latent=(128, 128), points=10, do_shift=False, strength=0.4, keep=(1, 5, 9)),
+}
+
+
+def key_shapes():
+    """state-dict keys / shapes of FluxLoraWrapper(depth 1 + 1, r256) at FLUX width, from the module tree itself"""
+    from visualcloze_amd.model import FLUX_DEV_FILL, FluxLoraWrapper, FluxParams
+    with torch.device("meta"):
+        m = FluxLoraWrapper(lora_rank=256, lora_scale=1.0,
+                            params=FluxParams(**{**FLUX_DEV_FILL, "depth": 1, "depth_single_blocks": 1}))
+    return [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+
+
+def inputs(case):
+    c = CASES[case]
+    h, w = c["row_latent"]
+    ids = O.grid_img_ids([(h, w)] * c["rows"])
+    N = ids.shape[0]
+    seed = 1000 + sorted(CASES).index(case) * 10
+    x = ptensor((1, N, 64), seed + 1, q=6)
+    cond = torch.cat([ptensor((1, N, 64), seed + 2, q=6), (ptensor((1, N, 256), seed + 3, q=0, kmax=1).abs() > 0.5).float()], -1)
+    return dict(x=x, cond=cond, img_ids=ids[None], txt=ptensor((1, T, 4096), seed + 4, q=6), txt_ids=torch.zeros(1, T, 3),
+                y=ptensor((1, 768), seed + 5, q=6), txt_mask=torch.ones(1, T, dtype=torch.int32),
+                img_mask=torch.ones(1, N, dtype=torch.int32), guidance=torch.full((1,), 30.0))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    ap.add_argument("--evals", type=int, default=None, help="stop after K evaluations (timing probe; nothing is written)")
+    a = ap.parse_args()
+    t0 = time.time()
+    # the deployed model holds bf16 parameters (models/util.py:402 `.to(torch.bfloat16)`): every procedural value is
+    # bf16-exact except the RMSNorm scales (1 + k/512), which are rounded here as loading them into the model rounds them
+    sd = {k: procedural_param(k, s, device="cpu").to(torch.bfloat16).float() for k, s in key_shapes()}
+    print(f"procedural weights: {sum(v.numel() for v in sd.values()) / 1e6:.0f} M parameters in {time.time() - t0:.0f} s", flush=True)
+    G = O.FluxGeometry(depth=1, depth_single_blocks=1)
+    out = {}
+    path = os.path.join(HERE, "fullwidth_traj.npz")
+    if a.only and os.path.exists(path):
+        out.update(np.load(path))
+    for case in ([a.only] if a.only else list(CASES)):
+        c, inp = CASES[case], inputs(case)
+        N = inp["x"].shape[1]
+        t = O.time_grid(c["points"], N, c["do_shift"], 1 if c["do_shift"] else 1.0, c["strength"])
+        if a.evals:
+            t = t[:a.evals + 1]
+        res = {}
+        for tag, P in (("bf16", O.Prec("bf16", "merged")), ("fp32", O.Prec("fp32", "ref"))):
+            def model_fn(xin, tm, P=P):
+                return O.flux_forward(sd, G, xin, inp["img_ids"], inp["txt"], inp["txt_ids"], tm, inp["y"], inp["txt_mask"],
+                                      inp["img_mask"], inp["guidance"], P=P)      # guidance bf16 as visualcloze.py:413
+            t1 = time.time()
+            with torch.no_grad():
+                states, evals = O.sample_euler(model_fn, P.r(inp["x"]), P.r(inp["cond"]), t, P)
+            res[tag] = states
+            print(f"{case} {tag}: {len(evals)} evaluations in {time.time() - t1:.0f} s ({torch.get_num_threads()} threads)", flush=True)
+        if a.evals:
+            continue
+        keep = [k for k in c["keep"] if k < len(res["bf16"])]
+        out[f"{case}_keep"] = np.asarray(keep, np.int32)
+        out[f"{case}_t"] = t.numpy()
+        out[f"{case}_x_sum"] = np.float64(inp["x"].double().sum().item())
+        for k in keep:
+            b, f = res["bf16"][k], res["fp32"][k]
+            assert torch.equal(b.to(torch.bfloat16).float(), b)                    # bf16-mode states are bf16 values
+            out[f"{case}_bf16_{k}"] = b.to(torch.bfloat16).view(torch.int16).numpy()
+            out[f"{case}_fp32_{k}"] = f.numpy()
+            print(f"  state {k}: oracle bf16-vs-fp32 rel-L2 {((b - f).norm() / f.norm()).item():.3e}", flush=True)
+        np.savez_compressed(path, **out)
+        print("wrote", path, os.path.getsize(path), "bytes", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -28,27 +28,51 @@ def ptensor(shape, seed: int, q: int = 7, kmax: int = 127, offset: float = 0.0) 
     return torch.tensor(k.astype(np.float32) * np.float32(2.0 ** -q) + np.float32(offset)).reshape(*shape)
 
 
+def ptensor_torch(shape, seed: int, q: int = 7, kmax: int = 127, offset: float = 0.0, device="cpu",
+                  dtype=torch.float32) -> torch.Tensor:
+    """`ptensor` evaluated with torch integer ops on `device` (the 0.6 B parameters of a full-width model take minutes in
+    numpy on one core, a second on the GPU): the same hash in int64 with 32-bit masks - bit-identical values, pinned by
+    tests/test_host_cpu.py::test_procedural_torch_equals_numpy."""
+    n = int(np.prod(shape))
+    M = 0xFFFFFFFF
+    out = torch.empty(n, dtype=dtype, device=device)
+    step = 1 << 24
+    for s0 in range(0, n, step):
+        h = torch.arange(s0, min(n, s0 + step), dtype=torch.int64, device=device)
+        h = (h * 2654435761 + (seed * 40503 + 12345)) & M
+        h = h ^ (h >> 15)
+        h = (h * 2246822519) & M
+        h = h ^ (h >> 13)
+        h = (h * 3266489917) & M
+        h = h ^ (h >> 16)
+        k = (h % (2 * kmax + 1) - kmax).to(torch.float32)
+        out[s0:s0 + h.numel()] = (k * (2.0 ** -q) + offset).to(dtype)
+    return out.reshape(*shape)
+
+
 def key_seed(key: str) -> int:
     return zlib.crc32(key.encode()) & 0x7FFFFFFF
 
 
-def procedural_param(key: str, shape) -> torch.Tensor:
-    """Weight for state-dict entry `key` (reference naming)."""
+def procedural_param(key: str, shape, device=None, dtype=torch.float32) -> torch.Tensor:
+    """Weight for state-dict entry `key` (reference naming).  `device`: evaluate with torch ops there
+    (`ptensor_torch`, same values) instead of numpy on the host."""
     seed = key_seed(key)
     shape = tuple(shape)
+    gen = ptensor if device is None else (lambda *a, **k: ptensor_torch(*a, device=device, dtype=dtype, **k))
     if key.endswith("norm.scale"):                       # RMSNorm scales ~ 1
-        return ptensor(shape, seed, q=9, kmax=64, offset=1.0)
+        return gen(shape, seed, q=9, kmax=64, offset=1.0)
     if key.endswith(".bias"):
-        return ptensor(shape, seed, q=9, kmax=32)
+        return gen(shape, seed, q=9, kmax=32)
     fan_in = shape[-1]
     q = int(round(math.log2(73.0 * math.sqrt(fan_in))))  # unit-variance outputs for unit-variance inputs
     if ".lora_A." in key:
-        return ptensor(shape, seed, q=q, kmax=127)
+        return gen(shape, seed, q=q, kmax=127)
     if ".lora_B." in key:
-        return ptensor(shape, seed, q=q + 2, kmax=127)   # LoRA path live at ~25 % of the base magnitude
+        return gen(shape, seed, q=q + 2, kmax=127)   # LoRA path live at ~25 % of the base magnitude
     if "_mod.lin" in key or "modulation.lin" in key or "adaLN_modulation" in key:
-        return ptensor(shape, seed, q=q + 2, kmax=127)   # keep shift/scale/gate ~ 0.25
-    return ptensor(shape, seed, q=q, kmax=127)
+        return gen(shape, seed, q=q + 2, kmax=127)   # keep shift/scale/gate ~ 0.25
+    return gen(shape, seed, q=q, kmax=127)
 
 
 def procedural_state_dict(key_shapes) -> dict:

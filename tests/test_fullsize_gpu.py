@@ -308,6 +308,69 @@ def test_full_depth_19_38_vs_oracle():
     assert e32 < 2.0 * floor
 
 
+TRAJ_FIXTURE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullwidth_traj.npz")
+
+
+def _traj_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_fullwidth_traj", os.path.join(os.path.dirname(TRAJ_FIXTURE), "make_fullwidth_traj.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.fixture(scope="module")
+def procedural_small_model():
+    """full width, 1 + 1 blocks, LoRA r256, PROCEDURAL weights (tests/procedural.py, evaluated on the GPU: bit-identical to
+    the numpy values the committed oracle trajectories were made from)"""
+    from tests.procedural import procedural_param
+    from visualcloze_amd.model import FLUX_DEV_FILL, FluxLoraWrapper, FluxParams
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        with torch.device(DEV):
+            m = FluxLoraWrapper(lora_rank=256, lora_scale=1.0, params=FluxParams(**{**FLUX_DEV_FILL, "depth": 1, "depth_single_blocks": 1}))
+    finally:
+        torch.set_default_dtype(old)
+    with torch.no_grad():
+        for k, v in m.state_dict().items():
+            v.copy_(procedural_param(k, v.shape, device=DEV, dtype=torch.float32))
+    return m.eval()
+
+
+@pytest.mark.parametrize("case", ["cfg2", "sdedit"])
+def test_full_width_trajectory_vs_oracle(procedural_small_model, case):
+    """The WHOLE loop at full width against the oracle's own trajectories (transport/integrators.py:106-120,
+    transport/transport.py:384): cfg 2's 30-point shifted grid = 29 evaluations at L = 3968, and the SDEdit stage's 10
+    points from strength 0.4 = 9 evaluations at L = 4608, D = 3072, 1 + 1 blocks.  The fused sampler's intermediate and
+    FINAL latents are held to the bf16-merged oracle (same rounding points) and the fp32-ref oracle (exact reference
+    semantics), with bounds stated against `floor` = the oracle's own bf16-vs-fp32 deviation on the same state:
+        HIP vs bf16 oracle <= 1.5 * floor,   HIP vs fp32 oracle <= 2 * floor      (final state and every saved one)."""
+    import numpy as np
+    from tests.helpers import parity_log
+    from visualcloze_amd.transport import Sampler, create_transport
+    FT = _traj_module()
+    fx = np.load(TRAJ_FIXTURE)
+    c, inp = FT.CASES[case], FT.inputs(case)
+    assert float(fx[f"{case}_x_sum"]) == inp["x"].double().sum().item()
+    opts = dict(sampling_method="euler", num_steps=c["points"], do_shift=c["do_shift"], return_trajectory=True,
+                time_shifting_factor=1 if c["do_shift"] else 1.0, strength=c["strength"])
+    fn = Sampler(create_transport()).sample_ode(**opts)
+    m = procedural_small_model
+    tr = fn(inp["x"].to(DEV, torch.bfloat16), m.forward, _kw(inp))
+    torch.cuda.synchronize()
+    assert tr.shape[0] == c["points"] and torch.isfinite(tr.float()).all()
+    last = int(fx[f"{case}_keep"][-1])
+    assert last == c["points"] - 1
+    for k in [int(v) for v in fx[f"{case}_keep"]]:
+        b16 = torch.tensor(fx[f"{case}_bf16_{k}"]).view(torch.bfloat16).float()
+        f32 = torch.tensor(fx[f"{case}_fp32_{k}"])
+        floor, e16, e32 = rel_l2(b16, f32), rel_l2(tr[k], b16), rel_l2(tr[k], f32)
+        parity_log(f"[trajectory 1+1 blocks, {case}] state {k}/{last}: HIP vs bf16 oracle {e16:.3e}, vs fp32 oracle {e32:.3e}, "
+                   f"oracle bf16-vs-fp32 floor {floor:.3e}")
+        assert e16 < 1.5 * floor and e32 < 2.0 * floor, (k, e16, e32, floor)
+
+
 def test_full_model_fused_equals_eager_and_is_deterministic():
     from visualcloze_amd.transport import Sampler, create_transport
     m = _build(19, 38)

@@ -221,3 +221,16 @@ def test_gemm_launch_plans_for_the_flux_shapes():
     # argument errors come back as codes, with a message
     a = hip.GemmArgs(); a.nprob = 1; a.p[0].M, a.p[0].N, a.p[0].K = 8, 8, 60
     assert L.vc_gemm_plan(C.byref(a), 0, (C.c_int32 * 6)()) == -1 and b"multiple of 64" in L.vc_last_error()
+
+
+def test_procedural_torch_equals_numpy():
+    """tests/procedural.py: the torch evaluation of the closed-form weights (what the GPU tests use at full width) is
+    bit-identical to the numpy one (what the golden generators use), chunk boundary included."""
+    import torch
+    from tests.procedural import procedural_param, ptensor, ptensor_torch
+    for key, shape in (("double_blocks.0.img_attn.qkv.weight", (96, 64)), ("x.norm.scale", (128,)), ("a.bias", (300,)),
+                       ("single_blocks.0.linear1.lora_B.weight", (70, 33)), ("m.img_mod.lin.weight", (50, 20))):
+        assert torch.equal(procedural_param(key, shape), procedural_param(key, shape, device="cpu"))
+    n = (1 << 24) + 5
+    assert torch.equal(ptensor((n,), 77), ptensor_torch((n,), 77))
+    assert torch.equal(ptensor((33, 7), 5, q=6).to(torch.bfloat16), ptensor_torch((33, 7), 5, q=6, dtype=torch.bfloat16))

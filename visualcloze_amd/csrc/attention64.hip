@@ -55,7 +55,7 @@ struct Attn64Args {
   const int32_t* kv_gap;      // optional [B][2]: keys / query rows lo <= i < hi masked too
   int64_t ld, bstride, ldo, out_bstride;
   int32_t B, L, Lpad, H, qblocks, items;
-  int32_t full_rounds, tail_items, tail_units;   // tail split, as attention.hip (full_rounds < 0 = off)
+  int32_t full_rounds, tail_items, tail_units;   // full_rounds >= 0: tail split on (the schedule itself is derived per XCD, see Sched64)
   float* part;
   // optional in-kernel QKNorm + RoPE of the query rows (q_scale != nullptr): as vc_qknorm_rope_vt
   const bf16_t* q_scale; const bf16_t* q_scale2; const float* rope; int64_t rope_bstride; int32_t split;
@@ -80,6 +80,28 @@ constexpr int PART64_O_BYTES = 4 * 2 * 16 * 64 * 8;
 constexpr int PART64_BYTES = PART64_O_BYTES + 4 * 2 * 64 * 8;
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 VC_DEV int chunk_begin64(int c, int units, int chunks) { return (int)(((long)c * units) / chunks); }
+
+// Work schedule of the persistent grid, PER XCD (grid % 8 == 0; block b runs on XCD b % 8 - observed placement, used for
+// speed only).  XCD x owns the contiguous logical items [start, start + n) that xcd_remap gives it: all query blocks of a
+// head are neighbours there, so the K / V^T tiles of a head stream through ONE L2.  Its W = grid / 8 workgroups take
+// `rounds` whole items each (item start + r * W + slot); the remaining `tail` items are cut along the keys into W equal
+// chunks of (item, KV tile) units - inside the SAME XCD, so that the tail round re-reads K / V^T from the L2 that already
+// holds them (round 2 cut the tail across the whole grid: every XCD streamed every tail head, 204 MB fetched per launch
+// for 73 MB of operands).
+struct Sched64 {
+  int W, start, n, rounds, tail, units;
+};
+VC_DEV Sched64 sched64(int x, int G, int items, int nkt) {
+  Sched64 s;
+  s.W = G >> 3;
+  const int q = items >> 3, r = items & 7;
+  s.n = q + (x < r ? 1 : 0);
+  s.start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  s.rounds = s.n / s.W;
+  s.tail = s.n - s.rounds * s.W;
+  s.units = s.tail * nkt;
+  return s;
+}
 
 VC_DEV int swap23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
 
@@ -207,28 +229,35 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
   const int G = gridDim.x;
   const int nkt_all = (a.L + KVB - 1) / KVB;
   const bool split = a.full_rounds >= 0;
-  const int chunk = split ? xcd_remap(blockIdx.x, G) : 0;
-  int tu = split ? chunk_begin64(chunk, a.tail_units, G) : 0;
-  const int tu_end = split ? chunk_begin64(chunk + 1, a.tail_units, G) : 0;
-  const int it_first = tu / nkt_all;
+  int tu = 0, tu_end = 0, it_first = 0, rounds_left = 0x7fffffff, id_full = blockIdx.x, id_step = G, id_tail = 0;
+  if (split) {      // few scalars survive into the loop: the next whole item and its stride, the tail's first item, the unit range
+    const int slot = blockIdx.x >> 3;
+    const Sched64 sc = sched64(blockIdx.x & 7, G, a.items, nkt_all);
+    tu = chunk_begin64(slot, sc.units, sc.W);
+    tu_end = chunk_begin64(slot + 1, sc.units, sc.W);
+    it_first = tu / nkt_all;
+    rounds_left = sc.rounds;
+    id_full = sc.start + slot;
+    id_step = sc.W;
+    id_tail = sc.start + sc.rounds * sc.W;
+  }
 
-  for (int seg = 0;; ++seg) {
-    int item, kt0 = 0, kt1 = -1, piece = -1;
-    if (!split) {
-      item = blockIdx.x + seg * G;
-      if (item >= a.items) break;
-    } else if (seg < a.full_rounds) {
-      item = blockIdx.x + seg * G;
+  for (;;) {
+    int id, kt0 = 0, kt1 = -1, piece = -1;
+    if (rounds_left > 0) {
+      if (!split && id_full >= a.items) break;
+      id = split ? id_full : xcd_remap(id_full, a.items);
+      id_full += id_step;
+      --rounds_left;
     } else {
       if (tu >= tu_end) break;
       const int it = tu / nkt_all;
       kt0 = tu - it * nkt_all;
       kt1 = min(nkt_all, kt0 + (tu_end - tu));
       tu += kt1 - kt0;
-      item = a.full_rounds * G + it;
-      if (kt1 - kt0 != nkt_all) piece = chunk * 2 + (it - it_first);
+      id = id_tail + it;
+      if (kt1 - kt0 != nkt_all) piece = blockIdx.x * 2 + (it - it_first);
     }
-    const int id = xcd_remap(item, a.items);
     const int qb_i = id % a.qblocks;
     const int bh = id / a.qblocks;
     const int h = bh % a.H, b = bh / a.H;
@@ -575,27 +604,29 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
 }
 
 // Combines the pieces of the tail items: out = sum_p w_p (O_p / l_p) / sum_p w_p, w_p = l_p 2^(m_p - max m).  One
-// workgroup per (tail item, query block of the wave); thread layout = the writer's.
+// workgroup per (XCD, tail item of that XCD, query block of the wave) on the XCD that wrote the pieces (block b -> XCD
+// b % 8); thread layout = the writer's.
 __global__ __launch_bounds__(256) void attn64_merge_kernel(const Attn64Args a, int G) {
-  const int it = blockIdx.x >> 1, qb = blockIdx.x & 1;
+  const int xcd = blockIdx.x & 7, it = blockIdx.x >> 4, qb = (blockIdx.x >> 3) & 1;
   const int nkt = (a.L + KVB - 1) / KVB;
+  const Sched64 sc = sched64(xcd, G, a.items, nkt);
+  if (it >= sc.tail) return;
   const int u0 = it * nkt, u1 = u0 + nkt;
-  int c = (int)(((long)u0 * G) / a.tail_units);
-  while (c > 0 && chunk_begin64(c, a.tail_units, G) > u0) --c;
-  while (c + 1 < G && chunk_begin64(c + 1, a.tail_units, G) <= u0) ++c;
-  if (chunk_begin64(c + 1, a.tail_units, G) >= u1) return;        // the whole item ran inside one chunk: already written
+  int c = (int)(((long)u0 * sc.W) / sc.units);
+  while (c > 0 && chunk_begin64(c, sc.units, sc.W) > u0) --c;
+  while (c + 1 < sc.W && chunk_begin64(c + 1, sc.units, sc.W) <= u0) ++c;
+  if (chunk_begin64(c + 1, sc.units, sc.W) >= u1) return;        // the whole item ran inside one chunk: already written
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 31, hh = lane >> 5;
-  const int item = a.full_rounds * G + it;
-  const int id = xcd_remap(item, a.items);
+  const int id = sc.start + sc.rounds * sc.W + it;
   const int qb_i = id % a.qblocks, bh = id / a.qblocks;
   const int h = bh % a.H, b = bh / a.H;
   const char* base = (const char*)a.part;
   const long ml_off = PART64_O_BYTES + ((wave * 2 + qb) * 64 + lane) * 8;
   float m = -INFINITY;
-  for (int cc = c; cc < G && chunk_begin64(cc, a.tail_units, G) < u1; ++cc) {
-    if (chunk_begin64(cc + 1, a.tail_units, G) == chunk_begin64(cc, a.tail_units, G)) continue;   // empty chunk (fewer units than blocks)
-    const int piece = cc * 2 + (it - chunk_begin64(cc, a.tail_units, G) / nkt);
+  for (int cc = c; cc < sc.W && chunk_begin64(cc, sc.units, sc.W) < u1; ++cc) {
+    if (chunk_begin64(cc + 1, sc.units, sc.W) == chunk_begin64(cc, sc.units, sc.W)) continue;   // empty chunk (fewer units than blocks)
+    const int piece = (cc * 8 + xcd) * 2 + (it - chunk_begin64(cc, sc.units, sc.W) / nkt);
     m = fmaxf(m, *(const float*)(base + (long)piece * PART64_BYTES + ml_off));
   }
   float acc[16][4];
@@ -604,9 +635,9 @@ __global__ __launch_bounds__(256) void attn64_merge_kernel(const Attn64Args a, i
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[i][e] = 0.f;
   float wsum = 0.f;
-  for (int cc = c; cc < G && chunk_begin64(cc, a.tail_units, G) < u1; ++cc) {
-    if (chunk_begin64(cc + 1, a.tail_units, G) == chunk_begin64(cc, a.tail_units, G)) continue;
-    const int piece = cc * 2 + (it - chunk_begin64(cc, a.tail_units, G) / nkt);
+  for (int cc = c; cc < sc.W && chunk_begin64(cc, sc.units, sc.W) < u1; ++cc) {
+    if (chunk_begin64(cc + 1, sc.units, sc.W) == chunk_begin64(cc, sc.units, sc.W)) continue;
+    const int piece = (cc * 8 + xcd) * 2 + (it - chunk_begin64(cc, sc.units, sc.W) / nkt);
     const char* pp = base + (long)piece * PART64_BYTES;
     f16x4 v[16];
 #pragma unroll
@@ -661,12 +692,20 @@ int vc_attention64_launch(const VcAttention& A, bool tail_split, int n_cu, uint6
   }
   const int G = n_cu;
   const int nkt = (L + KVB - 1) / KVB;
-  const int rounds = a.items / G, tail = a.items - rounds * G;
-  const int split_tiles = (int)(((long)tail * nkt + G - 1) / G);
-  if (tail_split && !kv_len && tail > 0 && scratch && scratch_bytes >= vc_attention64_scratch_bytes_impl(n_cu) && split_tiles + 4 < nkt) {
-    a.full_rounds = rounds; a.tail_items = tail; a.tail_units = tail * nkt;
+  // the tail split is scheduled per XCD (Sched64): cut where some XCD has tail items and cutting shortens its critical
+  // path by more than the merge costs (~4 tiles): plain = one more round of nkt tiles for the workgroups that draw a tail
+  // item, split = ceil(tail * nkt / W) tiles for every workgroup of that XCD
+  int any_tail = 0, worst_split = 0;
+  if (G % 8 == 0)
+    for (int x = 0; x < 8; ++x) {
+      const int W = G / 8, q = a.items / 8, r = a.items % 8, n = q + (x < r ? 1 : 0), tail = n % W;
+      any_tail |= tail;
+      worst_split = std::max(worst_split, (int)(((long)tail * nkt + W - 1) / W));
+    }
+  if (tail_split && !kv_len && any_tail && scratch && scratch_bytes >= vc_attention64_scratch_bytes_impl(n_cu) && worst_split + 4 < nkt) {
+    a.full_rounds = a.items / G; a.tail_items = a.items - a.full_rounds * G; a.tail_units = a.tail_items * nkt;
     hipLaunchKernelGGL(attn64_kernel, dim3(G), dim3(256), LDS64, s, a);
-    hipLaunchKernelGGL(attn64_merge_kernel, dim3(tail * 2), dim3(256), 0, s, a, G);
+    hipLaunchKernelGGL(attn64_merge_kernel, dim3(2 * G), dim3(256), 0, s, a, G);
   } else {
     hipLaunchKernelGGL(attn64_kernel, dim3(std::min(a.items, G)), dim3(256), LDS64, s, a);
   }

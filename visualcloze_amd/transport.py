@@ -82,8 +82,13 @@ class Sampler:
             t = solver_time_grid(num_steps, x.shape[1], t0, t1, do_shift, time_shifting_factor)
             from .model import Flux
             owner = getattr(model, "__self__", None)
-            if isinstance(owner, Flux) and getattr(model, "__name__", "") == "forward" and _fusable(owner, x):
-                return _sample_fused(owner, x, dict(model_kwargs), t, return_trajectory)
+            if isinstance(owner, Flux) and getattr(model, "__name__", "") == "forward":
+                if _fusable(owner, x):
+                    return _sample_fused(owner, x, dict(model_kwargs), t, return_trajectory)
+                # stepped eagerly; the velocity of this model is a bf16 tensor as the reference's is under autocast
+                # (visualcloze.py:363) whatever dtype Flux.forward hands back to its caller: dt * f stays a bf16 product
+                fwd = model
+                model = lambda xin, **k: fwd(xin, **k).to(torch.bfloat16)  # noqa: E731
             return _sample_foreign(model, x, dict(model_kwargs), t, return_trajectory)
 
         return _sample

@@ -88,6 +88,11 @@ typedef struct VcGemmArgs {
  * 416 tiles = 2 rounds at 81 % fill, or 256 tiles + 240 narrower ones).  Results do not depend on the cut.
  * VC_GEMM_NO_SPLIT (64) as tile_cfg keeps it one launch; (k << 8) forces the cut at row k * 256 (tests). */
 #define VC_GEMM_NO_SPLIT 64
+/* VC_GEMM_PERSIST (128) added to tile_cfg: a launch with more tiles than CUs on a loader-wave tile runs as ONE persistent
+ * workgroup per CU that walks the tiles of its XCD's strip and fetches the next tile's first operands during the current
+ * tile's epilogue (same results bit for bit; not for VC_EPI_GATE_RES).  Opt-in: measured neutral on MI355X (+0.05 % steps/s;
+ * the time it removes is idle time the power-limited clock already gives back), kept for boards where it is not. */
+#define VC_GEMM_PERSIST 128
 int vc_gemm(const VcGemmArgs* args, int tile_cfg, void* stream);
 /* The plan vc_gemm would execute for these arguments, without launching anything (works without a GPU): out[0] = first row
  * of the second launch (0 = a single launch), out[1], out[2] = tile number (1..5 as above) and main-loop form (0 plain,

@@ -1,0 +1,85 @@
+"""Full-DEPTH single evaluations at the two ENDS of cfg 2's time grid (test infrastructure): the CPU oracle's Flux.forward for
+the whole 19 + 38-block model (13.1 B parameters, D = 3072, L = 512 + 3456, LoRA r256) with PROCEDURAL weights and inputs
+(tests/procedural.py) at
+
+    t = 1.0              the first evaluation of the 30-point shifted grid (timestep embedding of 1000)
+    t = 1 - bf16(t_28)   the last one (~0.09: where the time embedding differs most from the middle of the grid)
+
+in both oracle modes (bf16 / merged LoRA = the HIP path's rounding points; fp32 / un-merged = exact reference semantics)
+-> tests/golden/fulldepth_times_oracle.npz.  tests/golden/fulldepth_cfg2_oracle.npz holds the same comparison at t = 0.62.
+About 45 min on 8 cores; weights are kept as bf16 on the host (26 GB) and widened one tensor at a time.
+
+    python tests/golden/make_fulldepth_times.py
+"""
+import importlib.util
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+
+import oracle.flux_oracle as O  # noqa: E402
+from tests.procedural import procedural_param  # noqa: E402
+
+
+class LazyF32(dict):
+    """bf16 storage, f32 on access (the values ARE bf16: exact)"""
+
+    def __getitem__(self, k):
+        return dict.__getitem__(self, k).float()
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+
+def flux_times():
+    t = O.time_grid(30, 3456, True, 1)
+    tm = 1.0 - t[:-1].to(torch.bfloat16).float()
+    return [float(tm[0]), float(tm[-1])]
+
+
+def main():
+    spec = importlib.util.spec_from_file_location("ft", os.path.join(HERE, "make_fullwidth_traj.py"))
+    FT = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(FT)
+    from visualcloze_amd.model import FLUX_DEV_FILL, FluxLoraWrapper, FluxParams
+    with torch.device("meta"):
+        m = FluxLoraWrapper(lora_rank=256, lora_scale=1.0, params=FluxParams(**FLUX_DEV_FILL))
+    t0 = time.time()
+    sd = LazyF32({k: procedural_param(k, tuple(v.shape), device="cpu").to(torch.bfloat16) for k, v in m.state_dict().items()})
+    print(f"procedural weights: {sum(dict.__getitem__(sd, k).numel() for k in sd) / 1e9:.2f} B parameters in {time.time() - t0:.0f} s", flush=True)
+    inp = FT.inputs("cfg2")
+    G = O.FluxGeometry()
+    out = {"x_sum": np.float64(inp["x"].double().sum().item())}
+    times = flux_times()
+    out["times"] = np.asarray(times, np.float64)
+    args = lambda t: (sd, G, torch.cat((inp["x"], inp["cond"]), -1), inp["img_ids"], inp["txt"], inp["txt_ids"],   # noqa: E731
+                      torch.tensor([t]), inp["y"], inp["txt_mask"], inp["img_mask"], inp["guidance"])
+    # both modes see the SAME guidance value (an f32 guidance tensor: 1000 * g = 30000 exactly; a bf16 one would round to
+    # 29952 in the bf16 mode only, and the bf16-vs-fp32 floor is meant to hold arithmetic noise, not an input difference)
+    orig = O.compute_vec
+    O.compute_vec = lambda *a, **k: orig(*a, **{**k, "guidance_is_bf16": False})
+    for i, t in enumerate(times):
+        for tag, P in (("bf16", O.Prec("bf16", "merged")), ("fp32", O.Prec("fp32", "ref"))):
+            t1 = time.time()
+            with torch.no_grad():
+                y = O.flux_forward(*args(t), P=P)
+            print(f"t = {t:.6f} {tag}: {time.time() - t1:.0f} s ({torch.get_num_threads()} threads)", flush=True)
+            if tag == "bf16":
+                assert torch.equal(y.to(torch.bfloat16).float(), y)
+                out[f"bf16_{i}"] = y.to(torch.bfloat16).view(torch.int16).numpy()
+                yb = y
+            else:
+                out[f"fp32_{i}"] = y.numpy().astype(np.float16)
+                print(f"  oracle bf16-vs-fp32 rel-L2 {((yb - y).norm() / y.norm()).item():.3e}", flush=True)
+        np.savez_compressed(os.path.join(HERE, "fulldepth_times_oracle.npz"), **out)
+    print("wrote fulldepth_times_oracle.npz", flush=True)
+
+
+if __name__ == "__main__":
+    main()

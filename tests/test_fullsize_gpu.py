@@ -319,23 +319,27 @@ def _traj_module():
     return mod
 
 
-@pytest.fixture(scope="module")
-def procedural_small_model():
-    """full width, 1 + 1 blocks, LoRA r256, PROCEDURAL weights (tests/procedural.py, evaluated on the GPU: bit-identical to
-    the numpy values the committed oracle trajectories were made from)"""
+def _build_procedural(depth, single):
+    """full width, LoRA r256, PROCEDURAL weights (tests/procedural.py, evaluated on the GPU: bit-identical to the numpy /
+    torch-CPU values the committed oracle fixtures were made from)"""
     from tests.procedural import procedural_param
     from visualcloze_amd.model import FLUX_DEV_FILL, FluxLoraWrapper, FluxParams
     old = torch.get_default_dtype()
     torch.set_default_dtype(torch.bfloat16)
     try:
         with torch.device(DEV):
-            m = FluxLoraWrapper(lora_rank=256, lora_scale=1.0, params=FluxParams(**{**FLUX_DEV_FILL, "depth": 1, "depth_single_blocks": 1}))
+            m = FluxLoraWrapper(lora_rank=256, lora_scale=1.0, params=FluxParams(**{**FLUX_DEV_FILL, "depth": depth, "depth_single_blocks": single}))
     finally:
         torch.set_default_dtype(old)
     with torch.no_grad():
         for k, v in m.state_dict().items():
             v.copy_(procedural_param(k, v.shape, device=DEV, dtype=torch.float32))
     return m.eval()
+
+
+@pytest.fixture(scope="module")
+def procedural_small_model():
+    return _build_procedural(1, 1)
 
 
 @pytest.mark.parametrize("case", ["cfg2", "sdedit"])
@@ -357,18 +361,47 @@ def test_full_width_trajectory_vs_oracle(procedural_small_model, case):
                 time_shifting_factor=1 if c["do_shift"] else 1.0, strength=c["strength"])
     fn = Sampler(create_transport()).sample_ode(**opts)
     m = procedural_small_model
-    tr = fn(inp["x"].to(DEV, torch.bfloat16), m.forward, _kw(inp))
+    kw = dict(_kw(inp), guidance=inp["guidance"].to(DEV))     # f32 guidance: the value both oracle modes were run with
+    tr = fn(inp["x"].to(DEV, torch.bfloat16), m.forward, kw)
     torch.cuda.synchronize()
     assert tr.shape[0] == c["points"] and torch.isfinite(tr.float()).all()
     last = int(fx[f"{case}_keep"][-1])
     assert last == c["points"] - 1
+    stride = int(fx["token_stride"])                  # intermediate states are stored for every stride-th token, the last whole
     for k in [int(v) for v in fx[f"{case}_keep"]]:
         b16 = torch.tensor(fx[f"{case}_bf16_{k}"]).view(torch.bfloat16).float()
-        f32 = torch.tensor(fx[f"{case}_fp32_{k}"])
-        floor, e16, e32 = rel_l2(b16, f32), rel_l2(tr[k], b16), rel_l2(tr[k], f32)
+        f32 = torch.tensor(fx[f"{case}_fp32_{k}"].astype("float32"))
+        got = tr[k] if k == last else tr[k][:, ::stride]
+        floor, e16, e32 = rel_l2(b16, f32), rel_l2(got, b16), rel_l2(got, f32)
         parity_log(f"[trajectory 1+1 blocks, {case}] state {k}/{last}: HIP vs bf16 oracle {e16:.3e}, vs fp32 oracle {e32:.3e}, "
                    f"oracle bf16-vs-fp32 floor {floor:.3e}")
         assert e16 < 1.5 * floor and e32 < 2.0 * floor, (k, e16, e32, floor)
+
+
+TIMES_FIXTURE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fulldepth_times_oracle.npz")
+
+
+def test_full_depth_at_both_ends_of_the_time_grid_vs_oracle():
+    """The full 19 + 38-block model at the FIRST and the LAST Flux time of cfg 2's 30-point grid (t = 1.0 and
+    t = 1 - bf16(t_28) ~ 0.09: the timestep embeddings furthest from the t = 0.62 of test_full_depth_19_38_vs_oracle),
+    procedural weights, against the committed oracle outputs of tests/golden/make_fulldepth_times.py; bounds as there:
+    HIP vs bf16-merged oracle <= 1.5 * floor, vs fp32-ref oracle <= 2 * floor."""
+    import numpy as np
+    from tests.helpers import parity_log
+    FT = _traj_module()
+    fx = np.load(TIMES_FIXTURE)
+    inp = FT.inputs("cfg2")
+    assert float(fx["x_sum"]) == inp["x"].double().sum().item()
+    m = _build_procedural(19, 38)
+    for i, t in enumerate(fx["times"]):
+        got = _call(m, inp, torch.tensor([float(t)], dtype=torch.float32)).float().cpu()
+        b16 = torch.tensor(fx[f"bf16_{i}"]).view(torch.bfloat16).float()
+        f32 = torch.tensor(fx[f"fp32_{i}"].astype("float32"))
+        floor, e16, e32 = rel_l2(b16, f32), rel_l2(got, b16), rel_l2(got, f32)
+        parity_log(f"[full depth 19+38, cfg2, procedural weights] t = {float(t):.4f}: HIP vs bf16-merged oracle {e16:.3e}, vs fp32-ref oracle "
+                   f"{e32:.3e}, oracle bf16-vs-fp32 floor {floor:.3e}")
+        assert torch.isfinite(got).all()
+        assert e16 < 1.5 * floor and e32 < 2.0 * floor, (float(t), e16, e32, floor)
 
 
 def test_full_model_fused_equals_eager_and_is_deterministic():

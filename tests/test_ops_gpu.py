@@ -127,6 +127,61 @@ def test_gemm_split_launch_against_block_round_quantisation(hip, epi, cut):
         assert float(vt2[..., L:].float().abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize("cfg", [34, 36])
+@pytest.mark.parametrize("epi", [0, 1, 3])
+@pytest.mark.parametrize("M,N,K", [(4400, 3264, 128), (4400, 3264, 64), (4100, 3100 // 8 * 8, 192), (2100, 6400, 320)])
+def test_gemm_persistent_tile_loop_equals_one_block_per_tile(hip, cfg, epi, M, N, K):
+    """GEMM_PERSIST + more tiles than CUs on a loader-wave tile: ONE persistent workgroup per CU walks the tiles of its XCD's
+    strip and fetches the next tile's W(0), W(1) during the current tile's epilogue (gemm_bf16_kernel PERSIST).  Same bits as one
+    workgroup per tile (the default) - for K = 64 (one K-tile: nothing to pipeline), 128, 192, 320 (ring wrap-around),
+    tile counts that are not multiples of 8, half-empty edge tiles - and the torch reference within bf16 tolerance."""
+    a_full = rnd(M, K + 64, seed=1)
+    a = a_full[:, :K]
+    w, bias = rnd(N, K, scale=K ** -0.5, seed=2), rnd(N, seed=3)
+    bm, bn = 256, (128 if cfg == 34 else 192)
+    assert ((M + bm - 1) // bm) * ((N + bn - 1) // bn) > hip.device_cus()
+    outs = []
+    for flags in (0, hip.GEMM_PERSIST, hip.GEMM_PERSIST):
+        out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        hip.gemm(hip.make_problem(a, w, bias, out), epi=epi, tile_cfg=cfg | flags)
+        outs.append(out)
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs[0].float()).all()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+    check(outs[1], R.gemm_ref(a, w, bias, epi, None, None))
+
+
+@pytest.mark.parametrize("cfg", [0, 34, 36])
+def test_gemm_persistent_grouped_qkv_epilogue(hip, cfg):
+    """The persistent loop across a PROBLEM boundary (the next tile belongs to the other stream: other A, W, bias, row
+    geometry) with batch-strided C rows and the V^T epilogue, two samples: the DoubleStreamBlock qkv launch."""
+    B, T, N, D = 2, 520, 1800, 1280
+    L, H = T + N, D // 128
+    Lp = (L + 63) // 64 * 64
+    xi, xt = rnd(B * N, D, seed=1), rnd(B * T, D, seed=2)
+    wi, wt = rnd(3 * D, D, scale=D ** -0.5, seed=3), rnd(3 * D, D, scale=D ** -0.5, seed=4)
+    bi, bt = rnd(3 * D, seed=5), rnd(3 * D, seed=6)
+
+    def run(flags):
+        qkv = torch.full((B * L, 3 * D), float("nan"), dtype=torch.bfloat16, device=DEV)
+        vt = torch.full((B, H, 128, Lp), 7.0, dtype=torch.bfloat16, device=DEV)
+        kw = dict(c_bstride=L * 3 * D)
+        hip.gemm([hip.make_problem(xi, wi, bi, qkv[T:], M=B * N, c_rpb=N, vt=vt, vt_col0=2 * D, vt_rpb=N, vt_row0=T, **kw),
+                  hip.make_problem(xt, wt, bt, qkv[:T], M=B * T, c_rpb=T, vt=vt, vt_col0=2 * D, vt_rpb=T, vt_row0=0, **kw)],
+                 epi=hip.EPI_QKV, tile_cfg=cfg | flags)
+        torch.cuda.synchronize()
+        return qkv, vt
+    q0, v0 = run(hip.GEMM_NO_SPLIT)
+    q1, v1 = run(hip.GEMM_PERSIST | hip.GEMM_NO_SPLIT)
+    assert torch.equal(q0[:, :2 * D], q1[:, :2 * D]) and torch.equal(v0, v1)
+    assert torch.isfinite(q1[:, :2 * D].float()).all() and bool(torch.isnan(q1[:, 2 * D:].float()).all())
+    want = torch.cat([torch.cat([R.gemm_ref(xt[b * T:(b + 1) * T], wt, bt, 0), R.gemm_ref(xi[b * N:(b + 1) * N], wi, bi, 0)]) for b in range(B)])
+    check(q1[:, :2 * D], want[:, :2 * D])
+    check(v1[..., :L].permute(0, 3, 1, 2).reshape(B * L, D), want[:, 2 * D:])
+    q2, v2 = run(hip.GEMM_PERSIST)                         # the launcher's own plan (may split): bf16-equal
+    check(q2[:, :2 * D], want[:, :2 * D])
+
+
 def test_gemm_transpose_detecting(hip):
     """A = I with an asymmetric W: a transposed C write cannot pass."""
     n = 128

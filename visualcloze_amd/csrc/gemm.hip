@@ -26,9 +26,18 @@ constexpr int BK = 64;
 // CONV (loader-wave schedule only): the A operand is the im2col matrix of a 3x3 convolution over an NHWC map, gathered
 // on the fly by the loader waves - K-tile kt lies inside tap kt*64 / C, row m is output pixel (m / W, m % W), out-of-
 // image taps read a zero row appended to the map.  Geometry rides in the A-addressing fields (vc_conv3x3_launch).
-template <int BM, int BN, int WM, int WN, int EPI, int PP, bool CONV = false>
+//
+// PERSIST (loader-wave schedule only): the grid is one workgroup per CU and every workgroup walks the tiles of its XCD's
+// strip (tile index = slot, slot + W, ... with W = grid / 8 workgroups per XCD: the order the hardware dispatcher gives the
+// one-block-per-tile launch).  What it buys is the seam between two tiles: while the 12 waves run the epilogue of tile i
+// the loader waves already have W(0), W(1) of tile i+1 in flight - the weight operand, streamed from HBM, the long-latency
+// one - into two ring slots that live ABOVE the epilogue's LDS staging area, and A(0) follows as soon as the staging area
+// has been read back; a new workgroup would pay dispatch + offsets + the full HBM latency of its first tiles instead
+// (6.0 k cycles of prologue + 1.2-3.8 k of dispatch gap per 90 k-cycle round at K = 3072).
+template <int BM, int BN, int WM, int WN, int EPI, int PP, bool CONV = false, bool PERSIST = false>
 __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_kernel(const VcGemmArgs args) {
   static_assert(!CONV || PP == 2, "the implicit-convolution A operand is gathered by loader waves");
+  static_assert(!PERSIST || (PP == 2 && !CONV), "the persistent tile loop exists for the loader-wave schedule");
   constexpr int NCW = WM * WN;                       // compute waves
   constexpr int NT = (NCW + (PP == 2 ? 4 : 0)) * 64;  // PP == 2 adds 4 loader waves (one per SIMD)
   constexpr int NS = PP == 2 ? 256 : NT;              // threads that stage operand tiles
@@ -56,48 +65,75 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
 #define VC_PHASE_STAMP(i) do {} while (0)
 #endif
 
-  // ---- which tile ----
-  int id = xcd_remap(blockIdx.x, gridDim.x);
-  int pi = 0;
+  // ---- which tile(s) ----
+  // one block per tile: logical id = xcd_remap(blockIdx) (XCD x works on one contiguous strip of ids).  PERSIST: the same
+  // strips, walked by the W = grid / 8 resident workgroups of the XCD: ids strip0 + slot, strip0 + slot + W, ...
+  int id_cur = xcd_remap(blockIdx.x, gridDim.x), id_end = 0, id_step = 0;
+  if constexpr (PERSIST) {
+    const int total = args.p[args.nprob - 1].tile_start + args.p[args.nprob - 1].tiles_m * args.p[args.nprob - 1].tiles_n;
+    const int x = blockIdx.x & 7, q = total >> 3, r = total & 7;
+    const int strip0 = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    id_cur = strip0 + (blockIdx.x >> 3);
+    id_end = strip0 + q + (x < r ? 1 : 0);
+    id_step = gridDim.x >> 3;
+    if (id_cur >= id_end) return;
+  }
+  struct Tile { VcGemmProblem P; int m0, n0; };
+  auto decode = [&](int id) {
+    int pi = 0;
 #pragma unroll
-  for (int q = 1; q < VC_GEMM_MAX_PROBLEMS; ++q)
-    if (q < args.nprob && id >= args.p[q].tile_start) pi = q;
-  const VcGemmProblem P = pi == 3 ? args.p[3] : pi == 2 ? args.p[2] : pi == 1 ? args.p[1] : args.p[0];
-  id -= P.tile_start;
-  constexpr int GROUP_M = 8;
-  const int in_group = GROUP_M * P.tiles_n;
-  const int group = id / in_group;
-  const int first_m = group * GROUP_M;
-  const int gsz = min(P.tiles_m - first_m, GROUP_M);
-  const int tm = first_m + (id % in_group) % gsz;
-  const int tn = (id % in_group) / gsz;
-  const int m0 = P.m_begin + tm * BM, n0 = tn * BN;     // m_begin: rows below it belong to the other launch of a split call
-  const int M = P.M, N = P.N, K = P.K;
-
-  const bf16_t* __restrict__ Ab = (const bf16_t*)P.A;
-  const bf16_t* __restrict__ Wb = (const bf16_t*)P.W;
-
+    for (int q = 1; q < VC_GEMM_MAX_PROBLEMS; ++q)
+      if (q < args.nprob && id >= args.p[q].tile_start) pi = q;
+    Tile t;
+    t.P = pi == 3 ? args.p[3] : pi == 2 ? args.p[2] : pi == 1 ? args.p[1] : args.p[0];
+    id -= t.P.tile_start;
+    constexpr int GROUP_M = 8;
+    const int in_group = GROUP_M * t.P.tiles_n;
+    const int group = id / in_group;
+    const int first_m = group * GROUP_M;
+    const int gsz = min(t.P.tiles_m - first_m, GROUP_M);
+    const int tm = first_m + (id % in_group) % gsz;
+    const int tn = (id % in_group) / gsz;
+    t.m0 = t.P.m_begin + tm * BM;     // m_begin: rows below it belong to the other launch of a split call
+    t.n0 = tn * BN;
+    return t;
+  };
   // ---- staging source offsets (elements), one per 16-B chunk this thread copies ----
   const int stid = PP == 2 ? (tid - NCW * 64) & 255 : tid;   // staging thread / wave index (PP == 2: loader waves)
   const int swave = PP == 2 ? (wave - NCW) & 3 : wave;
-  uint32_t a_off[A_IT], b_off[B_IT];
-  auto staging_offsets = [&]() {   // loader-wave kernels run this inside the loader branch only: nothing of it is live in compute waves
+  // loader-wave kernels run these inside the loader branch (and, PERSIST, at the seam between two tiles) only, each time into
+  // registers that die with their last piece: nothing of them is live in a compute wave's K loop
+  auto staging_offsets_a = [&](uint32_t (&ao)[A_IT], const VcGemmProblem& Q, int m0q, int st) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-      const int c = i * NS + stid;
+      const int c = i * NS + st;
       const int row = c >> 3, slot = (c & 7) ^ (row & 7);
-      const int grow = min(m0 + row, M - 1);
-      a_off[i] = (P.a_rpb > 0 ? (uint32_t)(grow / P.a_rpb) * (uint32_t)P.a_bstride + (uint32_t)(grow % P.a_rpb) * (uint32_t)P.lda
-                              : (uint32_t)grow * (uint32_t)P.lda) + slot * 8;
-    }
-#pragma unroll
-    for (int i = 0; i < B_IT; ++i) {
-      const int c = i * NS + stid;
-      const int row = c >> 3, slot = (c & 7) ^ (row & 7);
-      const int grow = min(n0 + row, N - 1);
-      b_off[i] = (uint32_t)grow * (uint32_t)P.ldw + slot * 8;
+      const int grow = min(m0q + row, Q.M - 1);
+      ao[i] = (Q.a_rpb > 0 ? (uint32_t)(grow / Q.a_rpb) * (uint32_t)Q.a_bstride + (uint32_t)(grow % Q.a_rpb) * (uint32_t)Q.lda
+                           : (uint32_t)grow * (uint32_t)Q.lda) + slot * 8;
     }
   };
+  auto staging_offsets_b = [&](uint32_t (&bo)[B_IT], const VcGemmProblem& Q, int n0q, int st) {
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const int c = i * NS + st;
+      const int row = c >> 3, slot = (c & 7) ^ (row & 7);
+      const int grow = min(n0q + row, Q.N - 1);
+      bo[i] = (uint32_t)grow * (uint32_t)Q.ldw + slot * 8;
+    }
+  };
+
+  for (bool first_tile = true;; first_tile = false) {      // (one pass unless PERSIST)
+  const Tile tile_cur = decode(id_cur);
+  const VcGemmProblem& P = tile_cur.P;
+  const int m0 = tile_cur.m0, n0 = tile_cur.n0;
+  const int M = P.M, N = P.N, K = P.K;
+  const bool has_next = PERSIST && id_cur + id_step < id_end;
+
+  const bf16_t* __restrict__ Ab = (const bf16_t*)P.A;
+  const bf16_t* __restrict__ Wb = (const bf16_t*)P.W;
+  uint32_t a_off[A_IT], b_off[B_IT];
+  auto staging_offsets = [&]() { staging_offsets_a(a_off, P, m0, stid); staging_offsets_b(b_off, P, n0, stid); };
   if constexpr (PP != 2) staging_offsets();
   // implicit 3x3 convolution: (y, x) of the output pixel each A piece of this thread belongs to, packed y << 16 | x
   const int cvC = (int)P.lda, cvW = P.a_rpb, cvH = (int)(P.a_bstride & 0xffffffff), cvMode = (int)(P.a_bstride >> 32);
@@ -145,12 +181,17 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
       if (B_CH % NS == 0 || i * NS + swave * 64 < B_CH) glds16(Wb + b_off[i] + k0, sb + (i * NS + swave * 64) * 16);
   };
   // PP == 2 (loader waves): A lives in a 2-deep ring, W in a 3-deep ring (2*A_BYTES + 3*B_BYTES = 136 KB for 256x192),
+  // PERSIST: slot 2 stays behind the A ring, slots 0 and 1 move to the top of the 160 KB so that the epilogue's staging
+  // area (which starts at 0 and covers the A ring and slot 2) never touches them: W(0), W(1) of the NEXT tile land there
+  // while the current tile's epilogue runs.
   constexpr int W_RING0 = 2 * A_BYTES;
+  constexpr int W_HI = 160 * 1024 - 2 * B_BYTES;
+  auto wslot = [&](int slot) { return PERSIST ? (slot == 2 ? W_RING0 : W_HI + slot * B_BYTES) : W_RING0 + slot * B_BYTES; };
   auto stage_a_piece = [&](int slot, int k0, int i) {
     if constexpr (CONV) glds16(conv_src(i), smem + slot * A_BYTES + (i * NS + swave * 64) * 16);   // (conv_set_k(k0) done by the caller)
     else glds16(Ab + a_off[i] + k0, smem + slot * A_BYTES + (i * NS + swave * 64) * 16);
   };
-  auto stage_w_piece = [&](int slot, int k0, int i) { glds16(Wb + b_off[i] + k0, smem + W_RING0 + slot * B_BYTES + (i * NS + swave * 64) * 16); };
+  auto stage_w_piece = [&](int slot, int k0, int i) { glds16(Wb + b_off[i] + k0, smem + wslot(slot) + (i * NS + swave * 64) * 16); };
 
   // ---- fragment read offsets ----
   const int fr = lane & 15, fq = lane >> 4;
@@ -209,18 +250,24 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
     constexpr int WD = 2;                               // W is issued WD tiles ahead into a ring of WD+1 slots
     if (wave >= NCW) {
       staging_offsets();
+      if (!PERSIST || first_tile) {
 #pragma unroll
-      for (int i = 0; i < A_IT; ++i) stage_a_piece(0, 0, i);
+        for (int i = 0; i < A_IT; ++i) stage_a_piece(0, 0, i);
 #pragma unroll
-      for (int d = 0; d < WD; ++d)
-        if (d < nk) {
+        for (int d = 0; d < WD; ++d)
+          if (d < nk) {
 #pragma unroll
-          for (int i = 0; i < B_IT; ++i) stage_w_piece(d, d * BK, i);
-        }
-      // the first barrier needs A(0) and W(0) only: W(1) - the last B_IT pieces issued - keeps flying, exactly as W(t+2)
-      // does in the steady state (it is waited for by the vmcnt(B_IT) that ends K-tile 0, one tile before its first reader)
-      if (nk > 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(B_IT) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            for (int i = 0; i < B_IT; ++i) stage_w_piece(d, d * BK, i);
+          }
+        // the first barrier needs A(0) and W(0) only: W(1) - the last B_IT pieces issued - keeps flying, exactly as W(t+2)
+        // does in the steady state (it is waited for by the vmcnt(B_IT) that ends K-tile 0, one tile before its first reader)
+        if (nk > 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(B_IT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      } else {
+        // this tile's W(0), W(1) (under the previous epilogue) and A(0) (after it) were issued at the end of the previous
+        // pass: A(0) went out last, everything before it has had an epilogue's time to land
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      }
       bar();
       int wsd = WD;                                     // W slot of tile kt+WD
       for (int kt = 0; kt < nk; ++kt) {
@@ -279,7 +326,7 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
       int ws = 0;                                       // W slot of tile kt
       for (int kt = 0; kt < nk; ++kt) {
         const char* base_a = smem + (kt & 1) * A_BYTES;
-        const char* base_b = smem + W_RING0 - A_BYTES + ws * B_BYTES;   // b_rd already carries +A_BYTES
+        const char* base_b = smem + wslot(ws) - A_BYTES;                 // b_rd already carries +A_BYTES
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
           bf16x8 af[MI], bfr[NI];
@@ -384,8 +431,12 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
   }
 
   VC_PHASE_STAMP(2);
+  // PERSIST: the next tile (decoded once more at the top of the next pass; scalar work)
+  const Tile tile_next = has_next ? decode(id_cur + id_step) : tile_cur;
+  auto epilogue = [&]() {
   int etid = tid;                       // opaque copy: keeps the epilogue's address arithmetic below the K loop
   asm volatile("" : "+v"(etid));
+  const int efr = PERSIST ? (etid & 15) : fr, efq = PERSIST ? ((etid & 63) >> 4) : fq;   // (PERSIST: nor above the tile loop)
   // ---- gate/residual epilogue of the loader-wave kernel: the residual chunks (and the gate chunk: the column of a
   // thread is the same in every pass-2 iteration) are requested NOW, so their HBM latency runs under pass 1 instead of
   // twice inside pass 2 (pass 2 was 10.6 k cycles per block against 2.7 k for the plain epilogue) ----
@@ -438,10 +489,10 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     if (PP == 2 && wave >= NCW) break;   // loader waves hold no accumulators
-    const int row = wm * TM + i * 16 + fr;
+    const int row = wm * TM + i * 16 + efr;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      const int col = wn * TN + j * 16 + fq * 4;
+      const int col = wn * TN + j * 16 + efq * 4;
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
       if (PP == 2) {
         // bias already in the accumulators
@@ -460,8 +511,27 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
       }
     }
   }
-  if constexpr (PREF) {   // LDS writes done; the residual prefetch stays in flight (__syncthreads would wait for it: vmcnt(0))
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if constexpr (PERSIST) {
+    // the seam: the loaders compute the next tile's offsets (a_off / b_off are dead once the K loop has issued its last
+    // pieces) and send W(0), W(1) of the next tile into ring slots 0 and 1 - above the staging area the other waves are
+    // writing right now; every reader of those slots passed the barrier that ended the K loop
+    if (wave >= NCW && has_next) {
+      int st = stid;
+      asm volatile("" : "+v"(st));     // (nothing of this is to be hoisted above the K loop)
+      uint32_t bn[B_IT];
+      staging_offsets_b(bn, tile_next.P, tile_next.n0, st);
+      const bf16_t* Wn = (const bf16_t*)tile_next.P.W;
+      const int nkn = tile_next.P.K / BK;
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+        if (d < nkn) {
+#pragma unroll
+          for (int i = 0; i < B_IT; ++i) glds16(Wn + bn[i] + d * BK, smem + wslot(d) + (i * NS + swave * 64) * 16);
+        }
+    }
+  }
+  if constexpr (PREF || PERSIST) {   // LDS writes done; the residual prefetch / the next tile's W pieces stay in flight
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (__syncthreads would wait for them: vmcnt(0))
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   } else {
@@ -550,23 +620,49 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
     *(u32x4*)(C + crow + n) = o;
   }
   VC_PHASE_STAMP(4);
+  };   // epilogue
+  epilogue();
+  if constexpr (!PERSIST) {
+    break;
+  } else {
+    if (!has_next) break;
+    // every wave has read its share of the staging area back: the A ring is free again
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (wave >= NCW) {
+      int st = stid;
+      asm volatile("" : "+v"(st));
+      uint32_t an[A_IT];
+      staging_offsets_a(an, tile_next.P, tile_next.m0, st);
+      const bf16_t* An = (const bf16_t*)tile_next.P.A;
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) glds16(An + an[i], smem + (i * NS + swave * 64) * 16);
+    }
+    id_cur += id_step;
+  }
+  }    // tiles
 }
 
-template <int BM, int BN, int WM, int WN, int PP>
+template <int BM, int BN, int WM, int WN, int PP, bool PERSIST = false>
 hipError_t launch_cfg(const VcGemmArgs& a, int total_tiles, hipStream_t s) {
   constexpr int NT = (WM * WN + (PP == 2 ? 4 : 0)) * 64;
   constexpr int LDS_STAGES = (PP == 2 ? 2 * BM + 3 * BN : 2 * (BM + BN)) * BK * 2, LDS_EPI = BM * (BN * 2 + 16);
   constexpr int LDS_EPIT = BN * (BM * 2 + 16);      // EPI_QKV stages V tiles transposed
   constexpr int LDS0 = LDS_STAGES > LDS_EPI ? LDS_STAGES : LDS_EPI;
-  constexpr int LDS = LDS0 > LDS_EPIT ? LDS0 : LDS_EPIT;
+  constexpr int LDS1 = LDS0 > LDS_EPIT ? LDS0 : LDS_EPIT;
+  // PERSIST: W ring slots 0 and 1 sit at the top of the 160 KB, above both staging images (and above slot 2)
+  static_assert(!PERSIST || (160 * 1024 - 2 * BN * BK * 2 >= LDS_EPI && 160 * 1024 - 2 * BN * BK * 2 >= LDS_EPIT &&
+                             160 * 1024 - 2 * BN * BK * 2 >= (2 * BM + BN) * BK * 2), "no room for the next tile's W(0), W(1)");
+  constexpr int LDS = PERSIST ? 160 * 1024 : LDS1;
   static_assert(LDS <= 160 * 1024, "tile does not fit the 160 KB LDS of a gfx950 CU");
   void (*fn)(const VcGemmArgs) = nullptr;
   switch (a.epi) {
-    case VC_EPI_QKV: fn = gemm_bf16_kernel<BM, BN, WM, WN, VC_EPI_QKV, PP>; break;
-    case VC_EPI_BIAS: fn = gemm_bf16_kernel<BM, BN, WM, WN, VC_EPI_BIAS, PP>; break;
-    case VC_EPI_GELU: fn = gemm_bf16_kernel<BM, BN, WM, WN, VC_EPI_GELU, PP>; break;
-    case VC_EPI_GATE_RES: fn = gemm_bf16_kernel<BM, BN, WM, WN, VC_EPI_GATE_RES, PP>; break;
-    case VC_EPI_SILU: fn = gemm_bf16_kernel<BM, BN, WM, WN, VC_EPI_SILU, PP>; break;
+    case VC_EPI_QKV: fn = gemm_bf16_kernel<BM, BN, WM, WN, VC_EPI_QKV, PP, false, PERSIST>; break;
+    case VC_EPI_BIAS: fn = gemm_bf16_kernel<BM, BN, WM, WN, VC_EPI_BIAS, PP, false, PERSIST>; break;
+    case VC_EPI_GELU: fn = gemm_bf16_kernel<BM, BN, WM, WN, VC_EPI_GELU, PP, false, PERSIST>; break;
+    case VC_EPI_GATE_RES: if constexpr (PERSIST) return hipErrorInvalidValue; else fn = gemm_bf16_kernel<BM, BN, WM, WN, VC_EPI_GATE_RES, PP>; break;
+    case VC_EPI_SILU: fn = gemm_bf16_kernel<BM, BN, WM, WN, VC_EPI_SILU, PP, false, PERSIST>; break;
     default: return hipErrorInvalidValue;
   }
   static VcOncePerDevice attr_done[5];
@@ -575,7 +671,7 @@ hipError_t launch_cfg(const VcGemmArgs& a, int total_tiles, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_done[a.epi].mark();
   }
-  hipLaunchKernelGGL(fn, dim3(total_tiles), dim3(NT), LDS, s, a);
+  hipLaunchKernelGGL(fn, dim3(PERSIST ? std::min(total_tiles, vc_cu_count() / 8 * 8) : total_tiles), dim3(NT), LDS, s, a);
   return hipGetLastError();
 }
 
@@ -665,7 +761,7 @@ TilePlan best_tile(const VcGemmArgs& a) {
   return best;
 }
 
-int launch_tiles(VcGemmArgs a, int tile_cfg, int pp, hipStream_t s, char* err, int errlen) {
+int launch_tiles(VcGemmArgs a, int tile_cfg, int pp, bool want_persist, hipStream_t s, char* err, int errlen) {
   if (tile_cfg < 1 || tile_cfg > 5 || pp > 2 || (pp == 1 && tile_cfg < 3) || (pp == 2 && tile_cfg != 4 && tile_cfg != 2)) { snprintf(err, errlen, "gemm: bad tile_cfg %d", tile_cfg); return VC_ERR_ARG; }
   const int bm = cfg_bm[tile_cfg], bn = cfg_bn[tile_cfg];
   int total = 0, np = 0;
@@ -680,12 +776,22 @@ int launch_tiles(VcGemmArgs a, int tile_cfg, int pp, hipStream_t s, char* err, i
   }
   if (np == 0) return VC_OK;
   a.nprob = np;
+  // VC_GEMM_PERSIST + more tiles than CUs on the loader-wave schedule: one persistent workgroup per CU walks them
+  // (gemm_bf16_kernel PERSIST).  OPT-IN: bit-identical, and worth +0.05 % steps/s at cfg 2 (-0.4 ... -0.7 % per qkv / MLP-up
+  // launch, profiles/r03d_*), +-0.2 % at the other geometries (profiles/r03e_persist_ab.log) - under the board's power limit
+  // the dispatch gap and the first-tile latency a fresh workgroup pays are idle, low-power time that the clock gives back.
+  // (Not the gated-residual epilogue: its residual prefetch registers + the loop state do not fit the 168-VGPR budget of the
+  // 3-waves-per-SIMD kernel - 39 spilled registers.)
+  const int n_cu8 = vc_cu_count() / 8 * 8;
+  const bool persist = pp == 2 && want_persist && n_cu8 >= 8 && total > n_cu8 && a.epi != VC_EPI_GATE_RES;
   hipError_t e;
   switch (tile_cfg) {
     case 1: e = launch_cfg<128, 128, 2, 2, 0>(a, total, s); break;
-    case 2: e = pp == 2 ? launch_cfg<256, 128, 4, 2, 2>(a, total, s) : launch_cfg<256, 128, 4, 2, 0>(a, total, s); break;
+    case 2: e = pp == 2 ? (persist ? launch_cfg<256, 128, 4, 2, 2, true>(a, total, s) : launch_cfg<256, 128, 4, 2, 2>(a, total, s))
+                        : launch_cfg<256, 128, 4, 2, 0>(a, total, s); break;
     case 3: e = pp ? launch_cfg<256, 256, 2, 4, 1>(a, total, s) : launch_cfg<256, 256, 2, 4, 0>(a, total, s); break;
-    case 4: e = pp == 2 ? launch_cfg<256, 192, 4, 2, 2>(a, total, s) : pp ? launch_cfg<256, 192, 4, 2, 1>(a, total, s) : launch_cfg<256, 192, 4, 2, 0>(a, total, s); break;
+    case 4: e = pp == 2 ? (persist ? launch_cfg<256, 192, 4, 2, 2, true>(a, total, s) : launch_cfg<256, 192, 4, 2, 2>(a, total, s))
+                        : pp ? launch_cfg<256, 192, 4, 2, 1>(a, total, s) : launch_cfg<256, 192, 4, 2, 0>(a, total, s); break;
     default: e = pp ? launch_cfg<256, 288, 4, 2, 1>(a, total, s) : launch_cfg<256, 288, 4, 2, 0>(a, total, s); break;
   }
   if (e != hipSuccess) { snprintf(err, errlen, "gemm launch: %s", hipGetErrorString(e)); return VC_ERR_HIP; }
@@ -769,14 +875,15 @@ int vc_gemm_launch(VcGemmArgs a, int tile_cfg, hipStream_t s, char* err, int err
   int rc = validate_gemm(a, err, errlen);
   if (rc != VC_OK) return rc;
   const GemmPlan pl = plan_gemm(a, tile_cfg);
-  if (pl.cut == 0) return launch_tiles(a, pl.tile1, pl.pp1, s, err, errlen);
+  const bool want_persist = (tile_cfg & VC_GEMM_PERSIST) != 0;
+  if (pl.cut == 0) return launch_tiles(a, pl.tile1, pl.pp1, want_persist, s, err, errlen);
   VcGemmArgs first = a;
   first.nprob = 1;
   first.p[0].M = pl.cut;                                       // rows [0, cut) of problem 0 on the 256x192 loader-wave tile
-  rc = launch_tiles(first, pl.tile1, pl.pp1, s, err, errlen);
+  rc = launch_tiles(first, pl.tile1, pl.pp1, want_persist, s, err, errlen);
   if (rc != VC_OK) return rc;
   a.p[0].m_begin = pl.cut;
-  return launch_tiles(a, pl.tile2, pl.pp2, s, err, errlen);
+  return launch_tiles(a, pl.tile2, pl.pp2, want_persist, s, err, errlen);
 }
 
 // the plan without the launch: out = {cut row, tile / loader mode of the first (or only) launch, of the second, tiles of both}

@@ -20,6 +20,7 @@ ABI_VERSION = 5                # VC_ABI_VERSION of include/vcloze_hip.h
 GEMM_MAX_PROBLEMS = 4          # VC_GEMM_MAX_PROBLEMS: grouped problems per vc_gemm launch
 EPI_BIAS, EPI_GELU, EPI_GATE_RES, EPI_SILU, EPI_QKV = 0, 1, 2, 3, 4
 GEMM_NO_SPLIT = 64             # VC_GEMM_NO_SPLIT: tile_cfg value that keeps an auto-tiled vc_gemm one launch
+GEMM_PERSIST = 128             # VC_GEMM_PERSIST: opt into the persistent tile loop of the loader-wave GEMM (multi-round launches)
 
 
 class VclozeHipError(RuntimeError):

@@ -350,6 +350,7 @@ def parse_args(argv=None):
     ap.add_argument("--tile-cfg", type=int, default=None)
     ap.add_argument("--attn-variant", type=int, default=None)
     ap.add_argument("--no-fuse-vt", action="store_true", help="A/B: V^T by the pre-pass kernel instead of the qkv GEMM's epilogue")
+    ap.add_argument("--no-fuse-knorm", action="store_true", help="A/B: key QKNorm + RoPE by the pre-pass kernel instead of the qkv GEMM's epilogue")
     ap.add_argument("--python-plan", action="store_true",
                     help="A/B: order the launches from Python (engine.FluxEngine) instead of the C handle API")
     ap.add_argument("--per-gpu-batch", type=int, default=1,
@@ -425,6 +426,8 @@ def main(argv=None):
         eng.attn_variant = a.attn_variant
     model.use_handle = not a.python_plan
     eng.fuse_vt = not a.no_fuse_vt
+    if a.no_fuse_knorm:
+        eng.fuse_knorm = False
     PB = a.per_gpu_batch
     x, kw = make_inputs(dev, wl, seed=par.sample_seed(0, rank * PB), B=PB)   # seed from the global sample index
     job = Job(model, x, kw, wl["steps"], t0=wl.get("t0", 0.0), do_shift=wl.get("do_shift", True))

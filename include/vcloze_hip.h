@@ -21,7 +21,7 @@ extern "C" {
 #define VC_ERR_HIP (-2)
 #define VC_ERR_STATE (-3)
 
-#define VC_ABI_VERSION 5
+#define VC_ABI_VERSION 6
 int vc_abi_version(void);
 const char* vc_last_error(void);
 /* sizeof(VcGemmProblem), sizeof(VcGemmArgs), sizeof(VcLnStream), sizeof(VcAttention), sizeof(VcFluxConfig),
@@ -66,6 +66,20 @@ typedef struct VcGemmProblem {
   void* vt;
   int64_t vt_bstride;
   int32_t vt_col0, vt_rpb, vt_row0, vt_lpad;
+  /* VC_EPI_QKV, kn_heads = H > 0 (N = 3 * 128 * H): W's rows / bias arrive HEAD-PERMUTED so that every key head lies inside
+   * one 192-column tile - permuted column p is logical column (t = p / 192, j = p % 192)
+   *     p < 192 H:   j < 128 ?  128 H + 128 t + j  (key head t)  :  64 t + j - 128  (query columns)
+   *     p < 256 H:   p - 128 H                                      (the other half of the query columns)
+   *     else:        p                                              (V, as before; vt_col0 = 256 H)
+   * and C is written at the logical columns ("B L (K H D)", layers.py:166,236) by any tile shape.  With kn_scale != NULL
+   * (forces the 256x192 tile) the epilogue ALSO applies QKNorm with kn_scale [128] bf16 and RoPE from kn_rope
+   * ([B?][L][64][2] f32, row vt_row0 + m % vt_rpb of batch element m / vt_rpb) to every key head before the row leaves
+   * (layers.py:63-84, math.py:112-117): bit-identical to vc_qknorm_rope_vt(parts = VC_QKN_K) over the plain output, which
+   * is then not needed - the "QKV + RoPE fused projection" (q: VcAttention.q_scale; V: vt). */
+  const void* kn_scale;
+  const float* kn_rope;
+  int64_t kn_rope_bstride;
+  int32_t kn_heads, kn_pad_;
 } VcGemmProblem;
 
 #define VC_GEMM_MAX_PROBLEMS 4
@@ -282,7 +296,11 @@ int vc_flux_destroy(void* handle);
 int vc_flux_bind_weight(void* handle, const char* name, const void* w, const void* bias, int32_t rows, int32_t cols, int64_t ldw);
 int64_t vc_flux_mod_offset(void* handle, const char* module_name);
 /* knobs for tests and A/B runs: "attn_variant" (-1 = by size, the default), "tile_cfg" (0), "fuse_qnorm" (1: query
- * QKNorm + RoPE inside the attention kernel), "fuse_vt" (1: V^T from the qkv GEMM's epilogue, VC_EPI_QKV) */
+ * QKNorm + RoPE inside the attention kernel), "fuse_vt" (1: V^T from the qkv GEMM's epilogue, VC_EPI_QKV);
+ * "qkv_heads" (0; = num_heads when the caller bound HEAD-PERMUTED qkv weights - every `*_attn.qkv` and the first
+ * 3 * hidden rows of every `linear1`, with their biases, in the row order VcGemmProblem.kn_heads describes) and, with it,
+ * "fuse_knorm" (0; 1: QKNorm + RoPE of the key heads inside the qkv GEMM's epilogue - with fuse_qnorm and fuse_vt the
+ * projection, the norms, RoPE and the V transpose are then ONE GEMM launch + the attention kernel: no pre-pass). */
 int vc_flux_set_option(void* handle, const char* name, int32_t value);
 int64_t vc_flux_workspace_bytes(void* handle, int32_t B, int32_t T, int32_t N, int32_t max_steps);
 

@@ -182,6 +182,47 @@ def test_gemm_persistent_grouped_qkv_epilogue(hip, cfg):
     check(q2[:, :2 * D], want[:, :2 * D])
 
 
+@pytest.mark.parametrize("cfg", [0, 1, 2, 4, 5, 19, 34, 36])
+@pytest.mark.parametrize("geom", [(2, 16, 24, 2), (1, 64, 320, 3), (2, 5, 27, 1), (1, 136, 700, 6)])
+def test_gemm_head_permuted_qkv_and_key_norm_in_the_epilogue(hip, cfg, geom):
+    """VcGemmProblem.kn_heads: qkv weights whose rows are head-permuted (every key head inside one 192-column tile) give the
+    SAME C (q | k | v at their logical columns) and the same V^T as the natural order, on every tile shape; with kn_scale
+    the 256x192 epilogue also applies QKNorm + RoPE to the key heads - bit-identical to GEMM + vc_qknorm_rope_vt(parts = K).
+    Two streams with their own key scales, batch-strided C rows, two batch elements, row counts off every tile edge."""
+    B, T, N, H = geom
+    D, L = 128 * H, T + N
+    Lp = (L + 63) // 64 * 64
+    xi, xt = rnd(B * N, D, seed=1), rnd(B * T, D, seed=2)
+    wi, wt = rnd(3 * D, D, scale=D ** -0.5, seed=3), rnd(3 * D, D, scale=D ** -0.5, seed=4)
+    bi, bt = rnd(3 * D, seed=5), rnd(3 * D, seed=6)
+    ks_i, ks_t = (1 + 0.1 * rnd(128, seed=8)).to(torch.bfloat16), (1 + 0.1 * rnd(128, seed=9)).to(torch.bfloat16)
+    qs = torch.ones(128, dtype=torch.bfloat16, device=DEV)
+    rope = torch.stack([rope_table(L), rope_table(L).flip(0)][:B]).contiguous()
+    perm = hip.qkv_head_permutation(H).to(DEV)
+
+    def run(permuted, fused, tile):
+        qkv = torch.full((B * L, 3 * D), float("nan"), dtype=torch.bfloat16, device=DEV)
+        vt = torch.full((B, H, 128, Lp), 7.0, dtype=torch.bfloat16, device=DEV)
+        kw = dict(c_bstride=L * 3 * D, vt=vt, vt_col0=2 * D)
+        kn_i = dict(kn_heads=H, kn_scale=ks_i if fused else None, kn_rope=rope if fused else None) if permuted else {}
+        kn_t = dict(kn_heads=H, kn_scale=ks_t if fused else None, kn_rope=rope if fused else None) if permuted else {}
+        w1, b1, w2, b2 = (wi[perm].contiguous(), bi[perm].contiguous(), wt[perm].contiguous(), bt[perm].contiguous()) if permuted else (wi, bi, wt, bt)
+        hip.gemm([hip.make_problem(xi, w1, b1, qkv[T:], M=B * N, c_rpb=N, vt_rpb=N, vt_row0=T, **kw, **kn_i),
+                  hip.make_problem(xt, w2, b2, qkv[:T], M=B * T, c_rpb=T, vt_rpb=T, vt_row0=0, **kw, **kn_t)], epi=hip.EPI_QKV, tile_cfg=tile)
+        torch.cuda.synchronize()
+        return qkv, vt
+    plain, vt0 = run(False, False, cfg | hip.GEMM_NO_SPLIT)
+    permd, vt1 = run(True, False, cfg | hip.GEMM_NO_SPLIT)
+    assert torch.equal(permd[:, :2 * D], plain[:, :2 * D]) and torch.equal(vt1, vt0)
+    assert bool(torch.isnan(permd[:, 2 * D:].float()).all()) and torch.isfinite(permd[:, :2 * D].float()).all()
+    fused, vt2 = run(True, True, cfg | hip.GEMM_NO_SPLIT)          # (kn_scale forces the 256x192 tile whatever cfg asks for)
+    want = plain.clone()
+    hip.qknorm_rope_vt(want, qs, ks_t, rope, vt0.clone(), L, H, q_scale2=qs, k_scale2=ks_i, split=T, B=B, parts=hip.QKN_K)
+    torch.cuda.synchronize()
+    assert torch.equal(fused[:, :2 * D], want[:, :2 * D]) and torch.equal(vt2, vt0)
+    assert not torch.equal(fused[:, D:2 * D], plain[:, D:2 * D])
+
+
 def test_gemm_transpose_detecting(hip):
     """A = I with an asymmetric W: a transposed C write cannot pass."""
     n = 128

@@ -56,7 +56,8 @@ def main():
         who, kv = o.split(":")
         k, v = kv.split("=")
         opts.setdefault(who, {})[k] = int(v)
-    base_opts = dict(attn_variant=eng.attn_variant, tile_cfg=eng.tile_cfg, fuse_qnorm=eng.fuse_qnorm, fuse_vt=eng.fuse_vt)
+    base_opts = dict(attn_variant=eng.attn_variant, tile_cfg=eng.tile_cfg, fuse_qnorm=eng.fuse_qnorm, fuse_vt=eng.fuse_vt,
+                     fuse_knorm=eng.fuse_knorm)
     jobs, libs = {}, {}
     for libname, alias in builds:
         libs[alias] = load(libname)

@@ -57,6 +57,33 @@ VC_DEV float silu_f(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
 
+// QKNorm (layers.py:63-84: x * rsqrt(mean(x^2) + 1e-6) -> bf16, * scale -> bf16) and RoPE on the interleaved pairs
+// (math.py:112-117) of the 8 consecutive elements a lane owns of a 128-wide head row; the row's 16 lanes are neighbours
+// (lane & 15 = position in the row).  ONE definition for the pre-pass kernels (norm.hip) and the qkv GEMM's epilogue
+// (gemm.hip), with floating-point contraction OFF: every product and sum is rounded as written (what torch's separate
+// mul / add kernels do), so the call sites give the same bits whatever the compiler would fuse around them.
+VC_DEV u32x4 qknorm_rope8(const u32x4 w, const float (&g)[8], const float (&cs)[8]) {
+#pragma clang fp contract(off)
+  float x[8];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { x[2 * e] = lo_bf(w[e]); x[2 * e + 1] = hi_bf(w[e]); }
+  float ss = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ss += x[e] * x[e];
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) ss += __shfl_xor(ss, o, 64);
+  const float rrms = 1.0f / sqrtf(ss * (1.0f / 128.0f) + 1e-6f);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) x[e] = rbf(rbf(x[e] * rrms) * g[e]);
+  u32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float co = cs[2 * e], si = cs[2 * e + 1];
+    o[e] = pack2bf(co * x[2 * e] - si * x[2 * e + 1], si * x[2 * e] + co * x[2 * e + 1]);
+  }
+  return o;
+}
+
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 // async HBM -> LDS copy, 16 B per lane; LDS destination = wave-uniform base + lane*16

@@ -56,7 +56,7 @@ struct Flux : Buffers {
   std::vector<SingleW> sgl;
   int64_t final_mod = 0;
   // options
-  int attn_variant = -1, tile_cfg = 0, fuse_qnorm = 1, fuse_vt = 1, n_cu = 256;
+  int attn_variant = -1, tile_cfg = 0, fuse_qnorm = 1, fuse_vt = 1, qkv_heads = 0, fuse_knorm = 0, n_cu = 256;
   // prepared geometry + workspace carve-up
   bool prepared = false;
   int B = 0, T = 0, N = 0, L = 0, Lp = 0, S = 0;
@@ -65,10 +65,11 @@ struct Flux : Buffers {
   // captured steps, most recently used first (a two-stage pipeline alternates between two geometries)
   hipGraphExec_t graph = nullptr;      // = graphs.front().second while a sample is in flight
   struct Key {
-    char* base; int B, T, N, S, ragged, gapped, variant, tile, fuse, fuse_vt, state_f32; hipStream_t s;
+    char* base; int B, T, N, S, ragged, gapped, variant, tile, fuse, fuse_vt, state_f32, qkv_heads, fuse_knorm; hipStream_t s;
     bool operator==(const Key& o) const {
       return base == o.base && B == o.B && T == o.T && N == o.N && S == o.S && ragged == o.ragged && gapped == o.gapped &&
-             variant == o.variant && tile == o.tile && fuse == o.fuse && fuse_vt == o.fuse_vt && state_f32 == o.state_f32 && s == o.s;
+             variant == o.variant && tile == o.tile && fuse == o.fuse && fuse_vt == o.fuse_vt && state_f32 == o.state_f32 &&
+             qkv_heads == o.qkv_heads && fuse_knorm == o.fuse_knorm && s == o.s;
     }
   } key{};
   std::vector<std::pair<Key, hipGraphExec_t>> graphs;
@@ -216,10 +217,17 @@ int resolve(Flux& f, Err e) {
 }
 
 // ---------------------------------------------------------------- launch helpers
-// qkv projections: with fuse_vt the V third leaves the GEMM transposed into VT (EPI_QKV) and the pre-pass is K only
-void with_vt(Flux& f, VcGemmProblem& p, int rows, int row0) {
-  if (!f.fuse_vt) return;
-  p.vt = f.VT; p.vt_bstride = (int64_t)f.H * 128 * f.Lp; p.vt_col0 = 2 * f.D; p.vt_rpb = rows; p.vt_row0 = row0; p.vt_lpad = f.Lp;
+// qkv projections: with fuse_vt the V third leaves the GEMM transposed into VT (EPI_QKV); with head-permuted weights (option
+// qkv_heads) C receives the logical columns and, with fuse_knorm, the key heads leave QK-normed and rotated: no pre-pass left
+bool kn_in_gemm(const Flux& f) { return f.fuse_knorm && f.qkv_heads > 0; }
+int qkv_epi(const Flux& f) { return f.fuse_vt || f.qkv_heads > 0 ? VC_EPI_QKV : VC_EPI_BIAS; }
+void with_vt(Flux& f, VcGemmProblem& p, int rows, int row0, const void* k_scale) {
+  if (f.fuse_vt) { p.vt = f.VT; p.vt_bstride = (int64_t)f.H * 128 * f.Lp; p.vt_col0 = 2 * f.D; p.vt_lpad = f.Lp; }
+  if (f.qkv_heads > 0) {
+    p.kn_heads = f.qkv_heads;
+    if (kn_in_gemm(f)) { p.kn_scale = k_scale; p.kn_rope = f.ROPE; p.kn_rope_bstride = (int64_t)f.L * 128; }
+  }
+  if (f.fuse_vt || f.qkv_heads > 0) { p.vt_rpb = rows; p.vt_row0 = row0; }
 }
 
 VcGemmProblem prob(const void* A, int64_t lda, const Lin& w, void* C, int64_t ldc, int M) {
@@ -270,8 +278,10 @@ int attention(Flux& f, const Ctx& c, const void* q1, const void* k1, const void*
   const int variant = attention_variant(f);
   const bool fused_q = (variant & 8) && f.fuse_qnorm;
   const int64_t ld = 3 * f.D, ldo = f.D + f.mlp;
-  TRY(vc_qknorm_rope_vt_launch(f.QKV, ld, f.L * ld, q1, k1, q2, k2, split, f.ROPE, (int64_t)f.L * 128, f.VT, f.B, f.L, f.Lp, f.H,
-                               VC_QKN_K | (fused_q ? 0 : VC_QKN_Q) | (f.fuse_vt ? 0 : VC_QKN_VT), c.s, e.buf, e.len));
+  const int parts = (kn_in_gemm(f) ? 0 : VC_QKN_K) | (fused_q ? 0 : VC_QKN_Q) | (f.fuse_vt ? 0 : VC_QKN_VT);
+  if (parts)
+    TRY(vc_qknorm_rope_vt_launch(f.QKV, ld, f.L * ld, q1, k1, q2, k2, split, f.ROPE, (int64_t)f.L * 128, f.VT, f.B, f.L, f.Lp, f.H,
+                                 parts, c.s, e.buf, e.len));
   VcAttention a;
   memset(&a, 0, sizeof(a));
   a.qkv = f.QKV; a.ld = ld; a.bstride = f.L * ld;
@@ -297,8 +307,8 @@ int double_block(Flux& f, const Ctx& c, const DoubleW& w, Err e) {
     VcGemmProblem p[2] = {prob(XH_I, D, w.qkv[0], f.QKV + (int64_t)T * ldq, ldq, B * N), prob(XH_T, D, w.qkv[1], f.QKV, ldq, B * T)};
     p[0].c_rpb = N; p[1].c_rpb = T;
     p[0].c_bstride = p[1].c_bstride = (int64_t)L * ldq;
-    with_vt(f, p[0], N, T); with_vt(f, p[1], T, 0);
-    TRY(gemm(f, p, 2, f.fuse_vt ? VC_EPI_QKV : VC_EPI_BIAS, nullptr, 0, c.s, e));
+    with_vt(f, p[0], N, T, w.ks[0]); with_vt(f, p[1], T, 0, w.ks[1]);
+    TRY(gemm(f, p, 2, qkv_epi(f), nullptr, 0, c.s, e));
   }
   TRY(attention(f, c, w.qs[1], w.ks[1], w.qs[0], w.ks[0], T, e));   // rows < T: the text stream's scales
   {  // x += gate * proj(attn): A rows are batch-strided views of CAT[:, :D]
@@ -331,8 +341,8 @@ int single_block(Flux& f, const Ctx& c, const SingleW& w, Err e) {
   TRY(ln1(f, c, w.mod, e));
   {
     VcGemmProblem p = prob(f.XH, D, w.qkv, f.QKV, 3 * D, M);
-    with_vt(f, p, f.L, 0);
-    TRY(gemm(f, &p, 1, f.fuse_vt ? VC_EPI_QKV : VC_EPI_BIAS, nullptr, 0, c.s, e));
+    with_vt(f, p, f.L, 0, w.ks);
+    TRY(gemm(f, &p, 1, qkv_epi(f), nullptr, 0, c.s, e));
   }
   TRY(lin(f, w.mlp, f.XH, D, f.CAT + D, ldc, M, VC_EPI_GELU, c.s, e));
   TRY(attention(f, c, w.qs, w.ks, nullptr, nullptr, 0, e));
@@ -433,7 +443,8 @@ void drop_graph(Flux& f) {
 
 // the hipGraph of ONE solver step: everything step-dependent (modulation rows, dt) is indexed on the device by STEP
 int step_graph(Flux& f, hipStream_t s, Err e) {
-  Flux::Key k{f.base, f.B, f.T, f.N, f.S, f.ragged, f.gapped, attention_variant(f), f.tile_cfg, f.fuse_qnorm, f.fuse_vt, f.state_f32, s};
+  Flux::Key k{f.base, f.B, f.T, f.N, f.S, f.ragged, f.gapped, attention_variant(f), f.tile_cfg, f.fuse_qnorm, f.fuse_vt, f.state_f32,
+              f.qkv_heads, f.fuse_knorm, s};
   for (size_t i = 0; i < f.graphs.size(); ++i)
     if (f.graphs[i].first == k) {
       auto hit = f.graphs[i];
@@ -531,6 +542,10 @@ int vc_flux_set_option_impl(void* handle, const char* name, int32_t value, char*
   else if (!strcmp(name, "tile_cfg")) f.tile_cfg = value;
   else if (!strcmp(name, "fuse_qnorm")) f.fuse_qnorm = value != 0;
   else if (!strcmp(name, "fuse_vt")) f.fuse_vt = value != 0;
+  else if (!strcmp(name, "qkv_heads")) {      // the bound qkv weights (linear1's first 3D rows) are head-permuted (vcloze_hip.h)
+    if (value != 0 && value != f.H) FAIL(VC_ERR_ARG, "flux_set_option: qkv_heads must be 0 or num_heads = %d", f.H);
+    f.qkv_heads = value;
+  } else if (!strcmp(name, "fuse_knorm")) f.fuse_knorm = value != 0;
   else FAIL(VC_ERR_ARG, "flux_set_option: unknown option '%s'", name);
   return VC_OK;
 }

@@ -477,12 +477,22 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
   // leaves as 16-B runs of 8 consecutive tokens per (head, dim) row of vt; a tile that straddles vt_col0 (or unaligned
   // row geometry) takes the ordinary path and scatters its V elements one by one (test geometries only).
   constexpr int EPT_LD = BM * 2 + 16;
+  // EPI_QKV with kn_heads = H > 0: the weight rows (output columns) arrive HEAD-PERMUTED (vcloze_hip.h): H blocks of
+  // [K head h (128) | 64 query columns], the other half of the query columns, V - every K head then lies inside ONE 192-wide
+  // tile, and with kn_scale the epilogue applies QKNorm + RoPE to it (layers.py:63-84, math.py:112-117) before the row
+  // leaves: the "QKV + RoPE fused projection".  C is always written at the LOGICAL columns (q | k | v).
   int vkind = 0;
+  const int knH = EPI == VC_EPI_QKV ? P.kn_heads : 0;
+  auto qkv_col = [&](int n) {        // permuted column (multiple of 8) -> logical column
+    if (n < 192 * knH) { const int t = n / 192, j = n - 192 * t; return j < 128 ? 128 * knH + 128 * t + j : 64 * t + j - 128; }
+    return n < 256 * knH ? n - 128 * knH : n;
+  };
   if constexpr (EPI == VC_EPI_QKV) {
     if (P.vt) {
       const bool aligned = ((P.vt_rpb | P.vt_row0 | P.vt_lpad | (int)(P.vt_bstride & 7)) & 7) == 0;
       vkind = n0 >= P.vt_col0 ? (aligned ? 1 : 2) : (n0 + BN > P.vt_col0 ? 2 : 0);
     }
+    if (BN == 192 && knH > 0 && P.kn_scale && n0 < 192 * knH) vkind = 3;     // [K head | 64 q columns] tile, norm in here
     vkind = __builtin_amdgcn_readfirstlane(vkind);
   }
   const bf16_t* __restrict__ bias = (const bf16_t*)P.bias;
@@ -569,6 +579,42 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
   bf16_t* __restrict__ C = (bf16_t*)P.C;
   const bf16_t* __restrict__ res = (const bf16_t*)P.res;
   const bf16_t* __restrict__ gate = (const bf16_t*)P.gate;
+  if constexpr (EPI == VC_EPI_QKV && BN == 192) {
+    if (vkind == 3) {
+      // columns 0..127 of the tile = K head t: 16 lanes own one row (8 elements each) - RMS over the 128 by 4 xor-shuffles,
+      // scale, RoPE on the interleaved pairs with the token's f32 (cos, sin) row; qknorm_rope8 (common.h) is the one
+      // definition the pre-pass kernels of norm.hip use too: same bits as GEMM + pre-pass.  Columns 128..191 = 64 query
+      // columns, copied.
+      const int t = n0 / 192;
+      const bf16_t* __restrict__ ksc = (const bf16_t*)P.kn_scale;
+      const u32x4 sw = *(const u32x4*)(ksc + (etid & 15) * 8);
+      float g[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { g[2 * e] = lo_bf(sw[e]); g[2 * e + 1] = hi_bf(sw[e]); }
+      for (int c = etid; c < BM * 16; c += NT) {          // NT % 16 == 0: a row's 16 lanes stay together
+        const int row = c >> 4, sub = c & 15;
+        const int m = min(m0 + row, M - 1);
+        const u32x4 tw = *(const u32x4*)(smem + row * EP_LD + sub * 16);
+        const int b = m / P.vt_rpb;
+        const float* rp = P.kn_rope + (long)b * P.kn_rope_bstride + (long)(P.vt_row0 + (m - b * P.vt_rpb)) * 128 + sub * 8;
+        const f32x4 c0 = *(const f32x4*)rp;
+        const f32x4 c1 = *(const f32x4*)(rp + 4);
+        const float cs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+        const u32x4 o = qknorm_rope8(tw, g, cs);
+        const long crow = P.c_rpb > 0 ? (long)(m / P.c_rpb) * P.c_bstride + (long)(m % P.c_rpb) * P.ldc : (long)m * P.ldc;
+        if (m0 + row < M) *(u32x4*)(C + crow + 128 * knH + 128 * t + sub * 8) = o;
+      }
+      for (int c = etid; c < BM * 8; c += NT) {
+        const int row = c >> 3, sub = c & 7;
+        const int m = m0 + row;
+        if (m >= M) continue;
+        const long crow = P.c_rpb > 0 ? (long)(m / P.c_rpb) * P.c_bstride + (long)(m % P.c_rpb) * P.ldc : (long)m * P.ldc;
+        *(u32x4*)(C + crow + 64 * t + sub * 8) = *(const u32x4*)(smem + row * EP_LD + 256 + sub * 16);
+      }
+      VC_PHASE_STAMP(4);
+      return;
+    }
+  }
 #pragma unroll PREF ? P2_IT : 4
   for (int it = 0; it < (PREF ? P2_IT : BM * CPR); ++it) {
     const int c = etid + it * NT;
@@ -617,7 +663,7 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
       for (int e = 0; e < 8; ++e) d[(long)e * P.vt_lpad] = (bf16_t)(o[e >> 1] >> (16 * (e & 1)));
       continue;
     }
-    *(u32x4*)(C + crow + n) = o;
+    *(u32x4*)(C + crow + (EPI == VC_EPI_QKV && knH > 0 ? qkv_col(n) : n)) = o;
   }
   VC_PHASE_STAMP(4);
   };   // epilogue
@@ -816,6 +862,11 @@ static int validate_gemm(VcGemmArgs& a, char* err, int errlen) {
       snprintf(err, errlen, "gemm: operand exceeds 32-bit element offsets"); return VC_ERR_ARG; }
     if (a.epi == VC_EPI_GATE_RES && (!p.res || !p.gate || p.rows_per_batch <= 0 || p.ldres % 8 || p.gate_bstride % 8 || a.gate_step_stride % 8)) {
       snprintf(err, errlen, "gemm: gate/residual epilogue needs res, gate, rows_per_batch"); return VC_ERR_ARG; }
+    if (a.epi == VC_EPI_QKV && p.kn_heads != 0 && (p.kn_heads < 0 || p.N != 384 * p.kn_heads || (p.vt && p.vt_col0 != 256 * p.kn_heads) ||
+                                                  (p.kn_scale && (!p.kn_rope || p.vt_rpb <= 0 || p.vt_row0 < 0 || p.kn_rope_bstride < 0)))) {
+      snprintf(err, errlen, "gemm: head-permuted qkv needs N = 3 * 128 * kn_heads (N=%d kn_heads=%d), vt_col0 = 2 * 128 * kn_heads, and with "
+                            "kn_scale a rope table + the row geometry vt_rpb / vt_row0", p.N, p.kn_heads); return VC_ERR_ARG; }
+    if (a.epi != VC_EPI_QKV && (p.kn_heads != 0 || p.kn_scale)) { snprintf(err, errlen, "gemm: kn_heads / kn_scale belong to VC_EPI_QKV"); return VC_ERR_ARG; }
     if (a.epi == VC_EPI_QKV && p.vt && (p.vt_rpb <= 0 || p.vt_col0 < 0 || p.vt_col0 % 8 || p.vt_col0 >= p.N || p.vt_row0 < 0 ||
                                         p.vt_lpad < p.vt_row0 + p.vt_rpb || p.vt_bstride < (int64_t)(p.N - p.vt_col0) * p.vt_lpad)) {
       snprintf(err, errlen, "gemm: bad V^T description (vt_col0=%d vt_rpb=%d vt_row0=%d vt_lpad=%d vt_bstride=%ld)", p.vt_col0, p.vt_rpb,
@@ -831,6 +882,8 @@ static GemmPlan plan_gemm(const VcGemmArgs& a, int tile_cfg) {
   const int force_cut = tile_cfg >> 8;                 // tests: cut problem 0 at row force_cut * 256
   const bool no_split = (tile_cfg & VC_GEMM_NO_SPLIT) != 0;
   tile_cfg &= 63;
+  for (int i = 0; i < a.nprob; ++i)      // K heads are normalised inside the epilogue: every K head must lie in one 192-wide tile
+    if (a.epi == VC_EPI_QKV && a.p[i].kn_scale) return GemmPlan{0, 4, tile_cfg != 0 && ((tile_cfg >> 4) & 3) != 2 ? (tile_cfg >> 4) & 3 : 2, 0, 0};
   if (tile_cfg != 0) return GemmPlan{0, tile_cfg & 15, (tile_cfg >> 4) & 3, 0, 0};
   const TilePlan whole = best_tile(a);
   // Block-round quantisation: cut problem 0's rows where the 256x192 tiles above the cut are (nearly) whole rounds of the 256

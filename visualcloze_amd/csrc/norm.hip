@@ -103,38 +103,18 @@ __global__ __launch_bounds__(256) void qknorm_rope_vt_kernel(bf16_t* __restrict_
     const int tok = t0 + (rowid & 63);
     const bool ok = tok < L;
     bf16_t* ptr = base + (long)(ok ? tok : 0) * ld + which * (H * 128) + sub * 8;
-    float x[8];
-    {
-      const u32x4 w = *(const u32x4*)ptr;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { x[2 * e] = lo_bf(w[e]); x[2 * e + 1] = hi_bf(w[e]); }
-    }
-    float ss = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ss += x[e] * x[e];
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) ss += __shfl_xor(ss, o, 64);
-    const float rrms = 1.0f / sqrtf(ss * (1.0f / 128.0f) + 1e-6f);
+    const u32x4 w = *(const u32x4*)ptr;
     const bf16_t* sc = (tok < split ? (which ? k_scale : q_scale) : (which ? k_scale2 : q_scale2)) + sub * 8;
     const u32x4 sw = *(const u32x4*)sc;
     float g[8];
 #pragma unroll
     for (int e = 0; e < 4; ++e) { g[2 * e] = lo_bf(sw[e]); g[2 * e + 1] = hi_bf(sw[e]); }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = rbf(rbf(x[e] * rrms) * g[e]);
     // RoPE on interleaved pairs; table [L][64][2] = (cos, sin)
     const float* rp = rope + (long)b * rope_bstride + (long)(ok ? tok : 0) * 128 + sub * 8;
     const f32x4 c0 = *(const f32x4*)rp;
     const f32x4 c1 = *(const f32x4*)(rp + 4);
     const float cs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
-    u32x4 o;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float co = cs[2 * e], si = cs[2 * e + 1];
-      const float o0 = co * x[2 * e] - si * x[2 * e + 1];
-      const float o1 = si * x[2 * e] + co * x[2 * e + 1];
-      o[e] = pack2bf(o0, o1);
-    }
+    const u32x4 o = qknorm_rope8(w, g, cs);
     if (ok) *(u32x4*)ptr = o;
   }
 
@@ -203,23 +183,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_rows_kernel(bf16_t* __restric
     for (int hh = 0; hh < HG; ++hh) w[hh] = (h0 + hh < H) ? *(const u32x4*)(base + hh * 128) : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
     for (int hh = 0; hh < HG; ++hh) {
-      float x[8];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { x[2 * e] = lo_bf(w[hh][e]); x[2 * e + 1] = hi_bf(w[hh][e]); }
-      float ss = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) ss += x[e] * x[e];
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) ss += __shfl_xor(ss, o, 64);
-      const float rrms = 1.0f / sqrtf(ss * (1.0f / 128.0f) + 1e-6f);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = rbf(rbf(x[e] * rrms) * g[e]);
-      u32x4 o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float co = cs[2 * e], si = cs[2 * e + 1];
-        o[e] = pack2bf(co * x[2 * e] - si * x[2 * e + 1], si * x[2 * e] + co * x[2 * e + 1]);
-      }
+      const u32x4 o = qknorm_rope8(w[hh], g, cs);
       if (h0 + hh < H) *(u32x4*)(base + hh * 128) = o;
     }
   }

@@ -70,6 +70,7 @@ class PreparedWeights:
     n_mod: int
     temb_freqs: torch.Tensor     # [128] f32
     ref: Optional[Dict[str, RefLinear]] = None    # lora_mode="ref": un-merged factors of every Linear (incl. the modulation ones)
+    qkv_heads: int = 0           # H > 0: every qkv weight / bias (linear1's first 3D rows) is HEAD-PERMUTED (hip.qkv_head_permutation)
 
 
 class Workspace:
@@ -130,6 +131,9 @@ class FluxEngine:
         self.attn_scratch = hip.attention_scratch(dev)
         self.fuse_qnorm = True     # variants 8 / 12: QKNorm + RoPE of the queries inside the attention kernel
         self.fuse_vt = weights.ref is None   # V^T written by the qkv GEMM's epilogue (EPI_QKV); the pre-pass is then K only
+        # QKNorm + RoPE of the key heads inside the qkv GEMM's epilogue (head-permuted weights, VcGemmProblem.kn_scale): with
+        # fuse_qnorm and fuse_vt no pre-pass kernel is left between the projection and the attention
+        self.fuse_knorm = weights.qkv_heads > 0
         self.tile_cfg = 0
         self.stream = torch.cuda.Stream(device=dev)   # capture needs a non-default stream
         self._ref_scratch: Dict[tuple, torch.Tensor] = {}
@@ -208,7 +212,7 @@ class FluxEngine:
         """hipGraph of ONE solver step (Flux evaluation + Euler update + device step-counter increment).
         Everything step-dependent (modulation rows, dt) is indexed on the device by ws.STEP, so the same
         graph replays for every step of every sample batch with this geometry."""
-        key = (ws.ragged, ws.gapped, self.attn_variant, self.tile_cfg, self.fuse_qnorm, self.fuse_vt)
+        key = (ws.ragged, ws.gapped, self.attn_variant, self.tile_cfg, self.fuse_qnorm, self.fuse_vt, self.fuse_knorm)
         if ws.graph is None or ws.graph_key != key:
             xs = ws.XS.clone()
             self.eval_once(ws, ws.STEP, euler=True, s=s)      # warm-up: sets func attributes outside capture
@@ -333,9 +337,10 @@ class FluxEngine:
         q1, k1, q2, k2 = scales
         variant = self.attention_variant(ws)
         fused_q = bool(variant & 8) and self.fuse_qnorm
-        parts = hip.QKN_K | (0 if fused_q else hip.QKN_Q) | (0 if self._vt_in_gemm() else hip.QKN_VT)
-        hip.qknorm_rope_vt(ws.QKV, q1, k1, ws.ROPE, ws.VT, ws.L, self.H, stream=s, q_scale2=q2, k_scale2=k2, split=split, B=ws.B,
-                           parts=parts)
+        parts = (0 if self._kn_in_gemm() else hip.QKN_K) | (0 if fused_q else hip.QKN_Q) | (0 if self._vt_in_gemm() else hip.QKN_VT)
+        if parts:
+            hip.qknorm_rope_vt(ws.QKV, q1, k1, ws.ROPE, ws.VT, ws.L, self.H, stream=s, q_scale2=q2, k_scale2=k2, split=split, B=ws.B,
+                               parts=parts)
         ev = getattr(self, "attn_events", None)     # bench.py: HIP events around the attention launch(es) IN SITU
         if ev is not None:
             e0 = hip.Event()
@@ -350,11 +355,23 @@ class FluxEngine:
     def _vt_in_gemm(self) -> bool:
         return self.fuse_vt and self.W.ref is None
 
-    def _qkv_epi(self, ws: Workspace, rows: int, row0: int):
-        """(epilogue, problem kwargs) of a qkv projection: with fuse_vt the V third goes straight to ws.VT, transposed"""
-        if not self._vt_in_gemm():
+    def _kn_in_gemm(self) -> bool:
+        return self.fuse_knorm and self.W.qkv_heads > 0 and self.W.ref is None
+
+    def _qkv_epi(self, ws: Workspace, rows: int, row0: int, k_scale=None):
+        """(epilogue, problem kwargs) of a qkv projection: with fuse_vt the V third goes straight to ws.VT, transposed; with
+        head-permuted weights C receives the logical columns and, with fuse_knorm, the key heads leave normalised + rotated"""
+        kw = {}
+        if self._vt_in_gemm():
+            kw.update(vt=ws.VT, vt_col0=2 * self.D)
+        if self.W.qkv_heads and self.W.ref is None:
+            kw.update(kn_heads=self.W.qkv_heads)
+            if self._kn_in_gemm():
+                kw.update(kn_scale=k_scale, kn_rope=ws.ROPE)
+        if not kw:
             return hip.EPI_BIAS, {}
-        return hip.EPI_QKV, dict(vt=ws.VT, vt_col0=2 * self.D, vt_rpb=rows, vt_row0=row0)
+        kw.update(vt_rpb=rows, vt_row0=row0)
+        return hip.EPI_QKV, kw
 
     def double_block(self, c, i: int) -> None:
         """DoubleStreamBlock i (layers.py:158-196) on ws.XI / ws.XT, in place."""
@@ -363,8 +380,8 @@ class FluxEngine:
         pf = f"double_blocks.{i}"
         im, tm = pf + ".img_mod.lin", pf + ".txt_mod.lin"
         self._ln2(c, im, tm, 0)
-        epi, kv_i = self._qkv_epi(ws, N, T)
-        _, kv_t = self._qkv_epi(ws, T, 0)
+        epi, kv_i = self._qkv_epi(ws, N, T, Wn[pf + ".img_attn.norm.key_norm.scale"])
+        _, kv_t = self._qkv_epi(ws, T, 0, Wn[pf + ".txt_attn.norm.key_norm.scale"])
         self._gemm([self._prob(pf + ".img_attn.qkv", c.XH_I, ws.QKV[T:], **c.qkv_i, **kv_i),
                     self._prob(pf + ".txt_attn.qkv", c.XH_T, ws.QKV[:T], **c.qkv_t, **kv_t)], epi=epi, s=s)
         self._attention(c, (Wn[pf + ".txt_attn.norm.query_norm.scale"], Wn[pf + ".txt_attn.norm.key_norm.scale"],
@@ -391,7 +408,7 @@ class FluxEngine:
         pf = f"single_blocks.{i}"
         mn = pf + ".modulation.lin"
         self._ln(c, ws.X, mn, 0, ws.XH, ws.L)
-        epi, kv = self._qkv_epi(ws, ws.L, 0)
+        epi, kv = self._qkv_epi(ws, ws.L, 0, Wn[pf + ".norm.key_norm.scale"])
         self._lin(pf + ".linear1.qkv", ws.XH, ws.QKV, epi=epi, s=s, **kv)
         self._lin(pf + ".linear1.mlp", ws.XH, ws.CAT[:, D:], epi=hip.EPI_GELU, s=s)
         self._attention(c, (Wn[pf + ".norm.query_norm.scale"], Wn[pf + ".norm.key_norm.scale"], None, None), 0)

@@ -73,9 +73,10 @@ class FluxHandle:
         except Exception:
             pass
 
-    def set_options(self, attn_variant=None, tile_cfg=0, fuse_qnorm=True, fuse_vt=True) -> None:
+    def set_options(self, attn_variant=None, tile_cfg=0, fuse_qnorm=True, fuse_vt=True, qkv_heads=0, fuse_knorm=False) -> None:
         want = dict(attn_variant=-1 if attn_variant is None else int(attn_variant), tile_cfg=int(tile_cfg),
-                    fuse_qnorm=int(bool(fuse_qnorm)), fuse_vt=int(bool(fuse_vt)))
+                    fuse_qnorm=int(bool(fuse_qnorm)), fuse_vt=int(bool(fuse_vt)), qkv_heads=int(qkv_heads),
+                    fuse_knorm=int(bool(fuse_knorm)))
         for k, v in want.items():
             if self._opts.get(k) != v:
                 hip._check(hip.lib().vc_flux_set_option(self.h, k.encode(), v), f"vc_flux_set_option({k})")

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VC_HIP_LIB") or os.path.join(_HERE, "lib", "libvcloze_hip.so")   # VC_HIP_LIB: profiling build
 CSRC = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 5                # VC_ABI_VERSION of include/vcloze_hip.h
+ABI_VERSION = 6                # VC_ABI_VERSION of include/vcloze_hip.h
 GEMM_MAX_PROBLEMS = 4          # VC_GEMM_MAX_PROBLEMS: grouped problems per vc_gemm launch
 EPI_BIAS, EPI_GELU, EPI_GATE_RES, EPI_SILU, EPI_QKV = 0, 1, 2, 3, 4
 GEMM_NO_SPLIT = 64             # VC_GEMM_NO_SPLIT: tile_cfg value that keeps an auto-tiled vc_gemm one launch
@@ -38,6 +38,7 @@ class GemmProblem(C.Structure):
         ("tiles_m", C.c_int32), ("tiles_n", C.c_int32), ("tile_start", C.c_int32), ("m_begin", C.c_int32),
         ("vt", C.c_void_p), ("vt_bstride", C.c_int64),
         ("vt_col0", C.c_int32), ("vt_rpb", C.c_int32), ("vt_row0", C.c_int32), ("vt_lpad", C.c_int32),
+        ("kn_scale", C.c_void_p), ("kn_rope", C.c_void_p), ("kn_rope_bstride", C.c_int64), ("kn_heads", C.c_int32), ("kn_pad_", C.c_int32),
     ]
 
 
@@ -217,8 +218,20 @@ def _bf16(t: torch.Tensor, name: str) -> None:
 # ------------------------------------------------------------------------------------------------
 # op wrappers (2-D row-major views; the last dim must be contiguous)
 # ------------------------------------------------------------------------------------------------
+def qkv_head_permutation(H: int) -> torch.Tensor:
+    """Row order of a HEAD-PERMUTED qkv weight [3 * 128 * H, K] (VcGemmProblem.kn_heads): H blocks of [key head h (128 rows) |
+    query rows 64 h .. 64 h + 63], then query rows 64 H .. 128 H - 1, then the V rows.  perm[p] = the original row."""
+    D = 128 * H
+    idx = []
+    for h in range(H):
+        idx += list(range(D + 128 * h, D + 128 * h + 128)) + list(range(64 * h, 64 * h + 64))
+    idx += list(range(64 * H, D)) + list(range(2 * D, 3 * D))
+    return torch.tensor(idx, dtype=torch.long)
+
+
 def make_problem(a, w, bias, out, res=None, gate=None, rows_per_batch=None, gate_bstride=0, M=None,
-                 a_rpb=0, a_bstride=0, c_rpb=0, c_bstride=0, vt=None, vt_col0=0, vt_rpb=0, vt_row0=0) -> GemmProblem:
+                 a_rpb=0, a_bstride=0, c_rpb=0, c_bstride=0, vt=None, vt_col0=0, vt_rpb=0, vt_row0=0,
+                 kn_heads=0, kn_scale=None, kn_rope=None) -> GemmProblem:
     """`M` + (a_rpb, a_bstride) / (c_rpb, c_bstride) describe batch-strided rows: `a` / `out` are then views of the
     FIRST batch element's rows (row m of the problem lives at (m // rpb) * bstride + (m % rpb) * ld).
     EPI_QKV: `vt` [B, H, 128, Lpad] receives the columns >= vt_col0 transposed; this problem's rows are tokens
@@ -254,7 +267,17 @@ def make_problem(a, w, bias, out, res=None, gate=None, rows_per_batch=None, gate
             raise VclozeHipError("gemm vt: contiguous [B, H, 128, Lpad] expected")
         p.vt, p.vt_bstride, p.vt_lpad = vt.data_ptr(), vt.stride(0), vt.shape[-1]
         p.vt_col0, p.vt_rpb, p.vt_row0 = vt_col0, vt_rpb or M, vt_row0
-    p._keep = (a, w, bias, out, res, gate, vt)   # the struct carries raw pointers: keep the operands alive with it
+    if kn_heads:
+        p.kn_heads = kn_heads        # w / bias are head-permuted (qkv_head_permutation); C receives the logical columns
+        if vt is None:
+            p.vt_rpb, p.vt_row0 = vt_rpb or M, vt_row0
+        if kn_scale is not None:     # ... and QKNorm + RoPE of the key heads happen in the epilogue
+            _bf16(kn_scale, "kn_scale")
+            if kn_rope is None or kn_rope.dtype != torch.float32 or not kn_rope.is_contiguous():
+                raise VclozeHipError("gemm kn_rope: contiguous f32 [B?, L, 64, 2] expected")
+            p.kn_scale, p.kn_rope = kn_scale.data_ptr(), kn_rope.data_ptr()
+            p.kn_rope_bstride = kn_rope.shape[-3] * 128 if kn_rope.dim() == 4 else 0
+    p._keep = (a, w, bias, out, res, gate, vt, kn_scale, kn_rope)   # the struct carries raw pointers: keep the operands alive with it
     return p
 
 

@@ -263,6 +263,9 @@ class Flux(nn.Module):
         # reference does - base GEMM, two skinny GEMMs, three bf16 roundings (models/modules/lora.py:92-98) - so that
         # the merge's one-rounding deviation is a choice, not a necessity; slower (+8 % FLOPs, unfused epilogues).
         self.lora_mode = "merged"
+        # the prepared qkv weights (merged mode) are stored HEAD-PERMUTED - every key head inside one 192-column GEMM tile -
+        # so that QKNorm + RoPE of k can ride the projection's epilogue (hip.qkv_head_permutation, VcGemmProblem.kn_heads)
+        self.qkv_permute = True
 
     # ------------------------------------------------------------------ weights -> engine
     def _linears(self):
@@ -272,7 +275,7 @@ class Flux(nn.Module):
 
     def _weights_fingerprint(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters()) + tuple(
-            m.scale for _, m in self._linears()) + (self.lora_mode,)
+            m.scale for _, m in self._linears()) + (self.lora_mode, self.qkv_permute)
 
     @staticmethod
     @torch.no_grad()
@@ -364,6 +367,16 @@ class Flux(nn.Module):
                 if b[n] is not None:
                     mod_b[off[n]:off[n] + w[n].shape[0]] = b[n]
         D = self.hidden_size
+        qkv_heads = 0
+        if ref is None and self.qkv_permute:
+            qkv_heads = self.num_heads
+            perm = hip.qkv_head_permutation(qkv_heads).to(dev)
+            names = [f"double_blocks.{i}.{st}_attn.qkv" for i in range(self.params.depth) for st in ("img", "txt")]
+            names += [f"single_blocks.{i}.linear1" for i in range(self.params.depth_single_blocks)]
+            for n in names:          # in place, one matrix at a time (a 57 MB temporary): linear1's rows [0, 3D) only
+                w[n][:3 * D] = w[n][:3 * D][perm]
+                if b[n] is not None:
+                    b[n][:3 * D] = b[n][:3 * D][perm]
         for i in range(self.params.depth_single_blocks):
             n = f"single_blocks.{i}.linear1"
             w[n + ".qkv"], w[n + ".mlp"] = w[n][: 3 * D], w[n][3 * D:]
@@ -379,7 +392,7 @@ class Flux(nn.Module):
             b.pop(n, None)
         half = 128
         freqs = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half).to(dev)
-        pw = PreparedWeights(w=w, b=b, mod_w=mod_w, mod_b=mod_b, mod_off=off, n_mod=o, temb_freqs=freqs, ref=ref)
+        pw = PreparedWeights(w=w, b=b, mod_w=mod_w, mod_b=mod_b, mod_off=off, n_mod=o, temb_freqs=freqs, ref=ref, qkv_heads=qkv_heads)
         self._engine = FluxEngine(self.params, pw, dev)
         self._handle = None
         if free_parameters:
@@ -417,7 +430,7 @@ class Flux(nn.Module):
         if self._handle is None or self._handle.W is not eng.W:
             from .handle import FluxHandle
             self._handle = FluxHandle(self.params, eng.W, eng.dev)
-        self._handle.set_options(eng.attn_variant, eng.tile_cfg, eng.fuse_qnorm, eng.fuse_vt)
+        self._handle.set_options(eng.attn_variant, eng.tile_cfg, eng.fuse_qnorm, eng.fuse_vt, eng.W.qkv_heads, eng.fuse_knorm)
         return self._handle
 
     # ------------------------------------------------------------------ the B1 boundary

@@ -173,6 +173,12 @@ typedef struct VcAttention {
   void* scratch; int64_t scratch_bytes;
   const void* q_scale; const void* q_scale2; const float* rope; int64_t rope_bstride;
   const int32_t* kv_gap;
+  /* > 0 (variants 8 / 12): the caller guarantees |q.k| * 128^-0.5 * log2(e) <= logit_bound for every query / key pair - with
+   * QK-normed operands (layers.py:75-84) |q|, |k| <= sqrt(128) * max|scale|, i.e. logit_bound = 16.33 * max|query_norm.scale|
+   * * max|key_norm.scale| is a property of the model's weights.  For logit_bound <= 100 the kernel then runs its softmax
+   * with a fixed reference point 0 (no running max: same function, 4 of 68 MFMAs and the row-max VALU work per tile
+   * saved); 0 = unknown: online softmax with running max. */
+  float logit_bound; int32_t pad_;
 } VcAttention;
 int vc_attention(const VcAttention* a, void* stream);
 int64_t vc_attention_scratch_bytes(void);
@@ -300,7 +306,9 @@ int64_t vc_flux_mod_offset(void* handle, const char* module_name);
  * "qkv_heads" (0; = num_heads when the caller bound HEAD-PERMUTED qkv weights - every `*_attn.qkv` and the first
  * 3 * hidden rows of every `linear1`, with their biases, in the row order VcGemmProblem.kn_heads describes) and, with it,
  * "fuse_knorm" (0; 1: QKNorm + RoPE of the key heads inside the qkv GEMM's epilogue - with fuse_qnorm and fuse_vt the
- * projection, the norms, RoPE and the V transpose are then ONE GEMM launch + the attention kernel: no pre-pass). */
+ * projection, the norms, RoPE and the V transpose are then ONE GEMM launch + the attention kernel: no pre-pass);
+ * "logit_bound_milli" (0; 1000 * VcAttention.logit_bound for every attention call of the model, from the bound QK-norm
+ * scales: 16330 * max|query_norm.scale| * max|key_norm.scale| over all blocks, rounded up). */
 int vc_flux_set_option(void* handle, const char* name, int32_t value);
 int64_t vc_flux_workspace_bytes(void* handle, int32_t B, int32_t T, int32_t N, int32_t max_steps);
 

@@ -177,6 +177,27 @@ def test_forward_sample_without_text_vs_reference(golden, variant):
     assert err < TOL_ORACLE and err_ref < TOL_GOLDEN
 
 
+def test_bounded_softmax_is_a_property_of_the_norm_scales(model, golden):
+    """model.prepare derives the logit bound of every attention call from the QK-norm scales (16.33 max|q scale| max|k scale|);
+    the attention kernel then needs no running max.  Same result as the running-max path within bf16 noise, same distance
+    from the reference's own fp32 run."""
+    from tests.procedural import tiny_inputs
+    m, sd = model
+    eng = m.engine()
+    assert 16.0 < eng.W.logit_bound < 30.0
+    inp = tiny_inputs(B=1)
+    t = torch.tensor([0.7])
+    try:
+        eng.attn_variant = 12
+        a = _fwd(m, inp, t).float().cpu()
+        eng.bounded_softmax = False
+        b = _fwd(m, inp, t).float().cpu()
+    finally:
+        eng.bounded_softmax, eng.attn_variant = True, None
+    assert rel_l2(a, b) < 5e-3
+    assert rel_l2(a, golden["flux_b1"]) < TOL_GOLDEN and rel_l2(b, golden["flux_b1"]) < TOL_GOLDEN
+
+
 def test_sampler_general_masks_vs_oracle():
     """The fused sampler keeps the state in kernel row order across the steps and scatters back at the end: against the
     oracle's bf16 sampler on masks with holes in both streams, and against host-driven stepping through Flux.forward."""

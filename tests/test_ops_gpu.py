@@ -464,6 +464,48 @@ def test_attention_leading_keys_masked(hip, variant, L, lo, hi, kv):
     assert float(out[~live].float().abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize("variant", [8, 12])
+@pytest.mark.parametrize("L,H,kv,gap", [(64, 2, None, None), (200, 3, None, None), (333, 2, 301, None), (320, 2, 300, (0, 128)),
+                                        (512, 2, 470, (100, 230)), (1664, 4, None, None), (3968, 24, None, None), (4000, 3, None, None)])
+def test_attention_bounded_logits_needs_no_running_max(hip, variant, L, H, kv, gap):
+    """VcAttention.logit_bound: when the caller bounds |q.k| 128^-0.5 log2(e) (QK-normed operands: a property of the norm
+    scales) the one-wave-per-SIMD kernel keeps the softmax's reference point at 0 - no row max, no rescale, no (-m) k-step.
+    Same function: against the f32 torch softmax and against the running-max path, with key padding, a masked gap (one that
+    starts at key 0 too), the tail split, and L off the 64-key tile."""
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(L, 3, H, 128, generator=g)
+    x[:, :2] = x[:, :2] / x[:, :2].pow(2).mean(-1, keepdim=True).sqrt()          # |q| = |k| = sqrt(128), as after QKNorm
+    qkv = x.reshape(L, 3 * H * 128).to(torch.bfloat16).to(DEV)
+    x = qkv.float().reshape(L, 3, H, 128)
+    vt = torch.zeros(1, H, 128, (L + 63) // 64 * 64, dtype=torch.bfloat16, device=DEV)
+    vt[0, :, :, :L] = x[:, 2].permute(1, 2, 0).to(torch.bfloat16)
+    s = torch.einsum("qhd,khd->hqk", x[:, 0], x[:, 1]) * 128 ** -0.5
+    bound = float(s.abs().max()) * 1.4426950408889634 * 1.01
+    assert bound < 17.0
+    live = torch.ones(L, dtype=torch.bool, device=DEV)
+    kvl = gp = None
+    if kv is not None:
+        live[kv:] = False
+        kvl = torch.tensor([kv], dtype=torch.int32, device=DEV)
+    if gap is not None:
+        live[gap[0]:gap[1]] = False
+        gp = torch.tensor([list(gap)], dtype=torch.int32, device=DEV)
+    outs = []
+    for lb in (bound, 0.0, 1e4):           # bounded; running max; a bound too large to trust f32 with -> running max again
+        o = torch.full((L, H * 128), float("nan"), dtype=torch.bfloat16, device=DEV)
+        hip.attention(qkv, vt, o, L, H, kv_len=kvl, variant=variant, kv_gap=gp, logit_bound=lb)
+        outs.append(o)
+    torch.cuda.synchronize()
+    s[:, :, ~live] = float("-inf")
+    ref = torch.einsum("hqk,khd->qhd", torch.softmax(s, -1), x[:, 2]).reshape(L, H * 128)
+    ref[~live] = 0
+    check(outs[0], R.rb(ref), tol=1e-2)
+    check(outs[1], R.rb(ref), tol=1e-2)
+    assert torch.equal(outs[1], outs[2])
+    assert float(outs[0][~live].float().abs().sum()) == 0.0
+    assert ((outs[0].float() - outs[1].float()).norm() / outs[1].float().norm()).item() < 4e-3
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 7, 8, 12])
 def test_attention_softmax_rescale_branch(hip, variant):
     """Force the online-softmax running max to jump late (a spiked key in the LAST tile) and early."""

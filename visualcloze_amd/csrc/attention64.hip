@@ -61,6 +61,12 @@ struct Attn64Args {
   const bf16_t* q_scale; const bf16_t* q_scale2; const float* rope; int64_t rope_bstride; int32_t split;
   uint64_t* debug_ts;   // profiling builds only (-DVC_ATTN_TIMESTAMPS): per workgroup (start, end, tiles)
 };
+// BOUNDED (VcAttention.logit_bound): the caller guarantees |c q.k| <= bound (log2 domain) for every query / key pair - with
+// QK-normed operands |q|, |k| <= sqrt(128) max|scale|, so the bound is a property of the model's norm scales.  A softmax
+// needs its running max only to keep 2^x in range; with bounded logits the reference point stays 0 for the whole row:
+// no row max, no rescale decision, no (-m) k-step (4 of 68 MFMAs per tile) - P = 2^(c q.k) directly, l and O accumulate
+// in f32 (|x| <= 100: 2^100 * L fits), the result O / l is the same function.  Masked keys still take the extra k-step,
+// in the tiles that hold any.
 
 constexpr int KVB = 64;
 constexpr int K_TILE = KVB * 256, V_TILE = 128 * KVB * 2;
@@ -183,6 +189,7 @@ VC_DEV float xsum32(float x) {
   return lo + hi;
 }
 
+template <bool BOUNDED>
 __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // the whole accumulator file belongs to the asm statements of this kernel
@@ -426,13 +433,15 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
       }
     };
     // one S chain: 8 k-steps over the head dimension + the (-m, mask) step
-    auto qk_step = [&](f32x16& Sx, auto Cc, auto Tc, const u32x4& kaug) {
+    auto qk_step = [&](f32x16& Sx, auto Cc, auto Tc, const u32x4& kaug, bool masked_tile) {
       constexpr int c = decltype(Cc)::value, qb = c >> 1, u = c & 1, t = decltype(Tc)::value;
       if constexpr (t < 8) mfma_qk<A_K + (u * 8 + t) * 4, A_Q + (qb * 8 + t) * 4, t == 0>(Sx);
 #ifndef VC_A64_NO_AUG       // analysis builds only (wrong results)
-      else mfma_aug(Sx, kaug, qaug[qb]);
+      else if (!BOUNDED || masked_tile) mfma_aug(Sx, kaug, qaug[qb]);     // BOUNDED: m = 0 for ever, only masks need the step
 #endif
     };
+    // does KV tile n hold a masked key (wave-uniform)?
+    auto tile_masked = [&](int n) { return n * KVB + KVB > kvlen || (n * KVB < gap_hi && n * KVB + KVB > gap_lo); };
 
     // ---- first tile, not overlapped: S(kt0) = K(kt0) . Q^T (m = 0), its row max, K(kt0+1) fragments ----
     sfor<0, 16>([&](auto UT) { read_k(I0{}, UT); });
@@ -443,20 +452,23 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
     SB();
     {
       u32x4 ka[2] = {make_kaug(kt0, 0), make_kaug(kt0, 1)};
+      const bool msk0 = tile_masked(kt0);
       sfor<0, 36>([&](auto Gp) {
         constexpr int g = decltype(Gp)::value, c = g / 9, t = g % 9;
-        qk_step(SBk[c], std::integral_constant<int, c>{}, std::integral_constant<int, t>{}, ka[c & 1]);
+        qk_step(SBk[c], std::integral_constant<int, c>{}, std::integral_constant<int, t>{}, ka[c & 1], msk0);
       });
     }
     SB();
     sfor<0, 16>([&](auto UT) { read_k(I1{}, UT); });
     asm volatile("s_nop 15" ::: "memory");                          // S(kt0) complete before the VALU reads it
     SB();
-    sfor<0, 4>([&](auto Cc) { sfor<0, 8>([&](auto Jc) { max_step(SBk[decltype(Cc)::value], Cc, Jc); }); });
-    decide0();
-    decide1(I0{});
-    decide1(I1{});
-    decide2(I0{}, true);
+    if constexpr (!BOUNDED) {
+      sfor<0, 4>([&](auto Cc) { sfor<0, 8>([&](auto Jc) { max_step(SBk[decltype(Cc)::value], Cc, Jc); }); });
+      decide0();
+      decide1(I0{});
+      decide1(I1{});
+      decide2(I0{}, true);
+    }
     resc = false;                                                   // O = 0, l = 0: nothing to rescale on the first tile
     wait_lgkm<0>();
     __builtin_amdgcn_s_barrier();      // every wave holds its K(kt0+1) fragments before tile kt0 sends K(kt0+4) into that slot
@@ -471,15 +483,16 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
       using SLOT_V = std::integral_constant<int, J>;                 // V^T(kt)
       using SLOT_K2 = std::integral_constant<int, (J + 2) % 3>;      // K(kt+2) fragments / V^T(kt+2) DMA
       using SLOT_K4 = std::integral_constant<int, (J + 1) % 3>;      // K(kt+4) DMA
-      rescale_o();
+      if constexpr (!BOUNDED) rescale_o();
       u32x4 ka[2] = {make_kaug(kt + 1, 0), make_kaug(kt + 1, 1)};
+      const bool msk1 = BOUNDED && tile_masked(min(kt + 1, kt1 - 1));
       SB();
       // ---------------- phase A: S(kt+1) = K(kt+1) . Q^T - m  ||  P(kt), l  ||  V^T(kt) fragments 0..7 ----------------
       float pe0 = 0.f, pe1 = 0.f;
       sfor<0, 36>([&](auto Gp) {
         constexpr int g = decltype(Gp)::value, c = g / 9, t = g % 9;
 #ifndef VC_A64_NO_MFMA
-        qk_step(SBk[(BASE + 4 + c) % 6], std::integral_constant<int, c>{}, std::integral_constant<int, t>{}, ka[c & 1]);
+        qk_step(SBk[(BASE + 4 + c) % 6], std::integral_constant<int, c>{}, std::integral_constant<int, t>{}, ka[c & 1], msk1);
 #else
         if constexpr (t == 0) asm volatile("" : "=v"(SBk[(BASE + 4 + c) % 6]));
 #endif
@@ -518,14 +531,16 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
 #endif
 #ifndef VC_A64_NO_SOFTMAX
         // S(kt+1) was completed by the last MFMAs of phase A: its first VALU read comes two MFMA gaps later
-        if constexpr (g >= 2 && g <= 9)
-          sfor<0, 4>([&](auto Cc) { max_step(SBk[(BASE + 4 + decltype(Cc)::value) % 6], Cc, std::integral_constant<int, g - 2>{}); });
-        if constexpr (g == 10) decide0();
-        if constexpr (g == 11) decide1(I0{});
-        if constexpr (g == 12) decide1(I1{});
+        if constexpr (!BOUNDED) {
+          if constexpr (g >= 2 && g <= 9)
+            sfor<0, 4>([&](auto Cc) { max_step(SBk[(BASE + 4 + decltype(Cc)::value) % 6], Cc, std::integral_constant<int, g - 2>{}); });
+          if constexpr (g == 10) decide0();
+          if constexpr (g == 11) decide1(I0{});
+          if constexpr (g == 12) decide1(I1{});
 #ifndef VC_A64_NO_AUG
-        if constexpr (g == 13) decide2(std::integral_constant<int, (BASE + 4) % 6>{}, false);
+          if constexpr (g == 13) decide2(std::integral_constant<int, (BASE + 4) % 6>{}, false);
 #endif
+        }
 #endif
 #ifndef VC_A64_NO_LDS
         if constexpr ((g & 1) && g < 16) {          // V^T fragment (dt + 2, s) into the register (dt, s) just retired
@@ -686,10 +701,15 @@ int vc_attention64_launch(const VcAttention& A, bool tail_split, int n_cu, uint6
   static VcOncePerDevice done;
   hipError_t e;
   if (done.need()) {
-    e = hipFuncSetAttribute((const void*)attn64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
+    e = hipFuncSetAttribute((const void*)attn64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
     if (e != hipSuccess) { snprintf(err, errlen, "attention64 attribute: %s", hipGetErrorString(e)); return VC_ERR_HIP; }
     done.mark();
   }
+  // logits bounded by the caller (|x| <= logit_bound in the log2 domain): 2^x, a row's sum over L keys and O stay far inside
+  // f32 for bound <= 100, so the softmax needs no running max (kernel header)
+  const bool bounded = A.logit_bound > 0.0f && A.logit_bound <= 100.0f;
+  void (*kern)(const Attn64Args) = bounded ? attn64_kernel<true> : attn64_kernel<false>;
   const int G = n_cu;
   const int nkt = (L + KVB - 1) / KVB;
   // the tail split is scheduled per XCD (Sched64): cut where some XCD has tail items and cutting shortens its critical
@@ -704,10 +724,10 @@ int vc_attention64_launch(const VcAttention& A, bool tail_split, int n_cu, uint6
     }
   if (tail_split && !kv_len && any_tail && scratch && scratch_bytes >= vc_attention64_scratch_bytes_impl(n_cu) && worst_split + 4 < nkt) {
     a.full_rounds = a.items / G; a.tail_items = a.items - a.full_rounds * G; a.tail_units = a.tail_items * nkt;
-    hipLaunchKernelGGL(attn64_kernel, dim3(G), dim3(256), LDS64, s, a);
+    hipLaunchKernelGGL(kern, dim3(G), dim3(256), LDS64, s, a);
     hipLaunchKernelGGL(attn64_merge_kernel, dim3(2 * G), dim3(256), 0, s, a, G);
   } else {
-    hipLaunchKernelGGL(attn64_kernel, dim3(std::min(a.items, G)), dim3(256), LDS64, s, a);
+    hipLaunchKernelGGL(kern, dim3(std::min(a.items, G)), dim3(256), LDS64, s, a);
   }
   e = hipGetLastError();
   if (e == hipSuccess) return VC_OK;

@@ -56,7 +56,7 @@ struct Flux : Buffers {
   std::vector<SingleW> sgl;
   int64_t final_mod = 0;
   // options
-  int attn_variant = -1, tile_cfg = 0, fuse_qnorm = 1, fuse_vt = 1, qkv_heads = 0, fuse_knorm = 0, n_cu = 256;
+  int attn_variant = -1, tile_cfg = 0, fuse_qnorm = 1, fuse_vt = 1, qkv_heads = 0, fuse_knorm = 0, logit_bound_milli = 0, n_cu = 256;
   // prepared geometry + workspace carve-up
   bool prepared = false;
   int B = 0, T = 0, N = 0, L = 0, Lp = 0, S = 0;
@@ -65,11 +65,11 @@ struct Flux : Buffers {
   // captured steps, most recently used first (a two-stage pipeline alternates between two geometries)
   hipGraphExec_t graph = nullptr;      // = graphs.front().second while a sample is in flight
   struct Key {
-    char* base; int B, T, N, S, ragged, gapped, variant, tile, fuse, fuse_vt, state_f32, qkv_heads, fuse_knorm; hipStream_t s;
+    char* base; int B, T, N, S, ragged, gapped, variant, tile, fuse, fuse_vt, state_f32, qkv_heads, fuse_knorm, bound; hipStream_t s;
     bool operator==(const Key& o) const {
       return base == o.base && B == o.B && T == o.T && N == o.N && S == o.S && ragged == o.ragged && gapped == o.gapped &&
              variant == o.variant && tile == o.tile && fuse == o.fuse && fuse_vt == o.fuse_vt && state_f32 == o.state_f32 &&
-             qkv_heads == o.qkv_heads && fuse_knorm == o.fuse_knorm && s == o.s;
+             qkv_heads == o.qkv_heads && fuse_knorm == o.fuse_knorm && bound == o.bound && s == o.s;
     }
   } key{};
   std::vector<std::pair<Key, hipGraphExec_t>> graphs;
@@ -291,6 +291,7 @@ int attention(Flux& f, const Ctx& c, const void* q1, const void* k1, const void*
   a.B = f.B; a.L = f.L; a.Lpad = f.Lp; a.H = f.H; a.variant = variant;
   a.scratch = f.ATT_SCRATCH; a.scratch_bytes = f.att_scratch_bytes;
   if (fused_q) { a.q_scale = q1; a.q_scale2 = q2; a.split = split; a.rope = f.ROPE; a.rope_bstride = (int64_t)f.L * 128; }
+  a.logit_bound = (float)f.logit_bound_milli * 1e-3f;
   return vc_attention_launch(a, c.s, e.buf, e.len);
 }
 
@@ -444,7 +445,7 @@ void drop_graph(Flux& f) {
 // the hipGraph of ONE solver step: everything step-dependent (modulation rows, dt) is indexed on the device by STEP
 int step_graph(Flux& f, hipStream_t s, Err e) {
   Flux::Key k{f.base, f.B, f.T, f.N, f.S, f.ragged, f.gapped, attention_variant(f), f.tile_cfg, f.fuse_qnorm, f.fuse_vt, f.state_f32,
-              f.qkv_heads, f.fuse_knorm, s};
+              f.qkv_heads, f.fuse_knorm, f.logit_bound_milli, s};
   for (size_t i = 0; i < f.graphs.size(); ++i)
     if (f.graphs[i].first == k) {
       auto hit = f.graphs[i];
@@ -546,6 +547,7 @@ int vc_flux_set_option_impl(void* handle, const char* name, int32_t value, char*
     if (value != 0 && value != f.H) FAIL(VC_ERR_ARG, "flux_set_option: qkv_heads must be 0 or num_heads = %d", f.H);
     f.qkv_heads = value;
   } else if (!strcmp(name, "fuse_knorm")) f.fuse_knorm = value != 0;
+  else if (!strcmp(name, "logit_bound_milli")) f.logit_bound_milli = value > 0 ? value : 0;
   else FAIL(VC_ERR_ARG, "flux_set_option: unknown option '%s'", name);
   return VC_OK;
 }

@@ -71,6 +71,7 @@ class PreparedWeights:
     temb_freqs: torch.Tensor     # [128] f32
     ref: Optional[Dict[str, RefLinear]] = None    # lora_mode="ref": un-merged factors of every Linear (incl. the modulation ones)
     qkv_heads: int = 0           # H > 0: every qkv weight / bias (linear1's first 3D rows) is HEAD-PERMUTED (hip.qkv_head_permutation)
+    logit_bound: float = 0.0     # 16.33 * max|query_norm.scale| * max|key_norm.scale| over all blocks: |q.k| 128^-0.5 log2(e) <= this
 
 
 class Workspace:
@@ -134,6 +135,8 @@ class FluxEngine:
         # QKNorm + RoPE of the key heads inside the qkv GEMM's epilogue (head-permuted weights, VcGemmProblem.kn_scale): with
         # fuse_qnorm and fuse_vt no pre-pass kernel is left between the projection and the attention
         self.fuse_knorm = weights.qkv_heads > 0
+        # the attention kernel may drop its running max when the model's QK-norm scales bound the logits (VcAttention.logit_bound)
+        self.bounded_softmax = True
         self.tile_cfg = 0
         self.stream = torch.cuda.Stream(device=dev)   # capture needs a non-default stream
         self._ref_scratch: Dict[tuple, torch.Tensor] = {}
@@ -212,7 +215,7 @@ class FluxEngine:
         """hipGraph of ONE solver step (Flux evaluation + Euler update + device step-counter increment).
         Everything step-dependent (modulation rows, dt) is indexed on the device by ws.STEP, so the same
         graph replays for every step of every sample batch with this geometry."""
-        key = (ws.ragged, ws.gapped, self.attn_variant, self.tile_cfg, self.fuse_qnorm, self.fuse_vt, self.fuse_knorm)
+        key = (ws.ragged, ws.gapped, self.attn_variant, self.tile_cfg, self.fuse_qnorm, self.fuse_vt, self.fuse_knorm, self.bounded_softmax)
         if ws.graph is None or ws.graph_key != key:
             xs = ws.XS.clone()
             self.eval_once(ws, ws.STEP, euler=True, s=s)      # warm-up: sets func attributes outside capture
@@ -346,7 +349,8 @@ class FluxEngine:
             e0 = hip.Event()
             e0.record(s)
         hip.attention(ws.QKV, ws.VT, c.ATT, ws.L, self.H, kv_len=c.kvl, variant=variant, stream=s, B=ws.B,
-                      scratch=self.attn_scratch, q_norm=(q1, q2, split, ws.ROPE) if fused_q else None, kv_gap=c.kvgap)
+                      scratch=self.attn_scratch, q_norm=(q1, q2, split, ws.ROPE) if fused_q else None, kv_gap=c.kvgap,
+                      logit_bound=self.W.logit_bound if self.bounded_softmax else 0.0)
         if ev is not None:
             e1 = hip.Event()
             e1.record(s)

@@ -62,7 +62,7 @@ class Attention(C.Structure):
                 ("B", C.c_int32), ("L", C.c_int32), ("Lpad", C.c_int32), ("H", C.c_int32), ("variant", C.c_int32), ("split", C.c_int32),
                 ("scratch", C.c_void_p), ("scratch_bytes", C.c_int64),
                 ("q_scale", C.c_void_p), ("q_scale2", C.c_void_p), ("rope", C.c_void_p), ("rope_bstride", C.c_int64),
-                ("kv_gap", C.c_void_p)]
+                ("kv_gap", C.c_void_p), ("logit_bound", C.c_float), ("pad_", C.c_int32)]
 
 
 class FluxConfig(C.Structure):
@@ -360,7 +360,8 @@ def attention_scratch(device) -> torch.Tensor:
     return _attn_scratch[key]
 
 
-def attention(qkv, vt, out, L, H, kv_len=None, variant=0, stream=None, B=1, scratch=None, q_norm=None, kv_gap=None):
+def attention(qkv, vt, out, L, H, kv_len=None, variant=0, stream=None, B=1, scratch=None, q_norm=None, kv_gap=None,
+              logit_bound=0.0):
     """out: [B*L, >=H*128] rows (B L (H D)), sample-major like qkv; kv_len: optional int32 device tensor [B];
     scratch: uint8 device buffer of >= vc_attention_scratch_bytes() for the tail split (taken from attention_scratch()
     when omitted); q_norm = (q_scale, q_scale2 | None, split, rope): QKNorm + RoPE of the RAW query rows inside the kernel
@@ -375,6 +376,7 @@ def attention(qkv, vt, out, L, H, kv_len=None, variant=0, stream=None, B=1, scra
     a.kv_gap = _p(kv_gap)      # int32 [B, 2] device tensor: (lo, hi) of a second masked range (needs kv_len)
     a.B, a.L, a.Lpad, a.H, a.variant = B, L, vt.shape[-1], H, variant
     a.scratch, a.scratch_bytes = _p(scratch), scratch.numel() if scratch is not None else 0
+    a.logit_bound = float(logit_bound)   # > 0: |q.k| * 128^-0.5 * log2(e) <= logit_bound guaranteed (variants 8 / 12: no running max)
     if q_norm is not None:
         qs, qs2, split, rope = q_norm
         _bf16(qs, "q_scale")

@@ -392,7 +392,13 @@ class Flux(nn.Module):
             b.pop(n, None)
         half = 128
         freqs = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half).to(dev)
-        pw = PreparedWeights(w=w, b=b, mod_w=mod_w, mod_b=mod_b, mod_off=off, n_mod=o, temb_freqs=freqs, ref=ref, qkv_heads=qkv_heads)
+        # |q|, |k| <= sqrt(128) * max|scale| after QKNorm (layers.py:75-84; RoPE is a rotation), so with c = 128^-0.5 * log2(e)
+        # every attention logit obeys |c q.k| <= 128 c max|q scale| max|k scale| (+1 % for the bf16 roundings on the way)
+        qmax = max(float(t.float().abs().max()) for n, t in w.items() if n.endswith("query_norm.scale"))
+        kmax = max(float(t.float().abs().max()) for n, t in w.items() if n.endswith("key_norm.scale"))
+        logit_bound = 1.01 * 128 ** 0.5 * 1.4426950408889634 * qmax * kmax
+        pw = PreparedWeights(w=w, b=b, mod_w=mod_w, mod_b=mod_b, mod_off=off, n_mod=o, temb_freqs=freqs, ref=ref, qkv_heads=qkv_heads,
+                             logit_bound=logit_bound)
         self._engine = FluxEngine(self.params, pw, dev)
         self._handle = None
         if free_parameters:
@@ -430,7 +436,8 @@ class Flux(nn.Module):
         if self._handle is None or self._handle.W is not eng.W:
             from .handle import FluxHandle
             self._handle = FluxHandle(self.params, eng.W, eng.dev)
-        self._handle.set_options(eng.attn_variant, eng.tile_cfg, eng.fuse_qnorm, eng.fuse_vt, eng.W.qkv_heads, eng.fuse_knorm)
+        self._handle.set_options(eng.attn_variant, eng.tile_cfg, eng.fuse_qnorm, eng.fuse_vt, eng.W.qkv_heads, eng.fuse_knorm,
+                                 eng.W.logit_bound if eng.bounded_softmax else 0.0)
         return self._handle
 
     # ------------------------------------------------------------------ the B1 boundary

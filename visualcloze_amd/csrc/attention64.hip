@@ -363,6 +363,19 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) asm volatile("" : "=v"(P[i >> 2][i & 3]));
 #endif
+    // BOUNDED: the first EARLY pairs of a tile's probabilities (block 0 of S, query block 0, keys 0..2*EARLY-1 of the lane)
+    // are exponentiated one phase early - in phase B of the PREVIOUS tile, in the MFMA gaps the row max used to fill - and
+    // wait in pn / l_early until phase A of their own tile opens (P(kt) itself is still feeding the P.V MFMAs then)
+#ifndef VC_A64_EARLY
+#define VC_A64_EARLY 6        /* A/B builds: 1 .. 8 (6 and 8 measure alike: +0.5 % steps/s over the same kernel without it) */
+#endif
+    constexpr int EARLY = BOUNDED ? VC_A64_EARLY : 0;
+    static_assert(!BOUNDED || (EARLY >= 1 && EARLY <= 8), "phase A has 32 gaps for (32 - EARLY) pairs + the pack of the last one");
+    uint32_t pn[8];
+    float l_early;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("" : "=v"(pn[i]));      // (VGPRs from the start; written before they are read)
+    asm volatile("" : "=v"(l_early));
     u32x4 vf[8];                       // V^T fragment ring
     float m_run[2] = {0.f, 0.f};       // running row max (log2 domain), always bf16-representable: -m_run sits in q_aug
     float l_acc[2] = {0.f, 0.f}, alpha[2] = {1.f, 1.f};
@@ -470,6 +483,15 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
       decide2(I0{}, true);
     }
     resc = false;                                                   // O = 0, l = 0: nothing to rescale on the first tile
+    if constexpr (BOUNDED) {                                        // the early pairs of the item's first tile (no phase B before it)
+      sfor<0, EARLY>([&](auto Kc) {
+        constexpr int k = decltype(Kc)::value;
+        const float e0 = __builtin_amdgcn_exp2f(SBk[0][2 * k]), e1 = __builtin_amdgcn_exp2f(SBk[0][2 * k + 1]);
+        if constexpr (k == 0) l_early = e0; else l_early += e0;
+        l_early += e1;
+        pn[k] = v_cvt_pk(e0, e1);
+      });
+    }
     wait_lgkm<0>();
     __builtin_amdgcn_s_barrier();      // every wave holds its K(kt0+1) fragments before tile kt0 sends K(kt0+4) into that slot
     SB();
@@ -489,32 +511,45 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
       SB();
       // ---------------- phase A: S(kt+1) = K(kt+1) . Q^T - m  ||  P(kt), l  ||  V^T(kt) fragments 0..7 ----------------
       float pe0 = 0.f, pe1 = 0.f;
+      if constexpr (BOUNDED) {           // the pairs exponentiated one phase early join P(kt) and l
+        sfor<0, EARLY>([&](auto Kc) { constexpr int k = decltype(Kc)::value; P[0][k >> 2][k & 3] = pn[k]; });
+        l_acc[0] += l_early;
+      }
       sfor<0, 36>([&](auto Gp) {
         constexpr int g = decltype(Gp)::value, c = g / 9, t = g % 9;
+        // filler position: the running-max kernel fills all 36 MFMA gaps (pair g at gap g, V^T fragments in the four thin
+        // gaps behind the (-m) steps); BOUNDED has 32 gaps h = 8c + t (the (-m) gaps exist in masked tiles only and stay
+        // empty), pairs EARLY.. at h = 0.., one V^T fragment in each of the last eight
+        constexpr int h = BOUNDED ? (t < 8 ? c * 8 + t : -1) : g;
+        constexpr int NP = 32 - EARLY;    // pairs done in this phase
 #ifndef VC_A64_NO_MFMA
         qk_step(SBk[(BASE + 4 + c) % 6], std::integral_constant<int, c>{}, std::integral_constant<int, t>{}, ka[c & 1], msk1);
 #else
         if constexpr (t == 0) asm volatile("" : "=v"(SBk[(BASE + 4 + c) % 6]));
 #endif
 #ifndef VC_A64_NO_SOFTMAX
-        if constexpr (g > 0 && g <= 32) {   // pair g-1: row sum and bf16 pack of the two probabilities exponentiated one gap earlier
-          constexpr int k = g - 1, pq = k >> 4, idx = k & 15, pu = idx >> 3, r0 = (idx & 7) * 2;
+        if constexpr (h > 0 && h <= NP) {   // pair h-1: row sum and bf16 pack of the two probabilities exponentiated one gap earlier
+          constexpr int k = h - 1 + EARLY, pq = k >> 4, idx = k & 15, pu = idx >> 3, r0 = (idx & 7) * 2;
           l_acc[pq] += pe0;
           l_acc[pq] += pe1;
           PIN(l_acc[pq]);
           P[pq][pu * 2 + (r0 >> 3)][(r0 & 7) >> 1] = v_cvt_pk(pe0, pe1);
         }
-        if constexpr (g < 32) {
-          constexpr int k = g, pq = k >> 4, idx = k & 15, pu = idx >> 3, r0 = (idx & 7) * 2;
+        if constexpr (h >= 0 && h < NP) {
+          constexpr int k = h + EARLY, pq = k >> 4, idx = k & 15, pu = idx >> 3, r0 = (idx & 7) * 2;
           pe0 = __builtin_amdgcn_exp2f(SBk[(BASE + pq * 2 + pu) % 6][r0]);
           pe1 = __builtin_amdgcn_exp2f(SBk[(BASE + pq * 2 + pu) % 6][r0 + 1]);
         }
 #endif
 #ifndef VC_A64_NO_LDS
-        if constexpr (g >= 32) {          // the four thin gaps at the end take the first eight V^T fragments
+        if constexpr (!BOUNDED && g >= 32) {          // the four thin gaps at the end take the first eight V^T fragments
           constexpr int f = (g - 32) * 2;   // fragment (dt = f >> 2, s = f & 3)
           lds_v<SLOT_V::value * V_TILE + (f >> 2) * 4096>(vf[f], v_rd[f & 3]);
           lds_v<SLOT_V::value * V_TILE + ((f + 1) >> 2) * 4096>(vf[f + 1], v_rd[(f + 1) & 3]);
+        }
+        if constexpr (BOUNDED && h >= 24) {
+          constexpr int f = h >= 24 ? h - 24 : 0;
+          lds_v<SLOT_V::value * V_TILE + (f >> 2) * 4096>(vf[f], v_rd[f & 3]);
         }
 #else
         if constexpr (g >= 32) { asm volatile("" : "=v"(vf[(g - 32) * 2])); asm volatile("" : "=v"(vf[(g - 32) * 2 + 1])); }
@@ -531,6 +566,20 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
 #endif
 #ifndef VC_A64_NO_SOFTMAX
         // S(kt+1) was completed by the last MFMAs of phase A: its first VALU read comes two MFMA gaps later
+        if constexpr (BOUNDED) {            // pairs 0..EARLY-1 of S(kt+1) (its block 0 was complete 27 MFMAs ago): exp at the even
+          if constexpr (g >= 2 && g < 2 + 2 * EARLY && (g & 1) == 0) {            // gaps 2, 4, ..., sum and pack one gap later
+            constexpr int k = (g - 2) / 2;
+            pe0 = __builtin_amdgcn_exp2f(SBk[(BASE + 4) % 6][2 * k]);
+            pe1 = __builtin_amdgcn_exp2f(SBk[(BASE + 4) % 6][2 * k + 1]);
+          }
+          if constexpr (g >= 3 && g < 3 + 2 * EARLY && (g & 1) == 1) {
+            constexpr int k = (g - 3) / 2;
+            if constexpr (k == 0) l_early = pe0; else l_early += pe0;
+            l_early += pe1;
+            PIN(l_early);
+            pn[k] = v_cvt_pk(pe0, pe1);
+          }
+        }
         if constexpr (!BOUNDED) {
           if constexpr (g >= 2 && g <= 9)
             sfor<0, 4>([&](auto Cc) { max_step(SBk[(BASE + 4 + decltype(Cc)::value) % 6], Cc, std::integral_constant<int, g - 2>{}); });

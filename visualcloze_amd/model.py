@@ -355,6 +355,12 @@ class Flux(nn.Module):
                 B = torch.zeros(m.out_features, rk, dtype=torch.bfloat16, device=dev)
                 A[:m.rank], B[:, :m.rank] = bf(m.lora_A.weight), bf(m.lora_B.weight)
                 bB = bf(m.lora_B.bias)
+                # the reference multiplies the bf16 lora output by a python float (lora.py:96: f32 arithmetic, ONE rounding);
+                # this mode applies it as the bf16 gate vector of the gated-residual epilogue - identical iff the scale
+                # itself is a bf16 value (1.0, 0.5, 0.75 ...); anything else would be rounded once more, so refuse it
+                if float(torch.tensor(m.scale, dtype=torch.bfloat16)) != float(m.scale):
+                    raise ValueError(f"lora_mode='ref': lora scale {m.scale} of {name} is not representable in bf16; the parity "
+                                     "mode would round it (use the merged mode, which applies it exactly in f32)")
                 sc = torch.full((m.out_features,), m.scale, dtype=torch.bfloat16, device=dev)
             from .engine import RefLinear
             ref[name] = RefLinear(w[name], b[name], A, B, bB, sc)

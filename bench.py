@@ -182,7 +182,7 @@ def flops_per_eval(T, N, D=3072, H=24, mlp=12288, depth=19, single=38, in_ch=384
     return lin, attn
 
 
-PMC_FILE = "profiles/r02_pmc_summary.json"
+PMC_FILE = "profiles/r03_pmc_summary.json"
 
 
 def pmc_traffic(kernel):
@@ -190,9 +190,10 @@ def pmc_traffic(kernel):
     (FETCH_SIZE and WRITE_SIZE in separate --pmc runs, KiB units; FETCH_SIZE x2 on gfx950 for wide coalesced reads,
     MI355X_MICROARCH.md §HBM) - hardware counters cannot be sampled from inside bench.py, so this field is a file
     lookup (`measured_in_this_run: false`), null when the file does not hold the kernel."""
-    for rel in (PMC_FILE, "profiles/r01h_pmc_summary.json"):
+    for rel in (PMC_FILE, "profiles/r02_pmc_summary.json"):
         try:
-            k = json.load(open(os.path.join(REPO, rel)))[kernel]
+            d = json.load(open(os.path.join(REPO, rel)))
+            k = d[kernel] if kernel in d else d[kernel.replace(", false, false>", ", false>")]    # (round-2 files: one template argument fewer)
             fetch, write = 2.0 * k["FETCH_SIZE"] * 1024.0, k["WRITE_SIZE"] * 1024.0
             return dict(fetch_bytes=round(fetch), write_bytes=round(write), total_bytes=round(fetch + write),
                         unit="bytes/launch", measured_in_this_run=False,
@@ -200,6 +201,76 @@ def pmc_traffic(kernel):
         except Exception:
             continue
     return None
+
+
+TRAFFIC_KERNEL = "gemm_bf16_kernel<256, 192, 4, 2, 2, 2"     # the GATE_RES instantiation of the loader-wave tile
+
+
+def traffic_probe():
+    """`python bench.py --traffic-probe`, run UNDER rocprofv3 by measure_traffic(): the launch mix `roofline_gemm` times -
+    attn.proj (two streams grouped), mlp.2 (grouped) and linear2 in the ratio 19 : 19 : 38 - on cfg-2-sized random operands."""
+    from visualcloze_amd import hip
+    hip.require_gpu()
+    dev, D, T, N, mlp = "cuda:0", 3072, 512, 3456, 12288
+    L = T + N
+    g = torch.Generator(device=dev).manual_seed(7)
+    r = lambda *s, sc=1.0: (torch.randn(*s, device=dev, generator=g) * sc).to(torch.bfloat16)  # noqa: E731
+    x = r(L, D)
+    gate = r(D)
+    att, hid, cat = r(L, D), r(L, mlp), r(L, D + mlp)
+    wp, wm, wl = r(D, D, sc=D ** -0.5), r(D, mlp, sc=mlp ** -0.5), r(D, D + mlp, sc=(D + mlp) ** -0.5)
+    b = torch.zeros(D, dtype=torch.bfloat16, device=dev)
+
+    def grouped(a, w):
+        return [hip.make_problem(a[T:], w, b, x[T:], res=x[T:], gate=gate), hip.make_problem(a[:T], w, b, x[:T], res=x[:T], gate=gate)]
+    for _ in range(3):
+        hip.gemm(grouped(att, wp), epi=hip.EPI_GATE_RES)
+        hip.gemm(grouped(hid, wm), epi=hip.EPI_GATE_RES)
+        for _ in range(2):
+            hip.gemm(hip.make_problem(cat, wl, b, x, res=x, gate=gate), epi=hip.EPI_GATE_RES)
+    torch.cuda.synchronize()
+
+
+def measure_traffic(timeout=150):
+    """HBM-side bytes per launch of the roofline kernel, MEASURED IN THIS RUN: two separate `rocprofv3 --pmc` passes
+    (FETCH_SIZE; WRITE_SIZE - they do not share a pass, MI355X_MICROARCH.md) over `bench.py --traffic-probe` in a child
+    process, KiB units, FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B on wide coalesced reads).  None when rocprofv3
+    is not on this machine or a pass fails (the committed PMC summary is then quoted instead, labelled as such)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    vals = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="vc_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+        try:
+            env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+                env.pop(k, None)
+            r = subprocess.run([exe, "--kernel-trace", "--pmc", ctr, "-d", tmp, "-o", "p", "--output-format", "csv", "--",
+                                sys.executable, os.path.abspath(__file__), "--traffic-probe"], cwd=tmp, env=env,
+                               capture_output=True, text=True, timeout=timeout)
+            files = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            xs = [float(row["Counter_Value"]) for f in files for row in csv.DictReader(open(f))
+                  if TRAFFIC_KERNEL in row["Kernel_Name"].replace("(anonymous namespace)::", "") and row["Counter_Name"] == ctr]
+            if len(xs) < 4:
+                return None
+            vals[ctr] = sum(xs) / len(xs)
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    fetch, write = 2.0 * vals["FETCH_SIZE"] * 1024.0, vals["WRITE_SIZE"] * 1024.0
+    return dict(fetch_bytes=round(fetch), write_bytes=round(write), total_bytes=round(fetch + write), unit="bytes/launch",
+                measured_in_this_run=True,
+                source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --traffic-probe` (the timed launch mix "
+                       "on cfg-2-sized random operands) in a child process; FETCH_SIZE x2 gfx950 correction")
 
 
 def roofline_gemm(job, iters=3):
@@ -248,7 +319,7 @@ def roofline_gemm(job, iters=3):
     n = len(launches)
     achieved = flops / (ms * 1e-3) / 1e12
     return dict(bound="mfma", achieved=round(achieved, 1), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
-                frac=round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), traffic=pmc_traffic("gemm_bf16_kernel<256, 192, 4, 2, 2, 2, false>"),
+                frac=round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), traffic=pmc_traffic("gemm_bf16_kernel<256, 192, 4, 2, 2, 2, false, false>"),
                 kernel="gemm_bf16_kernel<EPI_GATE_RES>", launches_per_eval=n,
                 flops_per_launch=flops / n, avg_launch_us=round(ms * 1e3 / n, 2))
 
@@ -347,6 +418,8 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="384-grid-2x3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.traffic = committed file)")
+    ap.add_argument("--traffic-probe", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--tile-cfg", type=int, default=None)
     ap.add_argument("--attn-variant", type=int, default=None)
     ap.add_argument("--no-fuse-vt", action="store_true", help="A/B: V^T by the pre-pass kernel instead of the qkv GEMM's epilogue")
@@ -403,6 +476,8 @@ def result_record(a, wl, world, elapsed, T, N, bcast_s, weight_bytes):
 
 def main(argv=None):
     a = parse_args(argv)
+    if a.traffic_probe:
+        return traffic_probe()
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -447,6 +522,11 @@ def main(argv=None):
     if rank == 0:
         rec["precompute_ms"] = round(job.precompute_ms(), 3)
         rec["roofline"] = roofline_gemm(job)
+        profiled = any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB"))
+        if world == 1 and not a.no_traffic and not profiled:
+            live = measure_traffic()                      # (not when this very run is being profiled already)
+            if live is not None:
+                rec["roofline"]["traffic"] = live
         rec["attention_kernel"] = roofline_attention(job)
         if world == 1 and not a.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(T, N, wl)

@@ -12,7 +12,7 @@ mkdir -p $OUT
 python bench.py --workload $WL $BENCH_EXTRA > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 tail -c 600 $OUT/${TAG}_bench.json
 rm -rf $OUT/${TAG}_prof
-rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof -o ${TAG} -- python bench.py --workload $WL --no-cpu-baseline $BENCH_EXTRA > $OUT/${TAG}_prof.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof -o ${TAG} -- python bench.py --workload $WL --no-cpu-baseline --no-traffic $BENCH_EXTRA > $OUT/${TAG}_prof.log 2>&1
 DB=$(ls $OUT/${TAG}_prof/*results.db 2>/dev/null | head -1)
 python tools/rocprof_summary.py $DB > $OUT/${TAG}_kernel_stats.csv
 python tools/rocprof_gaps.py $DB > $OUT/${TAG}_step_breakdown.csv
@@ -22,7 +22,7 @@ if [ "$PMC" = "pmc" ]; then
   i=0
   for ctrs in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
     i=$((i+1))
-    rocprofv3 --kernel-trace --pmc $ctrs -d $OUT/${TAG}_pmc/p$i -o p$i --output-format csv -- python bench.py --workload $WL --no-cpu-baseline --steps 2 --warmup 1 $BENCH_EXTRA > $OUT/${TAG}_pmc_p$i.log 2>&1
+    rocprofv3 --kernel-trace --pmc $ctrs -d $OUT/${TAG}_pmc/p$i -o p$i --output-format csv -- python bench.py --workload $WL --no-cpu-baseline --no-traffic --steps 2 --warmup 1 $BENCH_EXTRA > $OUT/${TAG}_pmc_p$i.log 2>&1
   done
   python tools/pmc_summary.py $OUT/${TAG}_pmc/p*/p*_counter_collection.csv > $OUT/${TAG}_pmc_summary.json
   rm -rf $OUT/${TAG}_pmc

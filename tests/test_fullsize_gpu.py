@@ -349,7 +349,9 @@ def test_full_width_trajectory_vs_oracle(procedural_small_model, case):
     points from strength 0.4 = 9 evaluations at L = 4608, D = 3072, 1 + 1 blocks.  The fused sampler's intermediate and
     FINAL latents are held to the bf16-merged oracle (same rounding points) and the fp32-ref oracle (exact reference
     semantics), with bounds stated against `floor` = the oracle's own bf16-vs-fp32 deviation on the same state:
-        HIP vs bf16 oracle <= 1.5 * floor,   HIP vs fp32 oracle <= 2 * floor      (final state and every saved one)."""
+        HIP vs bf16 oracle <= floor,   HIP vs fp32 oracle <= 1.5 * floor      (final state and every saved one;
+    measured: 0.3 * floor and 1.0 * floor - the fused loop drifts from exact arithmetic exactly as far as the reference's own
+    bf16 rounding does, and 3x less far from the oracle that rounds where it rounds)."""
     import numpy as np
     from tests.helpers import parity_log
     from visualcloze_amd.transport import Sampler, create_transport
@@ -375,7 +377,7 @@ def test_full_width_trajectory_vs_oracle(procedural_small_model, case):
         floor, e16, e32 = rel_l2(b16, f32), rel_l2(got, b16), rel_l2(got, f32)
         parity_log(f"[trajectory 1+1 blocks, {case}] state {k}/{last}: HIP vs bf16 oracle {e16:.3e}, vs fp32 oracle {e32:.3e}, "
                    f"oracle bf16-vs-fp32 floor {floor:.3e}")
-        assert e16 < 1.5 * floor and e32 < 2.0 * floor, (k, e16, e32, floor)
+        assert e16 < 1.0 * floor and e32 < 1.5 * floor, (k, e16, e32, floor)
 
 
 TIMES_FIXTURE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fulldepth_times_oracle.npz")

@@ -57,7 +57,7 @@ def main():
         k, v = kv.split("=")
         opts.setdefault(who, {})[k] = int(v)
     base_opts = dict(attn_variant=eng.attn_variant, tile_cfg=eng.tile_cfg, fuse_qnorm=eng.fuse_qnorm, fuse_vt=eng.fuse_vt,
-                     fuse_knorm=eng.fuse_knorm)
+                     fuse_knorm=eng.fuse_knorm, bounded_softmax=eng.bounded_softmax, mlp_first=eng.mlp_first)
     jobs, libs = {}, {}
     for libname, alias in builds:
         libs[alias] = load(libname)

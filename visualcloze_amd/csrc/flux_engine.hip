@@ -56,7 +56,7 @@ struct Flux : Buffers {
   std::vector<SingleW> sgl;
   int64_t final_mod = 0;
   // options
-  int attn_variant = -1, tile_cfg = 0, fuse_qnorm = 1, fuse_vt = 1, qkv_heads = 0, fuse_knorm = 0, logit_bound_milli = 0, n_cu = 256;
+  int attn_variant = -1, tile_cfg = 0, fuse_qnorm = 1, fuse_vt = 1, qkv_heads = 0, fuse_knorm = 0, logit_bound_milli = 0, mlp_first = 0, n_cu = 256;
   // prepared geometry + workspace carve-up
   bool prepared = false;
   int B = 0, T = 0, N = 0, L = 0, Lp = 0, S = 0;
@@ -65,11 +65,11 @@ struct Flux : Buffers {
   // captured steps, most recently used first (a two-stage pipeline alternates between two geometries)
   hipGraphExec_t graph = nullptr;      // = graphs.front().second while a sample is in flight
   struct Key {
-    char* base; int B, T, N, S, ragged, gapped, variant, tile, fuse, fuse_vt, state_f32, qkv_heads, fuse_knorm, bound; hipStream_t s;
+    char* base; int B, T, N, S, ragged, gapped, variant, tile, fuse, fuse_vt, state_f32, qkv_heads, fuse_knorm, bound, mlp_first; hipStream_t s;
     bool operator==(const Key& o) const {
       return base == o.base && B == o.B && T == o.T && N == o.N && S == o.S && ragged == o.ragged && gapped == o.gapped &&
              variant == o.variant && tile == o.tile && fuse == o.fuse && fuse_vt == o.fuse_vt && state_f32 == o.state_f32 &&
-             qkv_heads == o.qkv_heads && fuse_knorm == o.fuse_knorm && bound == o.bound && s == o.s;
+             qkv_heads == o.qkv_heads && fuse_knorm == o.fuse_knorm && bound == o.bound && mlp_first == o.mlp_first && s == o.s;
     }
   } key{};
   std::vector<std::pair<Key, hipGraphExec_t>> graphs;
@@ -345,8 +345,11 @@ int single_block(Flux& f, const Ctx& c, const SingleW& w, Err e) {
     with_vt(f, p, f.L, 0, w.ks);
     TRY(gemm(f, &p, 1, qkv_epi(f), nullptr, 0, c.s, e));
   }
-  TRY(lin(f, w.mlp, f.XH, D, f.CAT + D, ldc, M, VC_EPI_GELU, c.s, e));
+  // the attention kernel runs right behind the projection that wrote its operands, and the MLP-up GEMM right in front of the
+  // linear2 that reads its 97 MB (option mlp_first = the reference's textual order, layers.py:236-243)
+  if (f.mlp_first) TRY(lin(f, w.mlp, f.XH, D, f.CAT + D, ldc, M, VC_EPI_GELU, c.s, e));
   TRY(attention(f, c, w.qs, w.ks, nullptr, nullptr, 0, e));
+  if (!f.mlp_first) TRY(lin(f, w.mlp, f.XH, D, f.CAT + D, ldc, M, VC_EPI_GELU, c.s, e));
   VcGemmProblem p = prob(f.CAT, ldc, w.lin2, f.X, D, M);
   p.res = f.X; p.ldres = D; p.gate = modp(f, w.mod, 2); p.gate_bstride = f.n_mod; p.rows_per_batch = f.L;
   return gemm(f, &p, 1, VC_EPI_GATE_RES, c.step_ptr, c.mss, c.s, e);
@@ -445,7 +448,7 @@ void drop_graph(Flux& f) {
 // the hipGraph of ONE solver step: everything step-dependent (modulation rows, dt) is indexed on the device by STEP
 int step_graph(Flux& f, hipStream_t s, Err e) {
   Flux::Key k{f.base, f.B, f.T, f.N, f.S, f.ragged, f.gapped, attention_variant(f), f.tile_cfg, f.fuse_qnorm, f.fuse_vt, f.state_f32,
-              f.qkv_heads, f.fuse_knorm, f.logit_bound_milli, s};
+              f.qkv_heads, f.fuse_knorm, f.logit_bound_milli, f.mlp_first, s};
   for (size_t i = 0; i < f.graphs.size(); ++i)
     if (f.graphs[i].first == k) {
       auto hit = f.graphs[i];
@@ -548,6 +551,7 @@ int vc_flux_set_option_impl(void* handle, const char* name, int32_t value, char*
     f.qkv_heads = value;
   } else if (!strcmp(name, "fuse_knorm")) f.fuse_knorm = value != 0;
   else if (!strcmp(name, "logit_bound_milli")) f.logit_bound_milli = value > 0 ? value : 0;
+  else if (!strcmp(name, "mlp_first")) f.mlp_first = value != 0;
   else FAIL(VC_ERR_ARG, "flux_set_option: unknown option '%s'", name);
   return VC_OK;
 }

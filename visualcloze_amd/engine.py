@@ -137,6 +137,10 @@ class FluxEngine:
         self.fuse_knorm = weights.qkv_heads > 0
         # the attention kernel may drop its running max when the model's QK-norm scales bound the logits (VcAttention.logit_bound)
         self.bounded_softmax = True
+        # SingleStreamBlock launch order: qkv GEMM -> attention -> MLP-up GEMM -> linear2 (operands consumed right after they
+        # are produced: the attention finds q / k / V^T where the projection left them, linear2 its 97 MB of gelu(mlp)); True =
+        # MLP-up before the attention, the order of layers.py:236-243
+        self.mlp_first = False
         self.tile_cfg = 0
         self.stream = torch.cuda.Stream(device=dev)   # capture needs a non-default stream
         self._ref_scratch: Dict[tuple, torch.Tensor] = {}
@@ -215,7 +219,7 @@ class FluxEngine:
         """hipGraph of ONE solver step (Flux evaluation + Euler update + device step-counter increment).
         Everything step-dependent (modulation rows, dt) is indexed on the device by ws.STEP, so the same
         graph replays for every step of every sample batch with this geometry."""
-        key = (ws.ragged, ws.gapped, self.attn_variant, self.tile_cfg, self.fuse_qnorm, self.fuse_vt, self.fuse_knorm, self.bounded_softmax)
+        key = (ws.ragged, ws.gapped, self.attn_variant, self.tile_cfg, self.fuse_qnorm, self.fuse_vt, self.fuse_knorm, self.bounded_softmax, self.mlp_first)
         if ws.graph is None or ws.graph_key != key:
             xs = ws.XS.clone()
             self.eval_once(ws, ws.STEP, euler=True, s=s)      # warm-up: sets func attributes outside capture
@@ -414,8 +418,11 @@ class FluxEngine:
         self._ln(c, ws.X, mn, 0, ws.XH, ws.L)
         epi, kv = self._qkv_epi(ws, ws.L, 0, Wn[pf + ".norm.key_norm.scale"])
         self._lin(pf + ".linear1.qkv", ws.XH, ws.QKV, epi=epi, s=s, **kv)
-        self._lin(pf + ".linear1.mlp", ws.XH, ws.CAT[:, D:], epi=hip.EPI_GELU, s=s)
+        if self.mlp_first:      # (the reference's textual order; the product runs the attention right behind its projection)
+            self._lin(pf + ".linear1.mlp", ws.XH, ws.CAT[:, D:], epi=hip.EPI_GELU, s=s)
         self._attention(c, (Wn[pf + ".norm.query_norm.scale"], Wn[pf + ".norm.key_norm.scale"], None, None), 0)
+        if not self.mlp_first:
+            self._lin(pf + ".linear1.mlp", ws.XH, ws.CAT[:, D:], epi=hip.EPI_GELU, s=s)
         self._gated(c, (pf + ".linear2",), (ws.CAT,), (ws.X,), (self._mod(ws, mn, 2),), (ws.L,), ({},))
 
     def last_layer(self, c) -> None:

@@ -74,12 +74,13 @@ class FluxHandle:
             pass
 
     def set_options(self, attn_variant=None, tile_cfg=0, fuse_qnorm=True, fuse_vt=True, qkv_heads=0, fuse_knorm=False,
-                    logit_bound=0.0) -> None:
+                    logit_bound=0.0, mlp_first=False) -> None:
         import math
         want = dict(attn_variant=-1 if attn_variant is None else int(attn_variant), tile_cfg=int(tile_cfg),
                     fuse_qnorm=int(bool(fuse_qnorm)), fuse_vt=int(bool(fuse_vt)), qkv_heads=int(qkv_heads),
                     fuse_knorm=int(bool(fuse_knorm)),
-                    logit_bound_milli=int(math.ceil(logit_bound * 1000)) if 0 < logit_bound < 2e6 else 0)
+                    logit_bound_milli=int(math.ceil(logit_bound * 1000)) if 0 < logit_bound < 2e6 else 0,
+                    mlp_first=int(bool(mlp_first)))
         for k, v in want.items():
             if self._opts.get(k) != v:
                 hip._check(hip.lib().vc_flux_set_option(self.h, k.encode(), v), f"vc_flux_set_option({k})")

@@ -443,7 +443,7 @@ class Flux(nn.Module):
             from .handle import FluxHandle
             self._handle = FluxHandle(self.params, eng.W, eng.dev)
         self._handle.set_options(eng.attn_variant, eng.tile_cfg, eng.fuse_qnorm, eng.fuse_vt, eng.W.qkv_heads, eng.fuse_knorm,
-                                 eng.W.logit_bound if eng.bounded_softmax else 0.0)
+                                 eng.W.logit_bound if eng.bounded_softmax else 0.0, eng.mlp_first)
         return self._handle
 
     # ------------------------------------------------------------------ the B1 boundary

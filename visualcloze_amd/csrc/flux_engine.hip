@@ -219,7 +219,10 @@ int resolve(Flux& f, Err e) {
 // ---------------------------------------------------------------- launch helpers
 // qkv projections: with fuse_vt the V third leaves the GEMM transposed into VT (EPI_QKV); with head-permuted weights (option
 // qkv_heads) C receives the logical columns and, with fuse_knorm, the key heads leave QK-normed and rotated: no pre-pass left
-bool kn_in_gemm(const Flux& f) { return f.fuse_knorm && f.qkv_heads > 0; }
+int attention_variant(const Flux& f);
+// (where the one-wave-per-SIMD attention kernel runs: small geometries keep ONE pre-pass launch for q and k - the fused
+// epilogue needs the 256x192 tile, which their short M does not fill)
+bool kn_in_gemm(const Flux& f) { return f.fuse_knorm && f.qkv_heads > 0 && (attention_variant(f) & 8); }
 int qkv_epi(const Flux& f) { return f.fuse_vt || f.qkv_heads > 0 ? VC_EPI_QKV : VC_EPI_BIAS; }
 void with_vt(Flux& f, VcGemmProblem& p, int rows, int row0, const void* k_scale) {
   if (f.fuse_vt) { p.vt = f.VT; p.vt_bstride = (int64_t)f.H * 128 * f.Lp; p.vt_col0 = 2 * f.D; p.vt_lpad = f.Lp; }

@@ -344,7 +344,7 @@ class FluxEngine:
         q1, k1, q2, k2 = scales
         variant = self.attention_variant(ws)
         fused_q = bool(variant & 8) and self.fuse_qnorm
-        parts = (0 if self._kn_in_gemm() else hip.QKN_K) | (0 if fused_q else hip.QKN_Q) | (0 if self._vt_in_gemm() else hip.QKN_VT)
+        parts = (0 if self._kn_in_gemm(ws) else hip.QKN_K) | (0 if fused_q else hip.QKN_Q) | (0 if self._vt_in_gemm() else hip.QKN_VT)
         if parts:
             hip.qknorm_rope_vt(ws.QKV, q1, k1, ws.ROPE, ws.VT, ws.L, self.H, stream=s, q_scale2=q2, k_scale2=k2, split=split, B=ws.B,
                                parts=parts)
@@ -363,8 +363,11 @@ class FluxEngine:
     def _vt_in_gemm(self) -> bool:
         return self.fuse_vt and self.W.ref is None
 
-    def _kn_in_gemm(self) -> bool:
-        return self.fuse_knorm and self.W.qkv_heads > 0 and self.W.ref is None
+    def _kn_in_gemm(self, ws: Workspace) -> bool:
+        """key QKNorm + RoPE in the qkv GEMM's epilogue: where the one-wave-per-SIMD attention kernel runs (it normalises
+        its own queries, so no pre-pass is left).  Small geometries (cfg 1) keep ONE pre-pass launch for q and k: the fused
+        epilogue needs the 256x192 tile, which their short M does not fill (+1.2 ms of GEMM time at L = 1664)."""
+        return self.fuse_knorm and self.W.qkv_heads > 0 and self.W.ref is None and bool(self.attention_variant(ws) & 8)
 
     def _qkv_epi(self, ws: Workspace, rows: int, row0: int, k_scale=None):
         """(epilogue, problem kwargs) of a qkv projection: with fuse_vt the V third goes straight to ws.VT, transposed; with
@@ -374,7 +377,7 @@ class FluxEngine:
             kw.update(vt=ws.VT, vt_col0=2 * self.D)
         if self.W.qkv_heads and self.W.ref is None:
             kw.update(kn_heads=self.W.qkv_heads)
-            if self._kn_in_gemm():
+            if self._kn_in_gemm(ws):
                 kw.update(kn_scale=k_scale, kn_rope=ws.ROPE)
         if not kw:
             return hip.EPI_BIAS, {}

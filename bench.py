@@ -231,7 +231,7 @@ def traffic_probe():
     torch.cuda.synchronize()
 
 
-def measure_traffic(timeout=150):
+def measure_traffic(timeout=90):
     """HBM-side bytes per launch of the roofline kernel, MEASURED IN THIS RUN: two separate `rocprofv3 --pmc` passes
     (FETCH_SIZE; WRITE_SIZE - they do not share a pass, MI355X_MICROARCH.md) over `bench.py --traffic-probe` in a child
     process, KiB units, FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B on wide coalesced reads).  None when rocprofv3

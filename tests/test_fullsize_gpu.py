@@ -126,6 +126,23 @@ def test_full_width_one_plus_one_blocks_vs_oracle(small_model, geom):
     assert e32 < max(3e-2, 4 * floor)
 
 
+def test_full_width_batch_of_two_equals_per_sample(small_model):
+    """A per-GPU batch at full width (cfg 2 geometry, B = 2, different text / guidance per sample): one stacked launch
+    sequence - batch-strided qkv rows, the key norm of both samples in the GEMM's epilogue with per-sample RoPE rows, V^T per
+    sample, the batch dimension of the attention grid - equals the two B = 1 runs (same kernels; tile shapes per row block may
+    differ, hence bf16 noise instead of bit equality)."""
+    m, _ = small_model
+    a, b = _inputs("cfg2", seed=21), _inputs("cfg2", seed=22)
+    both = {k: torch.cat((a[k], b[k])) for k in a}
+    both["guidance"] = torch.tensor([30.0, 3.5])
+    b["guidance"] = torch.tensor([3.5])
+    t = torch.tensor([0.8, 0.3])
+    got = _call(m, both, t).float().cpu()
+    for i, one in enumerate((a, b)):
+        ref = _call(m, one, t[i:i + 1]).float().cpu()
+        assert rel_l2(got[i:i + 1], ref) < 5e-3, i
+
+
 @pytest.mark.parametrize("geom", list(GEOMS))
 def test_attention_properties(geom):
     from visualcloze_amd import hip

@@ -180,6 +180,24 @@ def test_gemm_persistent_grouped_qkv_epilogue(hip, cfg):
     check(v1[..., :L].permute(0, 3, 1, 2).reshape(B * L, D), want[:, 2 * D:])
     q2, v2 = run(hip.GEMM_PERSIST)                         # the launcher's own plan (may split): bf16-equal
     check(q2[:, :2 * D], want[:, :2 * D])
+    # and with head-permuted weights + the key norm in the epilogue (vkind 3 tiles leave the epilogue early inside the tile loop)
+    perm = hip.qkv_head_permutation(H).to(DEV)
+    ks = (1 + 0.1 * rnd(128, seed=8)).to(torch.bfloat16)
+    rope = torch.stack([rope_table(L), rope_table(L).flip(0)]).contiguous()
+    wip, bip, wtp, btp = wi[perm].contiguous(), bi[perm].contiguous(), wt[perm].contiguous(), bt[perm].contiguous()
+
+    def run_kn(flags):
+        qkv = torch.full((B * L, 3 * D), float("nan"), dtype=torch.bfloat16, device=DEV)
+        vt = torch.full((B, H, 128, Lp), 7.0, dtype=torch.bfloat16, device=DEV)
+        kw = dict(c_bstride=L * 3 * D, vt=vt, vt_col0=2 * D, kn_heads=H, kn_scale=ks, kn_rope=rope)
+        hip.gemm([hip.make_problem(xi, wip, bip, qkv[T:], M=B * N, c_rpb=N, vt_rpb=N, vt_row0=T, **kw),
+                  hip.make_problem(xt, wtp, btp, qkv[:T], M=B * T, c_rpb=T, vt_rpb=T, vt_row0=0, **kw)], epi=hip.EPI_QKV, tile_cfg=flags)
+        torch.cuda.synchronize()
+        return qkv, vt
+    k0, kv0 = run_kn(0)
+    k1, kv1 = run_kn(hip.GEMM_PERSIST)
+    assert torch.equal(k0[:, :2 * D], k1[:, :2 * D]) and torch.equal(kv0, kv1) and torch.equal(kv0, v0)
+    assert torch.equal(k0[:, :D], q0[:, :D]) and not torch.equal(k0[:, D:2 * D], q0[:, D:2 * D])
 
 
 @pytest.mark.parametrize("cfg", [0, 1, 2, 4, 5, 19, 34, 36])

@@ -7,7 +7,8 @@ the whole 19 + 38-block model (13.1 B parameters, D = 3072, L = 512 + 3456, LoRA
 
 in both oracle modes (bf16 / merged LoRA = the HIP path's rounding points; fp32 / un-merged = exact reference semantics)
 -> tests/golden/fulldepth_times_oracle.npz.  tests/golden/fulldepth_cfg2_oracle.npz holds the same comparison at t = 0.62.
-About 45 min on 8 cores; weights are kept as bf16 on the host (26 GB) and widened one tensor at a time.
+`--geom cfg3 | cfg5`: ONE evaluation at t = 0.62 of the same model on the 512-grid 2x3 (L = 6656) / 384-grid 3x4 (L = 7424)
+geometry -> fulldepth_<geom>_oracle.npz (every second image token).  About 45 min on 8 cores (a large geometry: ~40 min); weights are kept as bf16 on the host (26 GB) and widened one tensor at a time.
 
     python tests/golden/make_fulldepth_times.py
 """
@@ -43,7 +44,33 @@ def flux_times():
     return [float(tm[0]), float(tm[-1])]
 
 
+GEOMS = {      # the other full-depth fixtures: one evaluation at t = 0.62 on the two largest BASELINE geometries
+    "cfg3": dict(rows=2, row_latent=(64, 192)),      # 512-grid 2x3, L = 512 + 6144
+    "cfg5": dict(rows=3, row_latent=(48, 192)),      # 384-grid 3x4, L = 512 + 6912
+}
+TOKEN_STRIDE = 2      # (the large geometries are stored for every second image token)
+
+
+def geom_inputs(geom):
+    """procedural inputs of a geometry (as make_fullwidth_traj.inputs, which holds cfg 2 and the SDEdit stage)"""
+    from tests.procedural import ptensor
+    c = GEOMS[geom]
+    h, w = c["row_latent"]
+    ids = O.grid_img_ids([(h, w)] * c["rows"])
+    N = ids.shape[0]
+    seed = 2000 + sorted(GEOMS).index(geom) * 10
+    x = ptensor((1, N, 64), seed + 1, q=6)
+    cond = torch.cat([ptensor((1, N, 64), seed + 2, q=6), (ptensor((1, N, 256), seed + 3, q=0, kmax=1).abs() > 0.5).float()], -1)
+    return dict(x=x, cond=cond, img_ids=ids[None], txt=ptensor((1, 512, 4096), seed + 4, q=6), txt_ids=torch.zeros(1, 512, 3),
+                y=ptensor((1, 768), seed + 5, q=6), txt_mask=torch.ones(1, 512, dtype=torch.int32),
+                img_mask=torch.ones(1, N, dtype=torch.int32), guidance=torch.full((1,), 30.0))
+
+
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--geom", default=None, choices=sorted(GEOMS), help="instead of cfg 2's two grid ends: this geometry at t = 0.62")
+    a = ap.parse_args()
     spec = importlib.util.spec_from_file_location("ft", os.path.join(HERE, "make_fullwidth_traj.py"))
     FT = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(FT)
@@ -53,10 +80,13 @@ def main():
     t0 = time.time()
     sd = LazyF32({k: procedural_param(k, tuple(v.shape), device="cpu").to(torch.bfloat16) for k, v in m.state_dict().items()})
     print(f"procedural weights: {sum(dict.__getitem__(sd, k).numel() for k in sd) / 1e9:.2f} B parameters in {time.time() - t0:.0f} s", flush=True)
-    inp = FT.inputs("cfg2")
+    inp = geom_inputs(a.geom) if a.geom else FT.inputs("cfg2")
     G = O.FluxGeometry()
     out = {"x_sum": np.float64(inp["x"].double().sum().item())}
-    times = flux_times()
+    times = [0.62] if a.geom else flux_times()
+    stride = TOKEN_STRIDE if a.geom else 1
+    out["token_stride"] = np.int32(stride)
+    name = f"fulldepth_{a.geom}_oracle.npz" if a.geom else "fulldepth_times_oracle.npz"
     out["times"] = np.asarray(times, np.float64)
     args = lambda t: (sd, G, torch.cat((inp["x"], inp["cond"]), -1), inp["img_ids"], inp["txt"], inp["txt_ids"],   # noqa: E731
                       torch.tensor([t]), inp["y"], inp["txt_mask"], inp["img_mask"], inp["guidance"])
@@ -72,13 +102,13 @@ def main():
             print(f"t = {t:.6f} {tag}: {time.time() - t1:.0f} s ({torch.get_num_threads()} threads)", flush=True)
             if tag == "bf16":
                 assert torch.equal(y.to(torch.bfloat16).float(), y)
-                out[f"bf16_{i}"] = y.to(torch.bfloat16).view(torch.int16).numpy()
+                out[f"bf16_{i}"] = y[:, ::stride].to(torch.bfloat16).view(torch.int16).numpy()
                 yb = y
             else:
-                out[f"fp32_{i}"] = y.numpy().astype(np.float16)
+                out[f"fp32_{i}"] = y[:, ::stride].numpy().astype(np.float16)
                 print(f"  oracle bf16-vs-fp32 rel-L2 {((yb - y).norm() / y.norm()).item():.3e}", flush=True)
-        np.savez_compressed(os.path.join(HERE, "fulldepth_times_oracle.npz"), **out)
-    print("wrote fulldepth_times_oracle.npz", flush=True)
+        np.savez_compressed(os.path.join(HERE, name), **out)
+    print("wrote", name, flush=True)
 
 
 if __name__ == "__main__":

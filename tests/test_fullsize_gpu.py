@@ -400,7 +400,12 @@ def test_full_width_trajectory_vs_oracle(procedural_small_model, case):
 TIMES_FIXTURE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fulldepth_times_oracle.npz")
 
 
-def test_full_depth_at_both_ends_of_the_time_grid_vs_oracle():
+@pytest.fixture(scope="module")
+def procedural_full_model():
+    return _build_procedural(19, 38)
+
+
+def test_full_depth_at_both_ends_of_the_time_grid_vs_oracle(procedural_full_model):
     """The full 19 + 38-block model at the FIRST and the LAST Flux time of cfg 2's 30-point grid (t = 1.0 and
     t = 1 - bf16(t_28) ~ 0.09: the timestep embeddings furthest from the t = 0.62 of test_full_depth_19_38_vs_oracle),
     procedural weights, against the committed oracle outputs of tests/golden/make_fulldepth_times.py; bounds as there:
@@ -411,7 +416,7 @@ def test_full_depth_at_both_ends_of_the_time_grid_vs_oracle():
     fx = np.load(TIMES_FIXTURE)
     inp = FT.inputs("cfg2")
     assert float(fx["x_sum"]) == inp["x"].double().sum().item()
-    m = _build_procedural(19, 38)
+    m = procedural_full_model
     for i, t in enumerate(fx["times"]):
         got = _call(m, inp, torch.tensor([float(t)], dtype=torch.float32)).float().cpu()
         b16 = torch.tensor(fx[f"bf16_{i}"]).view(torch.bfloat16).float()
@@ -421,6 +426,34 @@ def test_full_depth_at_both_ends_of_the_time_grid_vs_oracle():
                    f"{e32:.3e}, oracle bf16-vs-fp32 floor {floor:.3e}")
         assert torch.isfinite(got).all()
         assert e16 < 1.5 * floor and e32 < 2.0 * floor, (float(t), e16, e32, floor)
+
+
+@pytest.mark.parametrize("geom", ["cfg3", "cfg5"])
+def test_full_depth_on_the_large_geometries_vs_oracle(procedural_full_model, geom):
+    """The full 19 + 38-block model on the two LARGEST BASELINE geometries (cfg 3: 512-grid 2x3, L = 6656; cfg 5: 384-grid
+    3x4, L = 7424 - other attention tails, other tile counts, other RoPE grids than cfg 2), one evaluation at t = 0.62,
+    procedural weights, against the committed oracle outputs of `tests/golden/make_fulldepth_times.py --geom <geom>`
+    (every second image token); bounds as at cfg 2: <= 1.5 * floor vs the bf16-merged oracle, <= 2 * floor vs fp32-ref."""
+    import importlib.util
+    import numpy as np
+    from tests.helpers import parity_log
+    path = os.path.join(os.path.dirname(TIMES_FIXTURE), f"fulldepth_{geom}_oracle.npz")
+    spec = importlib.util.spec_from_file_location("fdt", os.path.join(os.path.dirname(TIMES_FIXTURE), "make_fulldepth_times.py"))
+    FD = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(FD)
+    fx = np.load(path)
+    inp = FD.geom_inputs(geom)
+    assert float(fx["x_sum"]) == inp["x"].double().sum().item()
+    st = int(fx["token_stride"])
+    got = _call(procedural_full_model, inp, torch.tensor([float(fx["times"][0])], dtype=torch.float32)).float().cpu()
+    assert torch.isfinite(got).all()
+    got = got[:, ::st]
+    b16 = torch.tensor(fx["bf16_0"]).view(torch.bfloat16).float()
+    f32 = torch.tensor(fx["fp32_0"].astype("float32"))
+    floor, e16, e32 = rel_l2(b16, f32), rel_l2(got, b16), rel_l2(got, f32)
+    parity_log(f"[full depth 19+38, {geom} (L = {512 + inp['x'].shape[1]}), procedural weights] t = {float(fx['times'][0]):.2f}: HIP vs "
+               f"bf16-merged oracle {e16:.3e}, vs fp32-ref oracle {e32:.3e}, oracle bf16-vs-fp32 floor {floor:.3e}")
+    assert e16 < 1.5 * floor and e32 < 2.0 * floor, (geom, e16, e32, floor)
 
 
 def test_full_model_fused_equals_eager_and_is_deterministic():

@@ -669,7 +669,9 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
 
 // Combines the pieces of the tail items: out = sum_p w_p (O_p / l_p) / sum_p w_p, w_p = l_p 2^(m_p - max m).  One
 // workgroup per (XCD, tail item of that XCD, query block of the wave) on the XCD that wrote the pieces (block b -> XCD
-// b % 8); thread layout = the writer's.
+// b % 8); thread layout = the writer's.  ONE pass over the pieces with a running maximum (the accumulator is rescaled when
+// a piece raises it) and the next piece's loads issued before the current one is folded in: the kernel is a chain of
+// L2 round trips, not bandwidth, and this keeps the chain at ~one trip (+ the store) whatever the number of pieces.
 __global__ __launch_bounds__(256) void attn64_merge_kernel(const Attn64Args a, int G) {
   const int xcd = blockIdx.x & 7, it = blockIdx.x >> 4, qb = (blockIdx.x >> 3) & 1;
   const int nkt = (a.L + KVB - 1) / KVB;
@@ -682,38 +684,59 @@ __global__ __launch_bounds__(256) void attn64_merge_kernel(const Attn64Args a, i
   if (chunk_begin64(c + 1, sc.units, sc.W) >= u1) return;        // the whole item ran inside one chunk: already written
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 31, hh = lane >> 5;
-  const int id = sc.start + sc.rounds * sc.W + it;
-  const int qb_i = id % a.qblocks, bh = id / a.qblocks;
-  const int h = bh % a.H, b = bh / a.H;
   const char* base = (const char*)a.part;
   const long ml_off = PART64_O_BYTES + ((wave * 2 + qb) * 64 + lane) * 8;
-  float m = -INFINITY;
-  for (int cc = c; cc < sc.W && chunk_begin64(cc, sc.units, sc.W) < u1; ++cc) {
-    if (chunk_begin64(cc + 1, sc.units, sc.W) == chunk_begin64(cc, sc.units, sc.W)) continue;   // empty chunk (fewer units than blocks)
+  const long o_off = ((long)(wave * 2 + qb) * 16 * 64 + lane) * 8;
+  // chunk cc holds units of this item iff it is not empty (fewer units than blocks) and begins before u1
+  auto next_chunk = [&](int cc) {
+    while (cc < sc.W && chunk_begin64(cc, sc.units, sc.W) < u1 && chunk_begin64(cc + 1, sc.units, sc.W) == chunk_begin64(cc, sc.units, sc.W)) ++cc;
+    return (cc < sc.W && chunk_begin64(cc, sc.units, sc.W) < u1) ? cc : -1;
+  };
+  auto piece_ptr = [&](int cc) {
     const int piece = (cc * 8 + xcd) * 2 + (it - chunk_begin64(cc, sc.units, sc.W) / nkt);
-    m = fmaxf(m, *(const float*)(base + (long)piece * PART64_BYTES + ml_off));
+    return base + (long)piece * PART64_BYTES;
+  };
+  f16x4 v[16], vn[16];
+  f32x2 ml, mln = {0.f, 0.f};
+  int cc = next_chunk(c);
+  {
+    const char* pp = piece_ptr(cc);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = *(const f16x4*)(pp + o_off + i * 512);
+    ml = *(const f32x2*)(pp + ml_off);
   }
   float acc[16][4];
 #pragma unroll
   for (int i = 0; i < 16; ++i)
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[i][e] = 0.f;
-  float wsum = 0.f;
-  for (int cc = c; cc < sc.W && chunk_begin64(cc, sc.units, sc.W) < u1; ++cc) {
-    if (chunk_begin64(cc + 1, sc.units, sc.W) == chunk_begin64(cc, sc.units, sc.W)) continue;
-    const int piece = (cc * 8 + xcd) * 2 + (it - chunk_begin64(cc, sc.units, sc.W) / nkt);
-    const char* pp = base + (long)piece * PART64_BYTES;
-    f16x4 v[16];
+  float wsum = 0.f, m = -INFINITY;
+  for (;;) {
+    const int nx = next_chunk(cc + 1);
+    if (nx >= 0) {
+      const char* pp = piece_ptr(nx);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = *(const f16x4*)(pp + (((wave * 2 + qb) * 16 + i) * 64 + lane) * 8);
-    const f32x2 ml = *(const f32x2*)(pp + ml_off);
-    const float w = ml[1] * __builtin_amdgcn_exp2f(ml[0] - m);
-    wsum += w;
+      for (int i = 0; i < 16; ++i) vn[i] = *(const f16x4*)(pp + o_off + i * 512);
+      mln = *(const f32x2*)(pp + ml_off);
+    }
+    const float m_new = fmaxf(m, ml[0]);
+    const float keep = __builtin_amdgcn_exp2f(m - m_new);          // 0 on the first piece (m = -inf), 1 while the maximum stands
+    const float w = ml[1] * __builtin_amdgcn_exp2f(ml[0] - m_new);
+    m = m_new;
+    wsum = wsum * keep + w;
 #pragma unroll
     for (int i = 0; i < 16; ++i)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc[i][e] += w * (float)v[i][e];
+      for (int e = 0; e < 4; ++e) acc[i][e] = acc[i][e] * keep + w * (float)v[i][e];
+    if (nx < 0) break;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = vn[i];
+    ml = mln;
+    cc = nx;
   }
+  const int id = sc.start + sc.rounds * sc.W + it;
+  const int qb_i = id % a.qblocks, bh = id / a.qblocks;
+  const int h = bh % a.H, b = bh / a.H;
   const int q = qb_i * QB + wave * QW + qb * 32 + lq;
   if (q < a.L) {
     const float inv = 1.0f / wsum;
@@ -774,7 +797,10 @@ int vc_attention64_launch(const VcAttention& A, bool tail_split, int n_cu, uint6
   if (tail_split && !kv_len && any_tail && scratch && scratch_bytes >= vc_attention64_scratch_bytes_impl(n_cu) && worst_split + 4 < nkt) {
     a.full_rounds = a.items / G; a.tail_items = a.items - a.full_rounds * G; a.tail_units = a.tail_items * nkt;
     hipLaunchKernelGGL(kern, dim3(G), dim3(256), LDS64, s, a);
-    hipLaunchKernelGGL(attn64_merge_kernel, dim3(2 * G), dim3(256), 0, s, a, G);
+    // XCD x has (items / 8 [+ 1]) % (G / 8) tail items: 16 blocks (8 XCDs x 2 query blocks) per tail slot that any XCD fills
+    const int W = G >> 3, qn = a.items >> 3, rn = a.items & 7;
+    const int tail_slots = std::max(rn ? (qn + 1) % W : 0, qn % W);
+    hipLaunchKernelGGL(attn64_merge_kernel, dim3(16 * tail_slots), dim3(256), 0, s, a, G);
   } else {
     hipLaunchKernelGGL(kern, dim3(std::min(a.items, G)), dim3(256), LDS64, s, a);
   }

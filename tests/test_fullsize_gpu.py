@@ -441,6 +441,8 @@ def test_full_depth_on_the_large_geometries_vs_oracle(procedural_full_model, geo
     spec = importlib.util.spec_from_file_location("fdt", os.path.join(os.path.dirname(TIMES_FIXTURE), "make_fulldepth_times.py"))
     FD = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(FD)
+    if not os.path.exists(path):
+        pytest.skip(f"{os.path.basename(path)} not generated (tests/golden/make_fulldepth_times.py --geom {geom}, ~40 min of CPU)")
     fx = np.load(path)
     inp = FD.geom_inputs(geom)
     assert float(fx["x_sum"]) == inp["x"].double().sum().item()

@@ -324,16 +324,25 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
       VC_PHASE_STAMP(1);
       if (grp == 1) bar();
       int ws = 0;                                       // W slot of tile kt
+#ifdef VC_GEMM_NO_LDSREAD   // analysis builds only (tools/gemm_power.py): the fragments of K-slice 0 feed every MFMA
+      bf16x8 af[MI], bfr[NI];
+#endif
       for (int kt = 0; kt < nk; ++kt) {
         const char* base_a = smem + (kt & 1) * A_BYTES;
         const char* base_b = smem + wslot(ws) - A_BYTES;                 // b_rd already carries +A_BYTES
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
+#ifdef VC_GEMM_NO_LDSREAD
+          if (kt == 0 && kk == 0)
+#else
           bf16x8 af[MI], bfr[NI];
+#endif
+          {
 #pragma unroll
-          for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(base_a + ((a_rd + i * 16 * 128) ^ (kk * 64)));
+            for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(base_a + ((a_rd + i * 16 * 128) ^ (kk * 64)));
 #pragma unroll
-          for (int j = 0; j < NI; ++j) bfr[j] = *(const bf16x8*)(base_b + ((b_rd + j * 16 * 128) ^ (kk * 64)));
+            for (int j = 0; j < NI; ++j) bfr[j] = *(const bf16x8*)(base_b + ((b_rd + j * 16 * 128) ^ (kk * 64)));
+          }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           bar();
 #ifdef VC_GEMM_NO_MFMA

@@ -9,7 +9,10 @@ on random and on zero operands.  Energy per launch = average socket power x time
 builds price the three streams of the loop (matrix pipe, L2 -> LDS, LDS -> registers) in joules, which is the unit the
 power-limited board trades for time.
 
-    python tools/gemm_power.py [main nomfma nodma noldsread] [--seconds 4]"""
+    python tools/gemm_power.py [main nomfma nodma noldsread] [--seconds 4]
+
+--attention does the same for the attention launch of cfg 2 (variant 12, bounded logits) and the elimination builds of
+attention64.hip (VC_A64_NO_MFMA / NO_SOFTMAX / NO_LDS / NO_DMA -> `a64nomfma a64nosoftmax a64nolds a64nodma`)."""
 import argparse
 import ctypes as C
 import os
@@ -77,14 +80,40 @@ def loop(fn, seconds):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("builds", nargs="*", default=["main", "nomfma", "nodma", "noldsread"])
+    ap.add_argument("builds", nargs="*", default=None)
     ap.add_argument("--seconds", type=float, default=4.0)
+    ap.add_argument("--attention", action="store_true")
     a = ap.parse_args()
+    if a.builds is None or not a.builds:
+        a.builds = ["main", "a64nomfma", "a64nosoftmax", "a64nolds", "a64nodma"] if a.attention else ["main", "nomfma", "nodma", "noldsread"]
     hip.require_gpu()
     dev = "cuda:0"
     L, D = 3968, 3072
     g = torch.Generator(device=dev).manual_seed(0)
     rnd = lambda *s, sc=1.0: (torch.randn(*s, device=dev, generator=g) * sc).to(torch.bfloat16)
+    if a.attention:
+        time.sleep(2.0)
+        idle = smi()
+        print(f"idle: {idle[0]:.0f} W, {idle[1]:.0f} MHz", flush=True)
+        H = 24
+        for data in ("random", "zero"):
+            # q, k as the QKNorm leaves them (unit-RMS rows): |logit| <= sqrt(128) * log2(e) ... the bounded-softmax form applies
+            qkv = rnd(L, 3 * D) if data == "random" else torch.zeros(L, 3 * D, dtype=torch.bfloat16, device=dev)
+            vt = rnd(H, 128, L) if data == "random" else torch.zeros(H, 128, L, dtype=torch.bfloat16, device=dev)
+            o = torch.empty(L, D, dtype=torch.bfloat16, device=dev)
+            rows = {}
+            for name in a.builds:
+                hip._lib = load(name)
+                us, w, mhz, ns = loop(lambda: hip.attention(qkv, vt, o, L, H, variant=12, logit_bound=60.0), a.seconds)
+                rows[name] = (us, w, mhz)
+                print(f"attention L=3968 H=24 {data:6s} {name:13s}: {us:7.1f} us/launch  {w:6.0f} W  {mhz:5.0f} MHz  "
+                      f"{us * w * 1e-6:.4f} J/launch  ({us * (w - idle[0]) * 1e-6:.4f} J above idle; {ns} samples)", flush=True)
+                time.sleep(1.0)
+            if all(k in rows for k in ("main", "a64nomfma", "a64nosoftmax", "a64nolds", "a64nodma")):
+                e = {k: v[0] * (v[1] - idle[0]) * 1e-6 for k, v in rows.items()}
+                print(f"  -> above-idle energy per launch: all {e['main']:.4f} J; matrix pipe ~ {e['main'] - e['a64nomfma']:.4f}; softmax VALU ~ "
+                      f"{e['main'] - e['a64nosoftmax']:.4f}; fragment reads ~ {e['main'] - e['a64nolds']:.4f}; LDS-DMA ~ {e['main'] - e['a64nodma']:.4f}", flush=True)
+        return
     shapes = {   # name: (K, N, epilogue)
         "GATE_RES K=12288 N=3072": (4 * D, D, hip.EPI_GATE_RES),
         "BIAS     K=3072  N=9216": (D, 3 * D, hip.EPI_BIAS),

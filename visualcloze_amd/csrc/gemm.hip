@@ -22,6 +22,10 @@
 namespace {
 
 constexpr int BK = 64;
+// raster: ids walk GROUP_M m-tiles, then the n-tiles (an XCD's 32 resident workgroups = GROUP_M x 32/GROUP_M tiles)
+#ifndef VC_GEMM_GROUP_M
+#define VC_GEMM_GROUP_M 8
+#endif
 
 // CONV (loader-wave schedule only): the A operand is the im2col matrix of a 3x3 convolution over an NHWC map, gathered
 // on the fly by the loader waves - K-tile kt lies inside tap kt*64 / C, row m is output pixel (m / W, m % W), out-of-
@@ -87,7 +91,7 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
     Tile t;
     t.P = pi == 3 ? args.p[3] : pi == 2 ? args.p[2] : pi == 1 ? args.p[1] : args.p[0];
     id -= t.P.tile_start;
-    constexpr int GROUP_M = 8;
+    constexpr int GROUP_M = VC_GEMM_GROUP_M;
     const int in_group = GROUP_M * t.P.tiles_n;
     const int group = id / in_group;
     const int first_m = group * GROUP_M;

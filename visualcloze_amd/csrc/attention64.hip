@@ -563,6 +563,8 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
         if constexpr (g == 16) wait_lgkm<0>();      // V^T fragments 8..15 (and the K fragments issued so far)
 #ifndef VC_A64_NO_MFMA
         mfma_pv<A_O + (qb * 4 + dt) * 16>(vf[(dt & 1) * 4 + s], P[qb][s]);
+#else     // the asynchronous ds_read results stay live up to here (a dead output register would be reused while the read is in flight)
+        asm volatile("" ::"v"(vf[(dt & 1) * 4 + s]), "v"(P[qb][s]));
 #endif
 #ifndef VC_A64_NO_SOFTMAX
         // S(kt+1) was completed by the last MFMAs of phase A: its first VALU read comes two MFMA gaps later

@@ -4,6 +4,7 @@ D = 3072 / H = 24 / T = 512 with 1 DoubleStreamBlock + 1 SingleStreamBlock and L
 
     cfg2    384-grid 2x3   N = 3456  L = 3968   30 solver points = 29 evaluations, shifted grid      (transport.py:361-410)
     sdedit  1024^2 target  N = 4096  L = 4608   10 points from strength 0.4, no shift = 9 evaluations (visualcloze.py:184-234)
+    cfg5    384-grid 3x4   N = 6912  L = 7424   30 points, shifted grid; only with --only cfg5 -> fullwidth_traj_cfg5.npz
 
 For each: the bf16 / merged-LoRA oracle (same rounding points as the HIP path; bf16 state as visualcloze.py:399) and the
 fp32 / un-merged oracle (exact reference semantics) -> tests/golden/fullwidth_traj.npz: final latents, a few intermediate
@@ -29,9 +30,12 @@ from tests.procedural import procedural_param, ptensor  # noqa: E402
 
 T = 512
 TOKEN_STRIDE = 8
-CASES = {
-    "cfg2": dict(rows=2, row_latent=(48, 144), points=30, do_shift=True, strength=None, keep=(1, 10, 20, 29)),
-    "sdedit": dict(rows=1, row_latent=(128, 128), points=10, do_shift=False, strength=0.4, keep=(1, 5, 9)),
+CASES = {      # seed: base of the procedural input draws (fixed per case, so that adding a case moves no other)
+    "cfg2": dict(rows=2, row_latent=(48, 144), points=30, do_shift=True, strength=None, keep=(1, 10, 20, 29), seed=1000),
+    "sdedit": dict(rows=1, row_latent=(128, 128), points=10, do_shift=False, strength=0.4, keep=(1, 5, 9), seed=1010),
+    # the largest BASELINE geometry (384-grid 3x4, N = 6912, L = 7424): its own file, final state every 2nd token
+    "cfg5": dict(rows=3, row_latent=(48, 192), points=30, do_shift=True, strength=None, keep=(1, 15, 29), seed=1020,
+                 file="fullwidth_traj_cfg5.npz", final_stride=2),
 }
 
 
@@ -49,7 +53,7 @@ def inputs(case):
     h, w = c["row_latent"]
     ids = O.grid_img_ids([(h, w)] * c["rows"])
     N = ids.shape[0]
-    seed = 1000 + sorted(CASES).index(case) * 10
+    seed = c["seed"]
     x = ptensor((1, N, 64), seed + 1, q=6)
     cond = torch.cat([ptensor((1, N, 64), seed + 2, q=6), (ptensor((1, N, 256), seed + 3, q=0, kmax=1).abs() > 0.5).float()], -1)
     return dict(x=x, cond=cond, img_ids=ids[None], txt=ptensor((1, T, 4096), seed + 4, q=6), txt_ids=torch.zeros(1, T, 3),
@@ -68,16 +72,15 @@ def main():
     sd = {k: procedural_param(k, s, device="cpu").to(torch.bfloat16).float() for k, s in key_shapes()}
     print(f"procedural weights: {sum(v.numel() for v in sd.values()) / 1e6:.0f} M parameters in {time.time() - t0:.0f} s", flush=True)
     G = O.FluxGeometry(depth=1, depth_single_blocks=1)
-    out = {}
-    path = os.path.join(HERE, "fullwidth_traj.npz")
-    if a.only and os.path.exists(path):
-        out.update(np.load(path))
+    default_cases = [k for k, c in CASES.items() if "file" not in c]        # fullwidth_traj.npz; the others on request
     # both modes see the SAME guidance value (an f32 guidance tensor: 1000 * g = 30000 exactly; a bf16 one would round to
     # 29952 in the bf16 mode only, and the bf16-vs-fp32 floor is meant to hold arithmetic noise, not an input difference)
     orig = O.compute_vec
     O.compute_vec = lambda *a, **k: orig(*a, **{**k, "guidance_is_bf16": False})
-    for case in ([a.only] if a.only else list(CASES)):
+    for case in ([a.only] if a.only else default_cases):
         c, inp = CASES[case], inputs(case)
+        path = os.path.join(HERE, c.get("file", "fullwidth_traj.npz"))
+        out = dict(np.load(path)) if os.path.exists(path) else {}
         N = inp["x"].shape[1]
         t = O.time_grid(c["points"], N, c["do_shift"], 1 if c["do_shift"] else 1.0, c["strength"])
         if a.evals:
@@ -103,11 +106,12 @@ def main():
             assert torch.equal(b.to(torch.bfloat16).float(), b)                    # bf16-mode states are bf16 values
             # kept small: the FINAL state whole, intermediate states every TOKEN_STRIDE-th token; the fp32 oracle's states
             # stored as float16 (2e-4 rel-L2 against floors >= 2.6e-3)
-            sl = slice(None) if k == keep[-1] else slice(None, None, TOKEN_STRIDE)
+            sl = slice(None, None, c.get("final_stride", 1)) if k == keep[-1] else slice(None, None, TOKEN_STRIDE)
             out[f"{case}_bf16_{k}"] = b[:, sl].to(torch.bfloat16).view(torch.int16).numpy()
             out[f"{case}_fp32_{k}"] = f[:, sl].numpy().astype(np.float16)
             print(f"  state {k}: oracle bf16-vs-fp32 rel-L2 {((b - f).norm() / f.norm()).item():.3e}", flush=True)
         out["token_stride"] = np.int32(TOKEN_STRIDE)
+        out[f"{case}_final_stride"] = np.int32(c.get("final_stride", 1))
         np.savez_compressed(path, **out)
         print("wrote", path, os.path.getsize(path), "bytes", flush=True)
 

@@ -594,6 +594,61 @@ def test_graph_replay_with_device_step_counter(hip):
             check(out, R.gemm_ref(a, w, bias, 2, res, gates[i]))
 
 
+def test_attention_randomised_sweep(hip):
+    """Seeded sweep over what the parametrised cases do not enumerate: L off every tile size (1 ... 2600), 1-5 heads, batches
+    of 1-3 samples with PER-SAMPLE key padding and per-sample masked gaps (gaps that start at key 0, end at kv_len, cover
+    whole tiles or sit inside one), row strides wider than 3 H 128, on the 32-queries-per-wave kernel (variant 3), the
+    one-wave-per-SIMD kernel (12 = with tail split, 8 = without) and its bounded-logit form - each against the f32 torch
+    softmax over the live keys (math.py:9-60: masked keys get no weight, masked query rows come back as zeros)."""
+    g = torch.Generator().manual_seed(77)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))  # noqa: E731
+    for it in range(18):
+        L = ri(1, 160) if it % 3 == 0 else ri(161, 2600)
+        H, B, extra = ri(1, 5), ri(1, 3), 8 * ri(0, 4) * (it % 2)
+        ld = 3 * H * 128 + extra
+        x = torch.randn(B * L, 3, H, 128, generator=g)
+        x[:, :2] = x[:, :2] / x[:, :2].pow(2).mean(-1, keepdim=True).sqrt()      # |q| = |k| = sqrt(128), as after QKNorm
+        qkv = torch.zeros(B * L, ld, dtype=torch.bfloat16, device=DEV)
+        qkv[:, :3 * H * 128] = x.reshape(B * L, 3 * H * 128).to(torch.bfloat16).to(DEV)
+        xr = qkv[:, :3 * H * 128].float().reshape(B, L, 3, H, 128)
+        Lpad = (L + 63) // 64 * 64
+        vt = torch.zeros(B, H, 128, Lpad, dtype=torch.bfloat16, device=DEV)
+        vt[:, :, :, :L] = xr[:, :, 2].permute(0, 2, 3, 1).to(torch.bfloat16)
+        masked = it % 4 != 0
+        kvl = gp = None
+        live = torch.ones(B, L, dtype=torch.bool, device=DEV)
+        if masked:
+            kv = [ri(max(1, L // 2), L) for _ in range(B)]
+            gaps = []
+            for b in range(B):
+                lo = 0 if ri(0, 2) == 0 else ri(0, kv[b] - 1)
+                hi = kv[b] if ri(0, 5) == 0 and lo > 0 else ri(lo, min(kv[b], lo + ri(0, 300)))
+                if hi - lo >= kv[b]:           # never mask every key of a sample
+                    hi = lo
+                gaps.append([lo, hi])
+                live[b, kv[b]:] = False
+                live[b, lo:hi] = False
+            kvl = torch.tensor(kv, dtype=torch.int32, device=DEV)
+            gp = torch.tensor(gaps, dtype=torch.int32, device=DEV) if it % 4 != 1 else None
+            if gp is None:
+                live[:] = True
+                for b in range(B):
+                    live[b, kv[b]:] = False
+        s = torch.einsum("bqhd,bkhd->bhqk", xr[:, :, 0], xr[:, :, 1]) * 128 ** -0.5
+        bound = float(s.abs().max()) * 1.4426950408889634 * 1.01
+        s = s.masked_fill(~live[:, None, None, :], float("-inf"))
+        ref = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s, -1), xr[:, :, 2]).reshape(B, L, H * 128)
+        ref = (ref * live[:, :, None]).reshape(B * L, H * 128)
+        for variant, lb in ((3, 0.0), (8, 0.0), (12, 0.0), (12, bound)):
+            out = torch.full((B * L, H * 128), float("nan"), dtype=torch.bfloat16, device=DEV)
+            hip.attention(qkv, vt, out, L, H, kv_len=kvl, variant=variant, B=B, kv_gap=gp, logit_bound=lb)
+            torch.cuda.synchronize()
+            assert torch.isfinite(out.float()).all(), (it, L, H, B, variant, lb)
+            err = ((out.float() - ref).norm() / ref.norm()).item()
+            assert err < 1e-2, (it, L, H, B, variant, lb, err)
+            assert float(out.reshape(B, L, -1)[~live].float().abs().sum()) == 0.0, (it, L, H, B, variant)
+
+
 def test_gemm_randomised_shape_sweep(hip):
     """Seeded sweep over ragged shapes for the two tiles the cost model picks (128x128, 256x192 + loader waves): M not a
     multiple of any tile, N only a multiple of 8 (bias / staging slices that end mid-tile), K = 64 ... 1024 (1 to 16

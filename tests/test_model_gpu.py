@@ -198,6 +198,47 @@ def test_bounded_softmax_is_a_property_of_the_norm_scales(model, golden):
     assert rel_l2(a, golden["flux_b1"]) < TOL_GOLDEN and rel_l2(b, golden["flux_b1"]) < TOL_GOLDEN
 
 
+def test_forward_randomised_geometry_sweep_vs_oracle():
+    """Seeded sweep over input geometries the fixtures do not hold: 1-3 grid rows of unequal latent sizes (N = 1 ... ~190
+    image tokens, off every tile size), T = 1 ... 70 text tokens, batches of 1-3 with per-sample timesteps, right-padded
+    masks, masks with holes in both streams, and a sample without text - every one re-plans the engine (buffers, RoPE table,
+    mask layout, attention schedule).  Each evaluation against the bf16-merged oracle on the same inputs."""
+    import oracle.flux_oracle as O
+    from tests.helpers import parity_log, tiny_model
+    from tests.procedural import tiny_inputs
+    m, sd = tiny_model()
+    g = torch.Generator().manual_seed(5)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))  # noqa: E731
+    worst = 0.0
+    for it in range(12):
+        rows = tuple((2 * ri(1, 4), 2 * ri(1, 12)) for _ in range(ri(1, 3)))
+        T, B = (1 if it == 3 else ri(2, 70)), ri(1, 3)
+        inp = tiny_inputs(B=B, rows_hw=rows, T=T, seed=100 + it)
+        N = inp["x"].shape[1]
+        kind = it % 4
+        if kind == 1:                                   # right-padded, as models/sampling.py pads a ragged batch
+            for b in range(B):
+                inp["txt_mask"][b, ri(1, T):] = 0
+                inp["img_mask"][b, ri(1, N):] = 0
+        elif kind == 2:                                 # holes anywhere (at least one live token per stream)
+            for b in range(B):
+                inp["txt_mask"][b] = (torch.rand(T, generator=g) > 0.3).int()
+                inp["img_mask"][b] = (torch.rand(N, generator=g) > 0.2).int()
+                inp["txt_mask"][b, ri(0, T - 1)] = 1
+                inp["img_mask"][b, ri(0, N - 1)] = 1
+        elif kind == 3 and B > 1:                       # one sample without any text
+            inp["txt_mask"][B - 1] = 0
+        t = torch.rand(B, generator=g) * 0.98 + 0.01
+        got = _fwd(m, inp, t).float().cpu()
+        ref = _oracle(sd, inp, t)
+        assert got.shape == ref.shape and torch.isfinite(got).all(), (it, rows, T, B)
+        live = inp["img_mask"].bool()
+        e = rel_l2(got[live], ref[live])                # (rows of masked image tokens carry no meaning in either implementation)
+        worst = max(worst, e)
+        assert e < TOL_ORACLE, (it, rows, T, B, kind, e)
+    parity_log(f"[tiny, 12 random geometries / masks] worst Flux.forward rel-L2 vs bf16 oracle {worst:.3e}")
+
+
 def test_sampler_general_masks_vs_oracle():
     """The fused sampler keeps the state in kernel row order across the steps and scatters back at the end: against the
     oracle's bf16 sampler on masks with holes in both streams, and against host-driven stepping through Flux.forward."""

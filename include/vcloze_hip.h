@@ -21,7 +21,7 @@ extern "C" {
 #define VC_ERR_HIP (-2)
 #define VC_ERR_STATE (-3)
 
-#define VC_ABI_VERSION 6
+#define VC_ABI_VERSION 7
 int vc_abi_version(void);
 const char* vc_last_error(void);
 /* sizeof(VcGemmProblem), sizeof(VcGemmArgs), sizeof(VcLnStream), sizeof(VcAttention), sizeof(VcFluxConfig),
@@ -90,7 +90,17 @@ typedef struct VcGemmArgs {
   const int32_t* step_ptr;  /* optional device step counter: gate += *step_ptr * gate_step_stride */
   int64_t gate_step_stride;
   uint64_t* debug_ts;       /* NULL in production; profiling: per-segment s_memtime stamps of block 0 (tools/) */
+  /* Split-K remainder (ABI 7).  splitk_ws: optional f32 scratch of splitk_ws_bytes >= VC_GEMM_SPLITK_WS_BYTES in device
+   * memory, NULL = never split.  With it, an auto-tiled call (tile_cfg 0) whose 256x192 tiles are R whole rounds of the CUs
+   * plus a remainder of r tiles may run the remainder as r * S work items of K / S each (S <= 8, r * S <= CUs), which leave
+   * f32 partial tiles in the scratch; a second, HBM-bound launch sums the S partials of each tile in a fixed order and applies
+   * the epilogue (bias, GELU / SiLU / gate + residual) - bit-reproducible (static assignment), equal to the one-pass kernel up
+   * to f32 summation order.  Not for VC_EPI_QKV.  sk_*: filled by the launcher. */
+  void* splitk_ws;
+  int64_t splitk_ws_bytes;
+  int32_t sk_full, sk_rem, sk_S, sk_pad_;
 } VcGemmArgs;
+#define VC_GEMM_SPLITK_WS_BYTES (256LL * 256 * 192 * 4)   /* one 256x192 f32 tile per work item of one round of 256 CUs */
 
 /* Replaces torch.nn.functional.linear (+ fused neighbours) on the hot path.
  * tile_cfg: 0 = chosen by the launcher's cost model (what the product path passes); a fixed tile for tests and A/B runs:
@@ -100,8 +110,13 @@ typedef struct VcGemmArgs {
  * number of rounds of the 256 CUs, the rows of problem 0 are cut at a multiple of 256 so that the first launch is exact
  * rounds and the remainder runs on the tile shape that suits it (block-round quantisation: e.g. M = 6656, N = 3072 is
  * 416 tiles = 2 rounds at 81 % fill, or 256 tiles + 240 narrower ones).  Results do not depend on the cut.
- * VC_GEMM_NO_SPLIT (64) as tile_cfg keeps it one launch; (k << 8) forces the cut at row k * 256 (tests). */
+ * VC_GEMM_NO_SPLIT (64) as tile_cfg keeps it one launch; (k << 8), k <= 255, forces the cut at row k * 256 (tests).
+ * VC_GEMM_SPLITK(S) (S << 16, 2 <= S <= 8; tests and A/B runs) forces the 256x192 loader-wave tile with the tiles beyond the
+ * last whole round of the CUs (all tiles when there is no whole round) cut S ways along K (needs splitk_ws);
+ * VC_GEMM_NO_SPLITK keeps an auto-tiled call from doing so. */
 #define VC_GEMM_NO_SPLIT 64
+#define VC_GEMM_SPLITK(S) ((S) << 16)
+#define VC_GEMM_NO_SPLITK (1 << 20)
 /* VC_GEMM_PERSIST (128) added to tile_cfg: a launch with more tiles than CUs on a loader-wave tile runs as ONE persistent
  * workgroup per CU that walks the tiles of its XCD's strip and fetches the next tile's first operands during the current
  * tile's epilogue (same results bit for bit; not for VC_EPI_GATE_RES).  Opt-in: measured neutral on MI355X (+0.05 % steps/s;
@@ -110,8 +125,9 @@ typedef struct VcGemmArgs {
 int vc_gemm(const VcGemmArgs* args, int tile_cfg, void* stream);
 /* The plan vc_gemm would execute for these arguments, without launching anything (works without a GPU): out[0] = first row
  * of the second launch (0 = a single launch), out[1], out[2] = tile number (1..5 as above) and main-loop form (0 plain,
- * 1 ping-pong, 2 loader waves) of the first or only launch, out[3], out[4] = of the second, out[5] = tiles of both. */
-int vc_gemm_plan(const VcGemmArgs* args, int tile_cfg, int32_t out[6]);
+ * 1 ping-pong, 2 loader waves) of the first or only launch, out[3], out[4] = of the second, out[5] = tiles of both,
+ * out[6] = split-K factor S of the remainder tiles (0 = none), out[7] = how many tiles are split. */
+int vc_gemm_plan(const VcGemmArgs* args, int tile_cfg, int32_t out[8]);
 
 /* LayerNorm(eps=1e-6, no affine) + AdaLN modulate: y = bf16((1+scale)*LN(x) + shift).
  * Replaces layers.py:163-164,191,195,234 / 257.  x,y: [rows, D] bf16 (row strides ldx/ldy);

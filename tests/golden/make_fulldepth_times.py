@@ -66,10 +66,39 @@ def geom_inputs(geom):
                 img_mask=torch.ones(1, N, dtype=torch.int32), guidance=torch.full((1,), 30.0))
 
 
+def trajectory(K, sd, G, inp):
+    """K consecutive full-depth evaluations with the state fed back (transport/integrators.py:99-120 through oracle.sample_euler):
+    the one combination the other fixtures leave open - trajectories are 1 + 1 blocks, full depth is single evaluations."""
+    t = O.time_grid(30, inp["x"].shape[1], True, 1)[:K + 1]
+    out = {"x_sum": np.float64(inp["x"].double().sum().item()), "t": t.numpy(), "token_stride": np.int32(1)}
+    res = {}
+    for tag, P in (("bf16", O.Prec("bf16", "merged")), ("fp32", O.Prec("fp32", "ref"))):
+        def model_fn(xin, tm, P=P):
+            t1 = time.time()
+            y = O.flux_forward(sd, G, xin, inp["img_ids"], inp["txt"], inp["txt_ids"], tm, inp["y"], inp["txt_mask"], inp["img_mask"],
+                               inp["guidance"], P=P)
+            print(f"  {tag} evaluation at t = {float(tm[0]):.6f}: {time.time() - t1:.0f} s", flush=True)
+            return y
+        with torch.no_grad():
+            states, evals = O.sample_euler(model_fn, P.r(inp["x"]), P.r(inp["cond"]), t, P)
+        res[tag] = states
+        out[f"{tag}_model_t"] = np.asarray(evals, np.float64)
+    for k in range(1, K + 1):
+        b, f = res["bf16"][k], res["fp32"][k]
+        assert torch.equal(b.to(torch.bfloat16).float(), b)
+        out[f"bf16_{k}"] = b.to(torch.bfloat16).view(torch.int16).numpy()
+        out[f"fp32_{k}"] = f.numpy().astype(np.float16)
+        print(f"state {k}: oracle bf16-vs-fp32 rel-L2 {((b - f).norm() / f.norm()).item():.3e}", flush=True)
+    np.savez_compressed(os.path.join(HERE, "fulldepth_traj_oracle.npz"), **out)
+    print("wrote fulldepth_traj_oracle.npz", flush=True)
+
+
 def main():
     import argparse
     ap = argparse.ArgumentParser()
     ap.add_argument("--geom", default=None, choices=sorted(GEOMS), help="instead of cfg 2's two grid ends: this geometry at t = 0.62")
+    ap.add_argument("--traj", type=int, default=0, help="instead: the first K solver steps of cfg 2's 30-point grid through the full-depth "
+                    "model with the state FED BACK (fixed-grid Euler, each mode steps its own state) -> fulldepth_traj_oracle.npz")
     a = ap.parse_args()
     spec = importlib.util.spec_from_file_location("ft", os.path.join(HERE, "make_fullwidth_traj.py"))
     FT = importlib.util.module_from_spec(spec)
@@ -94,6 +123,8 @@ def main():
     # 29952 in the bf16 mode only, and the bf16-vs-fp32 floor is meant to hold arithmetic noise, not an input difference)
     orig = O.compute_vec
     O.compute_vec = lambda *a, **k: orig(*a, **{**k, "guidance_is_bf16": False})
+    if a.traj:
+        return trajectory(a.traj, sd, G, inp)
     for i, t in enumerate(times):
         for tag, P in (("bf16", O.Prec("bf16", "merged")), ("fp32", O.Prec("fp32", "ref"))):
             t1 = time.time()

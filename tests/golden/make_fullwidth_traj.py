@@ -5,6 +5,7 @@ D = 3072 / H = 24 / T = 512 with 1 DoubleStreamBlock + 1 SingleStreamBlock and L
     cfg2    384-grid 2x3   N = 3456  L = 3968   30 solver points = 29 evaluations, shifted grid      (transport.py:361-410)
     sdedit  1024^2 target  N = 4096  L = 4608   10 points from strength 0.4, no shift = 9 evaluations (visualcloze.py:184-234)
     cfg5    384-grid 3x4   N = 6912  L = 7424   30 points, shifted grid; only with --only cfg5 -> fullwidth_traj_cfg5.npz
+    cfg5_50 the same geometry and inputs, BASELINE's own 50 points = 49 evaluations; --only cfg5_50 -> fullwidth_traj_cfg5_50.npz
 
 For each: the bf16 / merged-LoRA oracle (same rounding points as the HIP path; bf16 state as visualcloze.py:399) and the
 fp32 / un-merged oracle (exact reference semantics) -> tests/golden/fullwidth_traj.npz: final latents, a few intermediate
@@ -36,6 +37,9 @@ CASES = {      # seed: base of the procedural input draws (fixed per case, so th
     # the largest BASELINE geometry (384-grid 3x4, N = 6912, L = 7424): its own file, final state every 2nd token
     "cfg5": dict(rows=3, row_latent=(48, 192), points=30, do_shift=True, strength=None, keep=(1, 15, 29), seed=1020,
                  file="fullwidth_traj_cfg5.npz", final_stride=2),
+    # BASELINE cfg 5 as it is quoted: 50 solver points = 49 evaluations (mu = 1.62667) on the same geometry and inputs
+    "cfg5_50": dict(rows=3, row_latent=(48, 192), points=50, do_shift=True, strength=None, keep=(1, 25, 49), seed=1020,
+                    file="fullwidth_traj_cfg5_50.npz", final_stride=2),
 }
 
 

@@ -192,7 +192,19 @@ def test_handle_error_behaviour(model):
     fh.prepare(kw["txt"], kw["y"], kw["guidance"], False, kw["img_ids"], kw["txt_ids"], 2)
     fh.forward(img, torch.tensor([0.5]), False, out)
     torch.cuda.synchronize()
+    # a handle built DIRECTLY over head-permuted weights reads qkv_heads from them (advisor r03: it used to default to 0 and
+    # scatter q/k/v into scrambled columns); with the engine's other options - qkv_heads omitted - same bits as the model's own
     assert torch.isfinite(out.float()).all()
+    e = m.engine()
+    fh.set_options(e.attn_variant, e.tile_cfg, e.fuse_qnorm, e.fuse_vt, None, e.fuse_knorm,
+                   e.W.logit_bound if e.bounded_softmax else 0.0, e.mlp_first, e.splitk)
+    fh.prepare(kw["txt"], kw["y"], kw["guidance"], False, kw["img_ids"], kw["txt_ids"], 2)
+    fh.forward(img, torch.tensor([0.5]), False, out)
+    torch.cuda.synchronize()
+    want = m.forward(img, kw["img_ids"], kw["txt"], kw["txt_ids"], torch.tensor([0.5], device=DEV), kw["y"], guidance=kw["guidance"])
+    assert m.engine().W.qkv_heads > 0 and torch.equal(out, want.to(out.dtype))
+    with pytest.raises(hip.VclozeHipError, match="follows the weights"):
+        fh.set_options(qkv_heads=0)
 
 
 def test_step_graph_cache_eviction_and_recapture(model):

@@ -30,7 +30,7 @@ def test_abi_exports_every_declared_symbol():
 def test_struct_layout_matches_header():
     from visualcloze_amd import hip
     assert ctypes.sizeof(hip.GemmProblem) == 9 * 8 + 9 * 8 + 16 * 4       # 9 pointers, 9 int64, 16 int32 (incl. the V^T and key-norm fields)
-    assert ctypes.sizeof(hip.GemmArgs) == 4 * ctypes.sizeof(hip.GemmProblem) + 8 + 8 + 8 + 8
+    assert ctypes.sizeof(hip.GemmArgs) == 4 * ctypes.sizeof(hip.GemmProblem) + 8 + 8 + 8 + 8 + 8 + 8 + 4 * 4   # + splitk_ws, its size, sk_* (ABI 7)
     assert ctypes.sizeof(hip.FluxConfig) == 14 * 4
     assert ctypes.sizeof(hip.FluxInputs) == 4 * 4 + 7 * 8 + 2 * 4
     # the library reports the same sizes (and hip.lib() refuses to load one that does not)
@@ -187,18 +187,20 @@ def test_gemm_launch_plans_for_the_flux_shapes():
     from visualcloze_amd import hip
     L = hip.lib()
 
-    def plan(Ms, N, K, epi=0, tile_cfg=0):
+    def plan(Ms, N, K, epi=0, tile_cfg=0, sk=False, n=6):
         a = hip.GemmArgs()
         a.nprob, a.epi = len(Ms), epi
+        if sk:                                                  # a split-K scratch is on offer (never dereferenced here)
+            a.splitk_ws, a.splitk_ws_bytes = 0x1000, hip.GEMM_SPLITK_WS_BYTES
         for i, M in enumerate(Ms):
             p = a.p[i]
             p.A = p.W = p.C = p.res = p.gate = 0x1000          # never dereferenced by the planner
             p.lda, p.ldw, p.ldc, p.ldres = K, K, N, N
             p.M, p.N, p.K, p.rows_per_batch = M, N, K, M
-        out = (C.c_int32 * 6)()
+        out = (C.c_int32 * 8)()
         rc = L.vc_gemm_plan(C.byref(a), tile_cfg, out)
         assert rc == 0, L.vc_last_error()
-        return list(out)
+        return list(out)[:n]
     T = 512
     # cfg 2 (N_img = 3456): exact rounds of the 256x192 loader-wave tile, never cut
     assert plan([3456, T], 3072, 3072, 2) == [0, 4, 2, 0, 0, 256]
@@ -218,9 +220,24 @@ def test_gemm_launch_plans_for_the_flux_shapes():
     # a fixed tile is taken literally; a forced cut is obeyed
     assert plan([3968], 3072, 3072, 0, 1)[:3] == [0, 1, 0] and plan([3968], 3072, 3072, 0, 36)[:3] == [0, 4, 2]
     assert plan([3968], 3072, 3072, 0, 3 << 8)[0] == 768
+    # SPLIT-K REMAINDER (a scratch on offer): the SDEdit stage's deep-K N = 3072 launches are 288 tiles = one round of 256 + 32
+    # tiles cut 8 ways along K (256 slices: one short round) instead of 432 narrower tiles; cfg 1's are 112 tiles x 2 slices;
+    # never at K = 3072 (partial traffic outweighs 1 / S of a short tile), never where the tiles are whole rounds (cfg 2),
+    # never for the qkv epilogue; two samples per GPU at the SDEdit stage (M = 9216: 576 tiles) -> 64 tiles x 4
+    assert plan([4608], 3072, 15360, 2, sk=True, n=8) == [0, 4, 2, 0, 0, 288, 8, 32]
+    assert plan([4096, T], 3072, 12288, 2, sk=True, n=8) == [0, 4, 2, 0, 0, 288, 8, 32]
+    assert plan([4096, T], 3072, 3072, 2, sk=True, n=8)[6:] == [0, 0]
+    assert plan([1664], 3072, 15360, 2, sk=True, n=8) == [0, 4, 2, 0, 0, 112, 2, 112]
+    assert plan([1152, T], 3072, 12288, 2, sk=True, n=8) == [0, 4, 2, 0, 0, 112, 2, 112]
+    assert plan([9216], 3072, 15360, 2, sk=True, n=8) == [0, 4, 2, 0, 0, 576, 4, 64]
+    assert plan([3968], 3072, 15360, 2, sk=True, n=8) == [0, 4, 2, 0, 0, 256, 0, 0]
+    assert plan([4608], 9216, 3072, 4, sk=True, n=8)[6:] == [0, 0]
+    assert plan([4608], 3072, 15360, 2, hip.GEMM_NO_SPLITK, sk=True, n=8)[:3] + plan([4608], 3072, 15360, 2, hip.GEMM_NO_SPLITK, sk=True, n=8)[6:] == [0, 2, 2, 0, 0]
+    assert plan([4608], 3072, 15360, 2, n=8)[6:] == [0, 0]                                   # no scratch, no split
+    assert plan([777], 1024, 512, 1, hip.GEMM_SPLITK(3), sk=True, n=8) == [0, 4, 2, 0, 0, 24, 3, 24]     # forced (tests)
     # argument errors come back as codes, with a message
     a = hip.GemmArgs(); a.nprob = 1; a.p[0].M, a.p[0].N, a.p[0].K = 8, 8, 60
-    assert L.vc_gemm_plan(C.byref(a), 0, (C.c_int32 * 6)()) == -1 and b"multiple of 64" in L.vc_last_error()
+    assert L.vc_gemm_plan(C.byref(a), 0, (C.c_int32 * 8)()) == -1 and b"multiple of 64" in L.vc_last_error()
 
 
 def test_procedural_torch_equals_numpy():

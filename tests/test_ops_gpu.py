@@ -307,6 +307,90 @@ def test_gemm_four_problems_batch_strided_rows(hip):
     assert torch.equal(oi, oi2) and torch.equal(ot, ot2)
 
 
+@pytest.mark.parametrize("S", [2, 3, 8])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3])
+@pytest.mark.parametrize("M,N,K", [(300, 192, 1024), (513, 264, 576), (37, 64, 512), (4608 + 40, 3072, 512), (1, 392, 1536)])
+def test_gemm_splitk_remainder(hip, S, epi, M, N, K):
+    """VC_GEMM_SPLITK(S): the 256x192 tiles beyond the last whole round of the CUs (all of them below one round) run as S
+    K-slices that leave f32 partial tiles in the scratch; the reduce launch sums them in slice order and applies the epilogue.
+    Against torch, against the one-pass kernel (same function up to the f32 summation order: <= 1 bf16 ulp on a few elements),
+    bit-reproducible, K-slices of unequal length (nk % S != 0), partial m / n tiles, strided A, residual in place."""
+    a = rnd(M, K + 64, seed=1)[:, :K]
+    w, bias = rnd(N, K, scale=K ** -0.5, seed=2), rnd(N, seed=3)
+    gate = rnd(N, seed=5)
+    x0 = rnd(M, N, seed=4)
+    ws = hip.splitk_workspace(DEV)
+    outs = []
+    for cfg in (hip.GEMM_SPLITK(S), hip.GEMM_SPLITK(S), 36):
+        out = x0.clone() if epi == 2 else torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        p = hip.make_problem(a, w, bias, out, res=out if epi == 2 else None, gate=gate if epi == 2 else None)
+        hip.gemm(p, epi=epi, tile_cfg=cfg, splitk_ws=ws)
+        torch.cuda.synchronize()
+        outs.append(out)
+    check(outs[0], R.gemm_ref(a, w, bias, epi, x0, gate))
+    assert torch.equal(outs[0], outs[1])                      # static assignment, fixed summation order
+    d = (outs[0].float() - outs[2].float()).abs()
+    assert d.max().item() <= 2 ** -5 * outs[2].float().abs().max().item()     # vs the one-pass kernel: rounding flips only
+    if M * N > 10000:
+        assert (d > 0).float().mean().item() < 0.1
+
+
+def test_gemm_splitk_grouped_batch_strided_with_step_counter(hip):
+    """Split-K of a GROUPED launch as the DoubleStream blocks issue it: two streams of two samples, batch-strided A rows out of a
+    joint buffer, per-sample gates picked by a device step counter, residual in place - and a scratch that is too small is refused."""
+    B, Nn, T, D, NO = 2, 520, 136, 768, 192
+    L = Nn + T
+    joint = rnd(B * L, NO + 64, seed=1)[:, :NO]
+    ld = joint.stride(0)
+    w2, b2 = rnd(D, NO, scale=NO ** -0.5, seed=7), rnd(D, seed=8)
+    gates = rnd(3, B, D, seed=9)                                   # [step][sample][D]
+    step = torch.tensor([2], dtype=torch.int32, device=DEV)
+    ws = hip.splitk_workspace(DEV)
+    res = {}
+    for tag, cfg in (("sk", hip.GEMM_SPLITK(3)), ("one", 36)):
+        oi, ot = rnd(B * Nn, D, seed=10), rnd(B * T, D, seed=11)
+        oi0, ot0 = oi.clone(), ot.clone()
+        ps = [hip.make_problem(joint[T:], w2, b2, oi, res=oi, gate=gates[0], rows_per_batch=Nn, gate_bstride=D, M=B * Nn, a_rpb=Nn, a_bstride=L * ld),
+              hip.make_problem(joint[:T], w2, b2, ot, res=ot, gate=gates[0], rows_per_batch=T, gate_bstride=D, M=B * T, a_rpb=T, a_bstride=L * ld)]
+        hip.gemm(ps, epi=hip.EPI_GATE_RES, tile_cfg=cfg, step_ptr=step, gate_step_stride=B * D, splitk_ws=ws)
+        torch.cuda.synchronize()
+        res[tag] = (oi, ot)
+    for b in range(B):
+        check(res["sk"][0][b * Nn:(b + 1) * Nn], R.gemm_ref(joint[b * L + T:(b + 1) * L], w2, b2, 2, oi0[b * Nn:(b + 1) * Nn], gates[2, b]))
+        check(res["sk"][1][b * T:(b + 1) * T], R.gemm_ref(joint[b * L:b * L + T], w2, b2, 2, ot0[b * T:(b + 1) * T], gates[2, b]))
+    for k in range(2):
+        d = (res["sk"][k].float() - res["one"][k].float()).abs().max().item()
+        assert d <= 2 ** -5 * res["one"][k].float().abs().max().item()
+    small = torch.empty(1 << 20, dtype=torch.uint8, device=DEV)
+    with pytest.raises(hip.VclozeHipError, match="splitk_ws"):
+        hip.gemm(hip.make_problem(joint[:T], w2, b2, rnd(T, D)), tile_cfg=hip.GEMM_SPLITK(2), splitk_ws=small)
+    with pytest.raises(hip.VclozeHipError, match="splitk_ws"):
+        hip.gemm(hip.make_problem(joint[:T], w2, b2, rnd(T, D)), tile_cfg=hip.GEMM_SPLITK(2))
+    with pytest.raises(hip.VclozeHipError, match="too short"):
+        hip.gemm(hip.make_problem(rnd(64, 128), rnd(64, 128), None, rnd(64, 64)), tile_cfg=hip.GEMM_SPLITK(4), splitk_ws=ws)
+
+
+@pytest.mark.parametrize("M,K", [(4608, 15360), (1664, 12288)])
+def test_gemm_splitk_taken_by_the_cost_model_at_product_shapes(hip, M, K):
+    """tile_cfg 0 with a scratch on offer at the shapes where the launcher takes the split (SDEdit stage: 288 tiles = 256 + 32 x 8
+    slices; cfg 1: 112 tiles x 2 slices), N = 3072, gate + residual in place: against torch and the one-pass plan."""
+    N = 3072
+    a, w, bias = rnd(M, K, seed=1), rnd(N, K, scale=K ** -0.5, seed=2), rnd(N, seed=3)
+    gate, x0 = rnd(N, seed=5), rnd(M, N, seed=4)
+    ws = hip.splitk_workspace(DEV)
+    outs = []
+    for cfg, wsk in ((0, ws), (0, ws), (hip.GEMM_NO_SPLITK, ws)):
+        out = x0.clone()
+        hip.gemm(hip.make_problem(a, w, bias, out, res=out, gate=gate), epi=2, tile_cfg=cfg, splitk_ws=wsk)
+        torch.cuda.synchronize()
+        outs.append(out)
+    check(outs[0], R.gemm_ref(a, w, bias, 2, x0, gate))
+    assert torch.equal(outs[0], outs[1])
+    assert not torch.equal(outs[0], outs[2])              # the split WAS taken (other summation order -> a few 1-ulp flips)
+    d = (outs[0].float() - outs[2].float()).abs()
+    assert d.max().item() <= 2 ** -5 * outs[2].float().abs().max().item()
+
+
 def test_gemm_rejects_bad_arguments(hip):
     a, w = rnd(8, 100), rnd(16, 100)
     with pytest.raises(hip.VclozeHipError):          # K not a multiple of 64

@@ -170,6 +170,9 @@ def test_single_process_degenerates():
     assert par.broadcast_weights(torch.nn.Linear(2, 2)) == 0.0
     lat = par.gather_latents([torch.ones(2, 3), torch.zeros(2, 3)], 2)
     assert len(lat) == 2 and all(t.device.type == "cpu" for t in lat)
+    src = [torch.ones(2, 3), torch.zeros(2, 3)]
+    same = par.gather_latents(src, 2, to_host=False)            # world of one, to_host=False: the caller's own storage, no copy
+    assert all(a.data_ptr() == b.data_ptr() for a, b in zip(same, src))
 
 
 def test_forced_world1_collectives_gloo(tmp_path):

@@ -40,7 +40,7 @@ int vc_gemm(const VcGemmArgs* args, int tile_cfg, void* stream) {
   if (!args) { snprintf(g_err, sizeof(g_err), "gemm: null args"); return VC_ERR_ARG; }
   return vc_gemm_launch(*args, tile_cfg, S(stream), ERRBUF);
 }
-int vc_gemm_plan(const VcGemmArgs* args, int tile_cfg, int32_t out[6]) {
+int vc_gemm_plan(const VcGemmArgs* args, int tile_cfg, int32_t out[8]) {
   if (!args || !out) { snprintf(g_err, sizeof(g_err), "gemm_plan: null argument"); return VC_ERR_ARG; }
   return vc_gemm_plan_impl(*args, tile_cfg, out, ERRBUF);
 }

@@ -41,6 +41,7 @@ struct Buffers {   // the workspace carve-up
   int32_t *STEP, *KVLEN, *KVGAP;
   void* ATT_SCRATCH = nullptr;
   int64_t att_scratch_bytes = 0;
+  void* SK_WS = nullptr;               // f32 partial tiles of split-K GEMM remainders (VcGemmArgs.splitk_ws)
 };
 
 struct Flux : Buffers {
@@ -56,7 +57,7 @@ struct Flux : Buffers {
   std::vector<SingleW> sgl;
   int64_t final_mod = 0;
   // options
-  int attn_variant = -1, tile_cfg = 0, fuse_qnorm = 1, fuse_vt = 1, qkv_heads = 0, fuse_knorm = 0, logit_bound_milli = 0, mlp_first = 0, n_cu = 256;
+  int attn_variant = -1, tile_cfg = 0, fuse_qnorm = 1, fuse_vt = 1, qkv_heads = 0, fuse_knorm = 0, logit_bound_milli = 0, mlp_first = 0, splitk = 1, n_cu = 256;
   // prepared geometry + workspace carve-up
   bool prepared = false;
   int B = 0, T = 0, N = 0, L = 0, Lp = 0, S = 0;
@@ -65,11 +66,11 @@ struct Flux : Buffers {
   // captured steps, most recently used first (a two-stage pipeline alternates between two geometries)
   hipGraphExec_t graph = nullptr;      // = graphs.front().second while a sample is in flight
   struct Key {
-    char* base; int B, T, N, S, ragged, gapped, variant, tile, fuse, fuse_vt, state_f32, qkv_heads, fuse_knorm, bound, mlp_first; hipStream_t s;
+    char* base; int B, T, N, S, ragged, gapped, variant, tile, fuse, fuse_vt, state_f32, qkv_heads, fuse_knorm, bound, mlp_first, splitk; hipStream_t s;
     bool operator==(const Key& o) const {
       return base == o.base && B == o.B && T == o.T && N == o.N && S == o.S && ragged == o.ragged && gapped == o.gapped &&
              variant == o.variant && tile == o.tile && fuse == o.fuse && fuse_vt == o.fuse_vt && state_f32 == o.state_f32 &&
-             qkv_heads == o.qkv_heads && fuse_knorm == o.fuse_knorm && bound == o.bound && mlp_first == o.mlp_first && s == o.s;
+             qkv_heads == o.qkv_heads && fuse_knorm == o.fuse_knorm && bound == o.bound && mlp_first == o.mlp_first && splitk == o.splitk && s == o.s;
     }
   } key{};
   std::vector<std::pair<Key, hipGraphExec_t>> graphs;
@@ -135,6 +136,7 @@ int64_t carve(Buffers& f, const Flux& g, char* base, int B, int T, int N, int S)
   f.STEP = c.take<int32_t>(1);               f.KVLEN = c.take<int32_t>(B);  f.KVGAP = c.take<int32_t>(2 * B);
   f.att_scratch_bytes = vc_attention_scratch_bytes_impl();
   f.ATT_SCRATCH = c.take<char>(f.att_scratch_bytes);
+  f.SK_WS = c.take<char>(VC_GEMM_SPLITK_WS_BYTES);
   return c.off;
 }
 
@@ -247,6 +249,7 @@ int gemm(Flux& f, const VcGemmProblem* ps, int n, int epi, const int32_t* step_p
   memset(&a, 0, sizeof(a));
   for (int i = 0; i < n; ++i) a.p[i] = ps[i];
   a.nprob = n; a.epi = epi; a.step_ptr = step_ptr; a.gate_step_stride = gate_step_stride;
+  if (f.splitk) { a.splitk_ws = f.SK_WS; a.splitk_ws_bytes = VC_GEMM_SPLITK_WS_BYTES; }   // the launcher's cost model decides
   return vc_gemm_launch(a, f.tile_cfg, s, e.buf, e.len);
 }
 int lin(Flux& f, const Lin& w, const void* A, int64_t lda, void* C, int64_t ldc, int M, int epi, hipStream_t s, Err e) {
@@ -451,7 +454,7 @@ void drop_graph(Flux& f) {
 // the hipGraph of ONE solver step: everything step-dependent (modulation rows, dt) is indexed on the device by STEP
 int step_graph(Flux& f, hipStream_t s, Err e) {
   Flux::Key k{f.base, f.B, f.T, f.N, f.S, f.ragged, f.gapped, attention_variant(f), f.tile_cfg, f.fuse_qnorm, f.fuse_vt, f.state_f32,
-              f.qkv_heads, f.fuse_knorm, f.logit_bound_milli, f.mlp_first, s};
+              f.qkv_heads, f.fuse_knorm, f.logit_bound_milli, f.mlp_first, f.splitk, s};
   for (size_t i = 0; i < f.graphs.size(); ++i)
     if (f.graphs[i].first == k) {
       auto hit = f.graphs[i];
@@ -555,6 +558,7 @@ int vc_flux_set_option_impl(void* handle, const char* name, int32_t value, char*
   } else if (!strcmp(name, "fuse_knorm")) f.fuse_knorm = value != 0;
   else if (!strcmp(name, "logit_bound_milli")) f.logit_bound_milli = value > 0 ? value : 0;
   else if (!strcmp(name, "mlp_first")) f.mlp_first = value != 0;
+  else if (!strcmp(name, "splitk")) f.splitk = value != 0;      // split-K remainders (VcGemmArgs.splitk_ws) where the launcher's model takes them
   else FAIL(VC_ERR_ARG, "flux_set_option: unknown option '%s'", name);
   return VC_OK;
 }

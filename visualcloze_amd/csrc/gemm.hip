@@ -38,8 +38,9 @@ constexpr int BK = 64;
 // one - into two ring slots that live ABOVE the epilogue's LDS staging area, and A(0) follows as soon as the staging area
 // has been read back; a new workgroup would pay dispatch + offsets + the full HBM latency of its first tiles instead
 // (6.0 k cycles of prologue + 1.2-3.8 k of dispatch gap per 90 k-cycle round at K = 3072).
-template <int BM, int BN, int WM, int WN, int EPI, int PP, bool CONV = false, bool PERSIST = false>
+template <int BM, int BN, int WM, int WN, int EPI, int PP, bool CONV = false, bool PERSIST = false, bool SPLITK = false>
 __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_kernel(const VcGemmArgs args) {
+  static_assert(!SPLITK || (PP == 2 && !CONV && !PERSIST), "split-K slices run on the plain loader-wave schedule");
   static_assert(!CONV || PP == 2, "the implicit-convolution A operand is gathered by loader waves");
   static_assert(!PERSIST || (PP == 2 && !CONV), "the persistent tile loop exists for the loader-wave schedule");
   constexpr int NCW = WM * WN;                       // compute waves
@@ -73,6 +74,17 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
   // one block per tile: logical id = xcd_remap(blockIdx) (XCD x works on one contiguous strip of ids).  PERSIST: the same
   // strips, walked by the W = grid / 8 resident workgroups of the XCD: ids strip0 + slot, strip0 + slot + W, ...
   int id_cur = xcd_remap(blockIdx.x, gridDim.x), id_end = 0, id_step = 0;
+  // SPLITK instantiation (its own launch, behind the whole tiles of the call): block p is WORK ITEM p of the remainder - K-slice
+  // p / sk_rem of tile sk_full + p % sk_rem (the items of one slice are neighbours: those that share an m-tile share their A
+  // slab in one XCD's L2).  An item leaves its f32 accumulators in args.splitk_ws [tile][slice][BM][BN] instead of running an
+  // epilogue; splitk_reduce_kernel finishes the tile.  Every other instantiation compiles exactly as without this.
+  int sk_slice = 0, sk_slot = -1;
+  if constexpr (SPLITK) {
+    sk_slice = blockIdx.x / args.sk_rem;
+    const int r = blockIdx.x - sk_slice * args.sk_rem;
+    id_cur = args.sk_full + r;
+    sk_slot = r * args.sk_S + sk_slice;
+  }
   if constexpr (PERSIST) {
     const int total = args.p[args.nprob - 1].tile_start + args.p[args.nprob - 1].tiles_m * args.p[args.nprob - 1].tiles_n;
     const int x = blockIdx.x & 7, q = total >> 3, r = total & 7;
@@ -134,8 +146,14 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
   const int M = P.M, N = P.N, K = P.K;
   const bool has_next = PERSIST && id_cur + id_step < id_end;
 
-  const bf16_t* __restrict__ Ab = (const bf16_t*)P.A;
-  const bf16_t* __restrict__ Wb = (const bf16_t*)P.W;
+  // K-tiles [kt_lo, kt_lo + nk) of this work item (the whole K unless it is a split-K slice)
+  int kt_lo = 0, nk = K / BK;
+  if constexpr (SPLITK) {
+    kt_lo = (int)((long)nk * sk_slice / args.sk_S);
+    nk = (int)((long)nk * (sk_slice + 1) / args.sk_S) - kt_lo;
+  }
+  const bf16_t* __restrict__ Ab = (const bf16_t*)P.A + (long)kt_lo * BK;
+  const bf16_t* __restrict__ Wb = (const bf16_t*)P.W + (long)kt_lo * BK;
   uint32_t a_off[A_IT], b_off[B_IT];
   auto staging_offsets = [&]() { staging_offsets_a(a_off, P, m0, stid); staging_offsets_b(b_off, P, n0, stid); };
   if constexpr (PP != 2) staging_offsets();
@@ -209,7 +227,6 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = K / BK;
   if constexpr (PP == 0) {
     // ---- simple schedule: double-buffered LDS, one barrier per K-tile ----
     stage(0, 0);
@@ -313,7 +330,7 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
       if (grp == 1) __builtin_amdgcn_s_setprio(1);
       // the accumulators start at the bias (6 8-B loads per lane, hidden under the wait for the first K-tile): epilogue
       // pass 1 is then convert + LDS write only (it was VALU-bound on the bias unpack/add: 6.9 k cycles per block)
-      if (P.bias) {
+      if (P.bias && (!SPLITK || sk_slice == 0)) {       // (a split-K tile: slice 0 carries the bias)
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
           const int col = n0 + wn * TN + j * 16 + fq * 4;
@@ -680,7 +697,24 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
   }
   VC_PHASE_STAMP(4);
   };   // epilogue
+  if constexpr (SPLITK) {
+    {
+      // a split-K slice: the f32 accumulators leave row-major, 16 B per lane (the 4 lanes of a row's fq group write 64 B runs;
+      // L2 merges the halves of a line), rows / columns beyond M / N included - the scratch is tile-sized, the reducer masks
+      if (wave < NCW) {
+        int pl = lane;                    // opaque copy: keeps this address arithmetic below the K loop
+        asm volatile("" : "+v"(pl));
+        float* __restrict__ wsp = (float*)args.splitk_ws + (long)sk_slot * (BM * BN) + (wm * TM + (pl & 15)) * BN + wn * TN + (pl >> 4) * 4;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) *(f32x4*)(wsp + i * 16 * BN + j * 16) = acc[i][j];
+      }
+      break;
+    }
+  } else {
   epilogue();
+  }
   if constexpr (!PERSIST) {
     break;
   } else {
@@ -701,6 +735,108 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
     id_cur += id_step;
   }
   }    // tiles
+}
+
+// slice 0 + slice 1 + ... + slice S-1 of one thread's 8 columns, in that order
+template <int S, int STRIDE>
+VC_DEV void sum_slices(const float* __restrict__ src, f32x4& a0, f32x4& a1) {
+  f32x4 lo[S], hi[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) { lo[s] = *(const f32x4*)(src + (long)s * STRIDE); hi[s] = *(const f32x4*)(src + (long)s * STRIDE + 4); }
+  a0 = lo[0]; a1 = hi[0];
+#pragma unroll
+  for (int s = 1; s < S; ++s) { a0 += lo[s]; a1 += hi[s]; }
+}
+
+// Second launch of a split-K call: sums the S f32 partial tiles of every remainder tile in slice order (slice 0 carries the
+// bias) and applies the epilogue exactly as pass 2 of gemm_bf16_kernel does - t = bf16(sum), then GELU / SiLU / res +
+// bf16(gate * t) - one thread per 16-B chunk of C, whole partial rows (768 B) per wave-instruction.  HBM-bound:
+// rem * S * BM * BN * 4 bytes read (they sit in the Infinity Cache: the slices were written microseconds ago).
+template <int BM, int BN, int EPI>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const VcGemmArgs args) {
+  constexpr int CPR = BN / 8, PER_TILE = BM * CPR, BPT = PER_TILE / 256;     // a block lies inside ONE tile: the problem is scalar
+  static_assert(PER_TILE % 256 == 0, "whole blocks per tile");
+  const int r = blockIdx.x / BPT;
+  const int cc = (blockIdx.x - r * BPT) * 256 + threadIdx.x, row = cc / CPR, ch = cc - row * CPR;
+  int id = __builtin_amdgcn_readfirstlane(args.sk_full + r), pi = 0;
+#pragma unroll
+  for (int q = 1; q < VC_GEMM_MAX_PROBLEMS; ++q)
+    if (q < args.nprob && id >= args.p[q].tile_start) pi = q;
+  const VcGemmProblem P = pi == 3 ? args.p[3] : pi == 2 ? args.p[2] : pi == 1 ? args.p[1] : args.p[0];   // scalar selects, as decode()
+  id -= P.tile_start;
+  constexpr int GROUP_M = VC_GEMM_GROUP_M;        // the raster of gemm_bf16_kernel's decode
+  const int in_group = GROUP_M * P.tiles_n, group = id / in_group, first_m = group * GROUP_M;
+  const int gsz = min(P.tiles_m - first_m, GROUP_M);
+  const int m = P.m_begin + (first_m + (id % in_group) % gsz) * BM + row, n = ((id % in_group) / gsz) * BN + ch * 8;
+  if (m >= P.M || n >= P.N) return;
+  const float* __restrict__ src = (const float*)args.splitk_ws + (long)r * args.sk_S * (BM * BN) + row * BN + ch * 8;
+  f32x4 a0, a1;
+  switch (args.sk_S) {        // (wave-uniform; each case is fully unrolled: all 2 S loads of a thread are in flight together)
+    case 2: sum_slices<2, BM * BN>(src, a0, a1); break;
+    case 3: sum_slices<3, BM * BN>(src, a0, a1); break;
+    case 4: sum_slices<4, BM * BN>(src, a0, a1); break;
+    case 5: sum_slices<5, BM * BN>(src, a0, a1); break;
+    case 6: sum_slices<6, BM * BN>(src, a0, a1); break;
+    case 7: sum_slices<7, BM * BN>(src, a0, a1); break;
+    default: sum_slices<8, BM * BN>(src, a0, a1); break;
+  }
+  float v[8];
+  u32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    o[e] = pack2bf(e < 2 ? a0[2 * e] : a1[2 * e - 4], e < 2 ? a0[2 * e + 1] : a1[2 * e - 3]);   // t = bf16(acc + bias)
+    v[2 * e] = lo_bf(o[e]); v[2 * e + 1] = hi_bf(o[e]);
+  }
+  const long crow = P.c_rpb > 0 ? (long)(m / P.c_rpb) * P.c_bstride + (long)(m % P.c_rpb) * P.ldc : (long)m * P.ldc;
+  if (EPI == VC_EPI_GELU) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const f32x2 g = gelu_tanh2(f32x2{v[2 * e], v[2 * e + 1]});
+      o[e] = pack2bf(g[0], g[1]);
+    }
+  } else if (EPI == VC_EPI_SILU) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack2bf(silu_f(v[2 * e]), silu_f(v[2 * e + 1]));
+  } else if (EPI == VC_EPI_GATE_RES) {
+    const long gate_step = args.step_ptr ? (long)(*args.step_ptr) * args.gate_step_stride : 0;
+    const u32x4 gg = *(const u32x4*)((const bf16_t*)P.gate + gate_step + (long)(m / P.rows_per_batch) * P.gate_bstride + n);
+    const u32x4 rr = *(const u32x4*)((const bf16_t*)P.res + (P.c_rpb > 0 ? crow : (long)m * P.ldres) + n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {   // out = res + bf16(gate * t), as pass 2 of the one-pass kernel
+      const f32x2 gv = f32x2{lo_bf(gg[e]), hi_bf(gg[e])} * f32x2{v[2 * e], v[2 * e + 1]};
+      const uint32_t gb = pack2bf(gv[0], gv[1]);
+      const f32x2 sum = f32x2{lo_bf(rr[e]), hi_bf(rr[e])} + f32x2{lo_bf(gb), hi_bf(gb)};
+      o[e] = pack2bf(sum[0], sum[1]);
+    }
+  }
+  *(u32x4*)((bf16_t*)P.C + crow + n) = o;
+}
+
+// First launch of the remainder: sk_rem * sk_S work items of the 256x192 loader-wave kernel, each over K / sk_S, no epilogue
+hipError_t launch_splitk_slices(const VcGemmArgs& a, hipStream_t s) {
+  constexpr int BM = 256, BN = 192, NT = 12 * 64, LDS = (2 * BM + 3 * BN) * BK * 2;
+  void (*fn)(const VcGemmArgs) = gemm_bf16_kernel<BM, BN, 4, 2, VC_EPI_BIAS, 2, false, false, true>;
+  static VcOncePerDevice attr_done;
+  if (attr_done.need()) {
+    hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return e;
+    attr_done.mark();
+  }
+  hipLaunchKernelGGL(fn, dim3(a.sk_rem * a.sk_S), dim3(NT), LDS, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_splitk_reduce(const VcGemmArgs& a, hipStream_t s) {
+  constexpr int BM = 256, BN = 192;
+  const unsigned grid = (unsigned)(a.sk_rem * (BM * (BN / 8) / 256));
+  switch (a.epi) {
+    case VC_EPI_BIAS: hipLaunchKernelGGL((splitk_reduce_kernel<BM, BN, VC_EPI_BIAS>), dim3(grid), dim3(256), 0, s, a); break;
+    case VC_EPI_GELU: hipLaunchKernelGGL((splitk_reduce_kernel<BM, BN, VC_EPI_GELU>), dim3(grid), dim3(256), 0, s, a); break;
+    case VC_EPI_SILU: hipLaunchKernelGGL((splitk_reduce_kernel<BM, BN, VC_EPI_SILU>), dim3(grid), dim3(256), 0, s, a); break;
+    case VC_EPI_GATE_RES: hipLaunchKernelGGL((splitk_reduce_kernel<BM, BN, VC_EPI_GATE_RES>), dim3(grid), dim3(256), 0, s, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
 }
 
 template <int BM, int BN, int WM, int WN, int PP, bool PERSIST = false>
@@ -820,7 +956,7 @@ TilePlan best_tile(const VcGemmArgs& a) {
   return best;
 }
 
-int launch_tiles(VcGemmArgs a, int tile_cfg, int pp, bool want_persist, hipStream_t s, char* err, int errlen) {
+int launch_tiles(VcGemmArgs a, int tile_cfg, int pp, bool want_persist, hipStream_t s, char* err, int errlen, int splitk_S = 0) {
   if (tile_cfg < 1 || tile_cfg > 5 || pp > 2 || (pp == 1 && tile_cfg < 3) || (pp == 2 && tile_cfg != 4 && tile_cfg != 2)) { snprintf(err, errlen, "gemm: bad tile_cfg %d", tile_cfg); return VC_ERR_ARG; }
   const int bm = cfg_bm[tile_cfg], bn = cfg_bn[tile_cfg];
   int total = 0, np = 0;
@@ -835,6 +971,20 @@ int launch_tiles(VcGemmArgs a, int tile_cfg, int pp, bool want_persist, hipStrea
   }
   if (np == 0) return VC_OK;
   a.nprob = np;
+  a.sk_full = total; a.sk_rem = 0; a.sk_S = 1;
+  if (splitk_S > 1) {      // the tiles beyond the last whole round of the CUs run as splitk_S K-slices each (plan_gemm decided)
+    const int n_cu = vc_cu_count();
+    const int full = total / n_cu * n_cu, rem = total - full;
+    if (tile_cfg != 4 || pp != 2 || a.epi == VC_EPI_QKV) { snprintf(err, errlen, "gemm: split-K runs on the 256x192 loader-wave tile, not with VC_EPI_QKV"); return VC_ERR_ARG; }
+    if (rem > 0) {
+      if (!a.splitk_ws || a.splitk_ws_bytes < (int64_t)rem * splitk_S * bm * bn * 4) {
+        snprintf(err, errlen, "gemm: split-K of %d tiles x %d slices needs %lld bytes of splitk_ws (have %lld)", rem, splitk_S,
+                 (long long)rem * splitk_S * bm * bn * 4, (long long)(a.splitk_ws ? a.splitk_ws_bytes : 0)); return VC_ERR_ARG; }
+      for (int i = 0; i < np; ++i)
+        if (a.p[i].K / BK < splitk_S) { snprintf(err, errlen, "gemm: K=%d is too short for %d slices", a.p[i].K, splitk_S); return VC_ERR_ARG; }
+      a.sk_full = full; a.sk_rem = rem; a.sk_S = splitk_S;
+    }
+  }
   // VC_GEMM_PERSIST + more tiles than CUs on the loader-wave schedule: one persistent workgroup per CU walks them
   // (gemm_bf16_kernel PERSIST).  OPT-IN: bit-identical, and worth +0.05 % steps/s at cfg 2 (-0.4 ... -0.7 % per qkv / MLP-up
   // launch, profiles/r03d_*), +-0.2 % at the other geometries (profiles/r03e_persist_ab.log) - under the board's power limit
@@ -842,8 +992,10 @@ int launch_tiles(VcGemmArgs a, int tile_cfg, int pp, bool want_persist, hipStrea
   // (Not the gated-residual epilogue: its residual prefetch registers + the loop state do not fit the 168-VGPR budget of the
   // 3-waves-per-SIMD kernel - 39 spilled registers.)
   const int n_cu8 = vc_cu_count() / 8 * 8;
-  const bool persist = pp == 2 && want_persist && n_cu8 >= 8 && total > n_cu8 && a.epi != VC_EPI_GATE_RES;
-  hipError_t e;
+  const bool persist = pp == 2 && want_persist && n_cu8 >= 8 && total > n_cu8 && a.epi != VC_EPI_GATE_RES && a.sk_S == 1;
+  hipError_t e = hipSuccess;
+  if (a.sk_S > 1) total = a.sk_full;        // the whole rounds run as ever (ids [0, sk_full)); the remainder follows below
+  if (total > 0)
   switch (tile_cfg) {
     case 1: e = launch_cfg<128, 128, 2, 2, 0>(a, total, s); break;
     case 2: e = pp == 2 ? (persist ? launch_cfg<256, 128, 4, 2, 2, true>(a, total, s) : launch_cfg<256, 128, 4, 2, 2>(a, total, s))
@@ -854,6 +1006,11 @@ int launch_tiles(VcGemmArgs a, int tile_cfg, int pp, bool want_persist, hipStrea
     default: e = pp ? launch_cfg<256, 288, 4, 2, 1>(a, total, s) : launch_cfg<256, 288, 4, 2, 0>(a, total, s); break;
   }
   if (e != hipSuccess) { snprintf(err, errlen, "gemm launch: %s", hipGetErrorString(e)); return VC_ERR_HIP; }
+  if (a.sk_S > 1) {
+    e = launch_splitk_slices(a, s);
+    if (e == hipSuccess) e = launch_splitk_reduce(a, s);
+    if (e != hipSuccess) { snprintf(err, errlen, "gemm split-K launch: %s", hipGetErrorString(e)); return VC_ERR_HIP; }
+  }
   return VC_OK;
 }
 
@@ -890,15 +1047,48 @@ static int validate_gemm(VcGemmArgs& a, char* err, int errlen) {
 }
 
 // The launch plan of one vc_gemm call: cut = first row of the second launch (0 = one launch); tile / pp of the two launches.
-struct GemmPlan { int cut, tile1, pp1, tile2, pp2; };
+struct GemmPlan { int cut, tile1, pp1, tile2, pp2, sk_S = 0, sk_tiles = 0; };
 static GemmPlan plan_gemm(const VcGemmArgs& a, int tile_cfg) {
-  const int force_cut = tile_cfg >> 8;                 // tests: cut problem 0 at row force_cut * 256
-  const bool no_split = (tile_cfg & VC_GEMM_NO_SPLIT) != 0;
+  const int force_cut = (tile_cfg >> 8) & 255;         // tests: cut problem 0 at row force_cut * 256
+  const int force_sk = (tile_cfg >> 16) & 15;          // tests / A-B: VC_GEMM_SPLITK(S)
+  const bool no_split = (tile_cfg & VC_GEMM_NO_SPLIT) != 0, no_splitk = (tile_cfg & VC_GEMM_NO_SPLITK) != 0;
   tile_cfg &= 63;
+  const long n_cus = vc_cu_count();
+  auto sk_plan = [&](int S) {
+    const long total = tiles_of(a, 4), rem = total % n_cus;
+    GemmPlan pl{0, 4, 2, 0, 0};
+    if (rem > 0) { pl.sk_S = S; pl.sk_tiles = (int)rem; }
+    return pl;
+  };
+  if (force_sk >= 2) return sk_plan(force_sk > 8 ? 8 : force_sk);
   for (int i = 0; i < a.nprob; ++i)      // K heads are normalised inside the epilogue: every K head must lie in one 192-wide tile
     if (a.epi == VC_EPI_QKV && a.p[i].kn_scale) return GemmPlan{0, 4, tile_cfg != 0 && ((tile_cfg >> 4) & 3) != 2 ? (tile_cfg >> 4) & 3 : 2, 0, 0};
   if (tile_cfg != 0) return GemmPlan{0, tile_cfg & 15, (tile_cfg >> 4) & 3, 0, 0};
   const TilePlan whole = best_tile(a);
+  // SPLIT-K REMAINDER: the 256x192 tiles are R whole rounds of the CUs plus r tiles - run those r as r * S slices of K / S
+  // (S <= 8, r * S <= CUs: ONE short round) that leave f32 partial tiles for a small second launch, instead of a second round
+  // at r / CUs fill or a narrower tile for everything.  Priced in the units of best_tile (one 256x192 tile of K = 15360 on its CU
+  // = 8.2e8 units = 255 us: 3.2e6 units per us): a slice pays its own prologue and the partial store instead of an epilogue
+  // (+150), the partials are written and read once at ~4 TB/s, the second launch costs a dependent kernel boundary (~3 us).
+  // Taken at >= 7 % under the best one-launch plan: SDEdit stage (L = 4608: 288 tiles = 256 + 32 x 8 slices, K = 12288 /
+  // 15360) and cfg 1 (L = 1664: 112 tiles x 2 slices); never at K = 3072 (the partial traffic outweighs 1 / S of a short tile).
+  GemmPlan sk{0, 0, 0, 0, 0};
+  double sk_cost = 1e300;
+  if (!no_splitk && a.splitk_ws && a.epi != VC_EPI_QKV) {
+    const long total = tiles_of(a, 4), R = total / n_cus, rem = total % n_cus;
+    const int nk = a.p[0].K / BK;
+    int S = rem > 0 ? (int)(n_cus / rem) : 0;
+    if (S > 8) S = 8;
+    if (S > nk / 8) S = nk / 8;
+    bool same_k = true;
+    for (int i = 1; i < a.nprob; ++i) same_k = same_k && a.p[i].K == a.p[0].K;
+    const double bytes = (double)rem * S * cfg_bm[4] * cfg_bn[4] * 4;
+    if (S >= 2 && same_k && bytes <= (double)a.splitk_ws_bytes) {
+      const double area = (double)cfg_bm[4] * cfg_bn[4] / cand_eff[1];
+      const double cost = R * area * (a.p[0].K + cand_ovh[1]) + area * ((double)a.p[0].K / S + cand_ovh[1] + 150.0) + (2.0 * bytes / 4e6 + 3.0) * 3.2e6;
+      if (cost < 0.93 * whole.cost) { sk = sk_plan(S); sk_cost = cost; }
+    }
+  }
   // Block-round quantisation: cut problem 0's rows where the 256x192 tiles above the cut are (nearly) whole rounds of the 256
   // CUs and price the remainder with the tile that suits it.  The two launches follow each other on the stream (the first
   // has a flat tail by construction); a cut is taken when the model says it saves >= 10 % and both launches fill their rounds.
@@ -908,6 +1098,7 @@ static GemmPlan plan_gemm(const VcGemmArgs& a, int tile_cfg) {
   // cut at 6144 rows, model -6.3 %) 8.683 / 8.693 = -0.1 % - hence the 10 % bar.
   int cut = 0;
   TilePlan rest_plan{0, 0, 0};
+  double best_cut = 1e300;
   if (!no_split || force_cut > 0) {
     double best = force_cut > 0 ? 1e300 : 0.90 * whole.cost;
     const int tn = (a.p[0].N + cfg_bn[4] - 1) / cfg_bn[4];
@@ -928,9 +1119,10 @@ static GemmPlan plan_gemm(const VcGemmArgs& a, int tile_cfg) {
       const int per_cu = rp.tile_cfg == 1 ? 2 : 1;
       const long tiles2 = tiles_of(rest, rp.tile_cfg), slots2 = (tiles2 + n_cu * per_cu - 1) / (n_cu * per_cu) * n_cu * per_cu;
       if (force_cut == 0 && tiles2 < 0.9 * slots2) continue;
-      if (t1 + rp.cost < best) { best = t1 + rp.cost; cut = rows; rest_plan = rp; }
+      if (t1 + rp.cost < best) { best = t1 + rp.cost; cut = rows; rest_plan = rp; best_cut = best; }
     }
   }
+  if (sk.sk_S > 1 && (cut == 0 || sk_cost <= best_cut)) return sk;
   if (cut == 0) return GemmPlan{0, whole.tile_cfg, whole.pp, 0, 0};
   return GemmPlan{cut, 4, 2, rest_plan.tile_cfg, rest_plan.pp};
 }
@@ -942,7 +1134,7 @@ int vc_gemm_launch(VcGemmArgs a, int tile_cfg, hipStream_t s, char* err, int err
   if (rc != VC_OK) return rc;
   const GemmPlan pl = plan_gemm(a, tile_cfg);
   const bool want_persist = (tile_cfg & VC_GEMM_PERSIST) != 0;
-  if (pl.cut == 0) return launch_tiles(a, pl.tile1, pl.pp1, want_persist, s, err, errlen);
+  if (pl.cut == 0) return launch_tiles(a, pl.tile1, pl.pp1, want_persist, s, err, errlen, pl.sk_S);
   VcGemmArgs first = a;
   first.nprob = 1;
   first.p[0].M = pl.cut;                                       // rows [0, cut) of problem 0 on the 256x192 loader-wave tile
@@ -953,7 +1145,7 @@ int vc_gemm_launch(VcGemmArgs a, int tile_cfg, hipStream_t s, char* err, int err
 }
 
 // the plan without the launch: out = {cut row, tile / loader mode of the first (or only) launch, of the second, tiles of both}
-int vc_gemm_plan_impl(VcGemmArgs a, int tile_cfg, int32_t out[6], char* err, int errlen) {
+int vc_gemm_plan_impl(VcGemmArgs a, int tile_cfg, int32_t out[8], char* err, int errlen) {
   const int rc = validate_gemm(a, err, errlen);
   if (rc != VC_OK) return rc;
   const GemmPlan pl = plan_gemm(a, tile_cfg);
@@ -962,5 +1154,6 @@ int vc_gemm_plan_impl(VcGemmArgs a, int tile_cfg, int32_t out[6], char* err, int
   VcGemmArgs first = a, rest = a;
   if (pl.cut) { first.nprob = 1; first.p[0].M = pl.cut; rest.p[0].m_begin = pl.cut; }
   out[5] = (int32_t)(tiles_of(first, pl.tile1) + (pl.cut ? tiles_of(rest, pl.tile2) : 0));
+  out[6] = pl.sk_S; out[7] = pl.sk_tiles;
   return VC_OK;
 }

@@ -142,6 +142,10 @@ class FluxEngine:
         # MLP-up before the attention, the order of layers.py:236-243
         self.mlp_first = False
         self.tile_cfg = 0
+        # f32 scratch for split-K GEMM remainders (VcGemmArgs.splitk_ws): where the 256x192 tiles are whole rounds of the CUs plus
+        # a few, the launcher may cut those few along K (SDEdit stage, cfg 1); False = never
+        self.splitk = True
+        self.splitk_ws = hip.splitk_workspace(dev)
         self.stream = torch.cuda.Stream(device=dev)   # capture needs a non-default stream
         self._ref_scratch: Dict[tuple, torch.Tensor] = {}
         if weights.ref is not None:
@@ -168,7 +172,8 @@ class FluxEngine:
                 self._linear_ref(c, epi, step_ptr, gate_step_stride, s)
             return
         probs = [hip.make_problem(c.a, self.W.w[c.name], self.W.b[c.name], c.out, **c.kw) for c in calls]
-        hip.gemm(probs, epi=epi, tile_cfg=self.tile_cfg, step_ptr=step_ptr, gate_step_stride=gate_step_stride, stream=s)
+        hip.gemm(probs, epi=epi, tile_cfg=self.tile_cfg, step_ptr=step_ptr, gate_step_stride=gate_step_stride, stream=s,
+                 splitk_ws=self.splitk_ws if self.splitk else None)
 
     def _prob(self, name, a, out, **kw) -> LinCall:
         return LinCall(name, a, out, kw)
@@ -219,7 +224,7 @@ class FluxEngine:
         """hipGraph of ONE solver step (Flux evaluation + Euler update + device step-counter increment).
         Everything step-dependent (modulation rows, dt) is indexed on the device by ws.STEP, so the same
         graph replays for every step of every sample batch with this geometry."""
-        key = (ws.ragged, ws.gapped, self.attn_variant, self.tile_cfg, self.fuse_qnorm, self.fuse_vt, self.fuse_knorm, self.bounded_softmax, self.mlp_first)
+        key = (ws.ragged, ws.gapped, self.attn_variant, self.tile_cfg, self.fuse_qnorm, self.fuse_vt, self.fuse_knorm, self.bounded_softmax, self.mlp_first, self.splitk)
         if ws.graph is None or ws.graph_key != key:
             xs = ws.XS.clone()
             self.eval_once(ws, ws.STEP, euler=True, s=s)      # warm-up: sets func attributes outside capture
@@ -287,7 +292,8 @@ class FluxEngine:
             hip.add3(ws.TVEC, ws.YVEC, None, out=ws.VEC, stream=s)
         hip.silu(ws.VEC, out=ws.H1, stream=s)
         if W.ref is None:
-            hip.gemm(hip.make_problem(ws.H1, W.mod_w, W.mod_b, ws.MOD), tile_cfg=self.tile_cfg, stream=s)
+            hip.gemm(hip.make_problem(ws.H1, W.mod_w, W.mod_b, ws.MOD), tile_cfg=self.tile_cfg, stream=s,
+                     splitk_ws=self.splitk_ws if self.splitk else None)
         else:                          # un-merged mode: every modulation Linear on its own column range of MOD
             for name, off in W.mod_off.items():
                 n = W.ref[name].w.shape[0]

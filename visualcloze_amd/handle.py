@@ -57,6 +57,9 @@ class FluxHandle:
         self._ws: Dict[tuple, torch.Tensor] = {}
         self._opts: Dict[str, int] = {}
         self.geom: Optional[Tuple[int, int, int, int]] = None
+        # the storage order of the bound qkv rows (head-permuted or natural) and the logit bound are PROPERTIES OF THE
+        # WEIGHTS, not knobs: a handle built directly must un-permute exactly as model.handle()'s does
+        self.set_options()
 
     def _bind(self, name, w, b, rows, cols):
         hip._bf16(w, name)
@@ -73,14 +76,20 @@ class FluxHandle:
         except Exception:
             pass
 
-    def set_options(self, attn_variant=None, tile_cfg=0, fuse_qnorm=True, fuse_vt=True, qkv_heads=0, fuse_knorm=False,
-                    logit_bound=0.0, mlp_first=False) -> None:
+    def set_options(self, attn_variant=None, tile_cfg=0, fuse_qnorm=True, fuse_vt=True, qkv_heads=None, fuse_knorm=False,
+                    logit_bound=0.0, mlp_first=False, splitk=True) -> None:
         import math
+        wq = int(getattr(self.W, "qkv_heads", 0) or 0)
+        if qkv_heads is None:
+            qkv_heads = wq
+        elif int(qkv_heads) != wq:
+            raise hip.VclozeHipError(f"set_options(qkv_heads={qkv_heads}): the bound qkv weights are stored with qkv_heads={wq} "
+                                     "(model.prepare / hip.qkv_head_permutation); the option follows the weights")
         want = dict(attn_variant=-1 if attn_variant is None else int(attn_variant), tile_cfg=int(tile_cfg),
                     fuse_qnorm=int(bool(fuse_qnorm)), fuse_vt=int(bool(fuse_vt)), qkv_heads=int(qkv_heads),
                     fuse_knorm=int(bool(fuse_knorm)),
                     logit_bound_milli=int(math.ceil(logit_bound * 1000)) if 0 < logit_bound < 2e6 else 0,
-                    mlp_first=int(bool(mlp_first)))
+                    mlp_first=int(bool(mlp_first)), splitk=int(bool(splitk)))
         for k, v in want.items():
             if self._opts.get(k) != v:
                 hip._check(hip.lib().vc_flux_set_option(self.h, k.encode(), v), f"vc_flux_set_option({k})")

@@ -16,11 +16,18 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VC_HIP_LIB") or os.path.join(_HERE, "lib", "libvcloze_hip.so")   # VC_HIP_LIB: profiling build
 CSRC = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 6                # VC_ABI_VERSION of include/vcloze_hip.h
+ABI_VERSION = 7                # VC_ABI_VERSION of include/vcloze_hip.h
 GEMM_MAX_PROBLEMS = 4          # VC_GEMM_MAX_PROBLEMS: grouped problems per vc_gemm launch
 EPI_BIAS, EPI_GELU, EPI_GATE_RES, EPI_SILU, EPI_QKV = 0, 1, 2, 3, 4
 GEMM_NO_SPLIT = 64             # VC_GEMM_NO_SPLIT: tile_cfg value that keeps an auto-tiled vc_gemm one launch
 GEMM_PERSIST = 128             # VC_GEMM_PERSIST: opt into the persistent tile loop of the loader-wave GEMM (multi-round launches)
+GEMM_NO_SPLITK = 1 << 20       # VC_GEMM_NO_SPLITK: an auto-tiled call keeps its remainder tiles whole even with a splitk_ws
+GEMM_SPLITK_WS_BYTES = 256 * 256 * 192 * 4     # VC_GEMM_SPLITK_WS_BYTES
+
+
+def GEMM_SPLITK(S: int) -> int:
+    """VC_GEMM_SPLITK(S): force the 256x192 loader-wave tile with the remainder tiles cut S ways along K (tests, A/B runs)"""
+    return int(S) << 16
 
 
 class VclozeHipError(RuntimeError):
@@ -46,6 +53,8 @@ class GemmArgs(C.Structure):
     _fields_ = [
         ("p", GemmProblem * 4), ("nprob", C.c_int32), ("epi", C.c_int32),
         ("step_ptr", C.c_void_p), ("gate_step_stride", C.c_int64), ("debug_ts", C.c_void_p),
+        ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64),
+        ("sk_full", C.c_int32), ("sk_rem", C.c_int32), ("sk_S", C.c_int32), ("sk_pad_", C.c_int32),
     ]
 
 
@@ -281,8 +290,15 @@ def make_problem(a, w, bias, out, res=None, gate=None, rows_per_batch=None, gate
     return p
 
 
-def gemm(problems, epi=EPI_BIAS, tile_cfg=0, step_ptr=None, gate_step_stride=0, stream=None, debug_ts=None) -> None:
+def splitk_workspace(device) -> torch.Tensor:
+    """f32 scratch for the split-K remainder of vc_gemm (VcGemmArgs.splitk_ws): one 256x192 tile per CU of one round"""
+    return torch.empty(GEMM_SPLITK_WS_BYTES, dtype=torch.uint8, device=device)
+
+
+def gemm(problems, epi=EPI_BIAS, tile_cfg=0, step_ptr=None, gate_step_stride=0, stream=None, debug_ts=None, splitk_ws=None) -> None:
     args = GemmArgs()
+    if splitk_ws is not None:
+        args.splitk_ws, args.splitk_ws_bytes = splitk_ws.data_ptr(), splitk_ws.numel() * splitk_ws.element_size()
     if isinstance(problems, GemmProblem):
         problems = [problems]
     args.nprob = len(problems)

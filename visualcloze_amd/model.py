@@ -287,10 +287,15 @@ class Flux(nn.Module):
         tensor) and every parameter of the Linear is left EMPTY, so that preparing a sampling-only rank never holds the
         un-merged and the merged set at once (26.3 GB peak instead of 56.7)."""
         W = m.weight.detach()
-        W32 = W.float()
+        W32 = W.float()                   # NOT a copy when the parameter is f32 already: never update it in place
         B32 = None if m.bias is None else m.bias.detach().float()
         if m.rank:
-            W32 += m.scale * (m.lora_B.weight.detach().float() @ m.lora_A.weight.detach().float())
+            delta = m.scale * (m.lora_B.weight.detach().float() @ m.lora_A.weight.detach().float())
+            if W32.data_ptr() == W.data_ptr() and not consume:
+                W32 = W32 + delta                 # out of place: the module keeps its un-merged weight
+            else:
+                W32 += delta                      # our own f32 temporary (or storage the module gives away)
+            del delta
             if m.lora_B.bias is not None:
                 B32 = (B32 if B32 is not None else 0) + m.scale * m.lora_B.bias.detach().float()
         if out is None and consume and W.dtype == torch.bfloat16 and W.is_contiguous():
@@ -399,10 +404,11 @@ class Flux(nn.Module):
         half = 128
         freqs = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half).to(dev)
         # |q|, |k| <= sqrt(128) * max|scale| after QKNorm (layers.py:75-84; RoPE is a rotation), so with c = 128^-0.5 * log2(e)
-        # every attention logit obeys |c q.k| <= 128 c max|q scale| max|k scale| (+1 % for the bf16 roundings on the way)
+        # every attention logit obeys |c q.k| <= 128 c max|q scale| max|k scale| (+2 %: q and k pass three bf16 roundings each - norm, scale, RoPE -
+        # worth (1 + 2^-9)^6 = 1.012 on the product; the kernel only compares the bound with its <= 100 cutoff)
         qmax = max(float(t.float().abs().max()) for n, t in w.items() if n.endswith("query_norm.scale"))
         kmax = max(float(t.float().abs().max()) for n, t in w.items() if n.endswith("key_norm.scale"))
-        logit_bound = 1.01 * 128 ** 0.5 * 1.4426950408889634 * qmax * kmax
+        logit_bound = 1.02 * 128 ** 0.5 * 1.4426950408889634 * qmax * kmax
         pw = PreparedWeights(w=w, b=b, mod_w=mod_w, mod_b=mod_b, mod_off=off, n_mod=o, temb_freqs=freqs, ref=ref, qkv_heads=qkv_heads,
                              logit_bound=logit_bound)
         self._engine = FluxEngine(self.params, pw, dev)
@@ -443,7 +449,7 @@ class Flux(nn.Module):
             from .handle import FluxHandle
             self._handle = FluxHandle(self.params, eng.W, eng.dev)
         self._handle.set_options(eng.attn_variant, eng.tile_cfg, eng.fuse_qnorm, eng.fuse_vt, eng.W.qkv_heads, eng.fuse_knorm,
-                                 eng.W.logit_bound if eng.bounded_softmax else 0.0, eng.mlp_first)
+                                 eng.W.logit_bound if eng.bounded_softmax else 0.0, eng.mlp_first, eng.splitk)
         return self._handle
 
     # ------------------------------------------------------------------ the B1 boundary

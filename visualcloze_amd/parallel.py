@@ -136,9 +136,12 @@ def max_over_ranks(seconds: float, device: Optional[torch.device] = None, force:
     return float(t.item())
 
 
-def gather_latents(local: Sequence[torch.Tensor], n_samples: int, force: bool = False) -> Optional[List[torch.Tensor]]:
-    """Collect the final latents (0.44 MB per sample at cfg 2) on rank 0 in global sample order, as HOST tensors (in a
-    world of one too).  Every sample of the job normally has one shape and dtype - then ONE padded tensor collective moves
+def gather_latents(local: Sequence[torch.Tensor], n_samples: int, force: bool = False,
+                   to_host: bool = True) -> Optional[List[torch.Tensor]]:
+    """Collect the final latents (0.44 MB per sample at cfg 2) on rank 0 in global sample order.  `to_host` (default):
+    HOST tensors whatever the world size - one contract for the caller that saves or post-processes on the CPU; with
+    `to_host=False` the tensors stay where the collective leaves them (the caller's own device tensors in a world of one -
+    no D2H sync -, rank 0's GPU under RCCL, the host under gloo).  Every sample of the job normally has one shape and dtype - then ONE padded tensor collective moves
     them (no pickling; RCCL gathers device tensors, gloo host tensors); a job that mixes grid sizes or dtypes falls back to
     `gather_object`."""
     if any(t.shape != local[0].shape or t.dtype != local[0].dtype for t in local[1:]):
@@ -146,7 +149,7 @@ def gather_latents(local: Sequence[torch.Tensor], n_samples: int, force: bool = 
     else:
         uniform_here = 1
     if world() == 1 and not (force and dist.is_initialized()):
-        return [t.detach().cpu() for t in local]
+        return [t.detach().cpu() for t in local] if to_host else [t.detach() for t in local]
     w, r = world(), rank()
     slots = (n_samples + w - 1) // w
     on_gpu = dist.get_backend() == "nccl"
@@ -193,7 +196,7 @@ def gather_latents(local: Sequence[torch.Tensor], n_samples: int, force: bool = 
     out = [None] * n_samples
     for rr in range(w):
         for i, k in enumerate(shard_indices(n_samples, rr, w)):
-            out[k] = parts[rr][i].cpu()
+            out[k] = parts[rr][i].cpu() if to_host else parts[rr][i]
     return out  # type: ignore[return-value]
 
 

@@ -35,14 +35,24 @@ WORKLOADS = {
     "384-grid-3x4": dict(rows=3, row_latent=(48, 192), steps=50),
     # cfg 5's SDEdit upsample stage of one 1024x1024 target (visualcloze.py:184-234): 10 points from strength 0.4, no shift
     "1024-sdedit-upsample": dict(rows=1, row_latent=(128, 128), steps=10, t0=0.4, do_shift=False),
+    # shapes the pipeline really produces from non-square photographs (resize_with_aspect_ratio, visualcloze.py:28-60: area
+    # ~384^2, both sides floored to multiples of 16, every row at the aspect of ITS first image, :312-323): 3:4 portraits are
+    # 320x432 px = 54x40 latent = 540 tokens, a 2x3 grid of them N = 3240, L = 3752 - off every 64 / 128 / 256 tile edge;
+    # "mixed": portrait first row, 4:3 landscape (432x320 px) second row - rows of different width in one sequence
+    "384-grid-2x3-p34": dict(row_latents=[(54, 120), (54, 120)], steps=30),
+    "384-grid-2x3-mixed": dict(row_latents=[(54, 120), (40, 162)], steps=30),
 }
+for _w in WORKLOADS.values():
+    _w.setdefault("row_latents", [_w["row_latent"]] * _w["rows"] if "row_latent" in _w else None)
+    _w.setdefault("rows", len(_w["row_latents"]))
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense, MI355X_MICROARCH.md
 
 
-def grid_img_ids(rows, h, w):
-    """models/sampling.py:56-59: axis0 = row index + 1, axis1 = y, axis2 = x (per concatenated row)."""
+def grid_img_ids(rows, h=None, w=None):
+    """models/sampling.py:56-59: axis0 = row index + 1, axis1 = y, axis2 = x (per concatenated row).  `rows`: a count of
+    equal rows of latent size (h, w), or a list of per-row latent sizes."""
     out = []
-    for j in range(rows):
+    for j, (h, w) in enumerate([(h, w)] * rows if isinstance(rows, int) else rows):
         ids = torch.zeros(h // 2, w // 2, 3)
         ids[..., 0] = j + 1
         ids[..., 1] = torch.arange(h // 2)[:, None]
@@ -79,15 +89,14 @@ def build_model(dev, rank, world, lora_rank=256):
 
 
 def make_inputs(dev, wl, seed, B=1):
-    h, w = wl["row_latent"]
-    ids = grid_img_ids(wl["rows"], h, w)
+    ids = grid_img_ids(wl["row_latents"])
     N = ids.shape[0]
     g = torch.Generator(device="cpu").manual_seed(seed)
     x = torch.randn(B, N, 64, generator=g)
     cond = torch.randn(B, N, 320, generator=g)
     mask = torch.zeros(N)
-    per_row = N // wl["rows"]
-    mask[(wl["rows"] - 1) * per_row + per_row * 2 // 3:] = 1          # last cell(s) of the last row masked
+    last = (wl["row_latents"][-1][0] // 2) * (wl["row_latents"][-1][1] // 2)
+    mask[N - last + last * 2 // 3:] = 1                               # last cell(s) of the last row masked
     cond[..., 64:] = mask[None, :, None]
     kw = dict(txt=torch.randn(B, 512, 4096, generator=g).to(dev, torch.bfloat16), txt_ids=torch.zeros(B, 512, 3, device=dev),
               txt_mask=torch.ones(B, 512, dtype=torch.int32, device=dev),
@@ -338,6 +347,9 @@ def roofline_attention(job, iters=3):
     fused_q = bool(v & 8) and eng.fuse_qnorm
     sc = eng.W.w["single_blocks.0.norm.query_norm.scale"]
     qn = (sc, None, 0, ws.ROPE) if fused_q else None
+    bound = eng.W.logit_bound if eng.bounded_softmax else 0.0
+    # attention64.hip runs attn64_kernel<true> (no running max) when the weights' norm scales bound the logits by <= 100
+    template = ("attn64_kernel<true> (bounded logits: no running max)" if 0.0 < bound <= 100.0 else "attn64_kernel<false> (running max)") if v & 8 else "attn_fwd_kernel"
     with torch.cuda.stream(eng.stream):
         ws.STEP.zero_()
         eng.eval_once(ws, ws.STEP, euler=False, s=s)              # warm
@@ -353,7 +365,7 @@ def roofline_attention(job, iters=3):
 
         def iso():
             hip.attention(ws.QKV, ws.VT, ws.CAT[:, :eng.D], ws.L, eng.H, variant=v, stream=s, B=ws.B, scratch=eng.attn_scratch,
-                          q_norm=qn)
+                          q_norm=qn, logit_bound=bound)          # the SAME instantiation the product launches
         iso()
         e0, e1 = hip.Event(), hip.Event()
         e0.record(s)
@@ -362,7 +374,7 @@ def roofline_attention(job, iters=3):
         e1.record(s)
         ms_iso = e0.elapsed_ms(e1) / (iters * 10)
     fl = 4.0 * ws.L * ws.L * eng.D * ws.B
-    return dict(kernel="attn64_kernel (+ attn64_merge_kernel)" if v & 8 else "attn_fwd_kernel", variant=v,
+    return dict(kernel=(template + " + attn64_merge_kernel") if v & 8 else template, variant=v, logit_bound=round(bound, 3),
                 query_norm_in_kernel=fused_q, timed="in situ: HIP events around each attention launch inside product-plan "
                 "evaluations", launches_timed=len(situ), avg_launch_us=round(ms * 1e3, 2),
                 median_launch_us=round(situ[len(situ) // 2] * 1e3, 2), isolated_us=round(ms_iso * 1e3, 2),
@@ -392,7 +404,7 @@ def cpu_baseline(T, N, wl):
                "s.linear2.weight": r(D, 5 * D), "s.linear2.bias": torch.zeros(D),
                "s.norm.query_norm.scale": torch.ones(128), "s.norm.key_norm.scale": torch.ones(128)})
     img, txt, vec = torch.randn(1, N, D, generator=g), torch.randn(1, T, D, generator=g), torch.randn(1, D, generator=g)
-    ids = torch.cat((torch.zeros(T, 3), grid_img_ids(wl['rows'], *wl['row_latent'])))[None]
+    ids = torch.cat((torch.zeros(T, 3), grid_img_ids(wl['row_latents'])))[None]
     cs = O.rope_cos_sin(ids, G.axes_dim, G.theta)
     x = torch.cat((txt, img), 1)
 
@@ -420,10 +432,12 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.traffic = committed file)")
     ap.add_argument("--traffic-probe", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--stub-engine", action="store_true", help=argparse.SUPPRESS)   # tests: the driver over gloo without a GPU
     ap.add_argument("--tile-cfg", type=int, default=None)
     ap.add_argument("--attn-variant", type=int, default=None)
     ap.add_argument("--no-fuse-vt", action="store_true", help="A/B: V^T by the pre-pass kernel instead of the qkv GEMM's epilogue")
     ap.add_argument("--no-fuse-knorm", action="store_true", help="A/B: key QKNorm + RoPE by the pre-pass kernel instead of the qkv GEMM's epilogue")
+    ap.add_argument("--no-splitk", action="store_true", help="A/B: never cut GEMM remainder tiles along K (VcGemmArgs.splitk_ws)")
     ap.add_argument("--python-plan", action="store_true",
                     help="A/B: order the launches from Python (engine.FluxEngine) instead of the C handle API")
     ap.add_argument("--per-gpu-batch", type=int, default=1,
@@ -474,15 +488,62 @@ def result_record(a, wl, world, elapsed, T, N, bcast_s, weight_bytes):
     return rec
 
 
+def self_launch(a, argv):
+    """`python bench.py --gpus N` started BARE (no WORLD_SIZE in the environment): re-run this command as N ranks under
+    torch.distributed.run on this node - the launch line the task statement gives - and hand its exit code back.  Rank 0 of
+    the child job prints the one JSON line on the inherited stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))   # dmabuf IPC for RCCL
+    return subprocess.call(cmd, env=env)
+
+
+class StubJob:
+    """--stub-engine (tests only): the Job protocol without a GPU - what the multi-rank driver needs to be exercised over gloo"""
+
+    def __init__(self, rank):
+        self.rank = rank
+
+    def restart_sample(self):
+        pass
+
+    def step(self):
+        time.sleep(0.002 * (self.rank + 1))
+
+
 def main(argv=None):
     a = parse_args(argv)
     if a.traffic_probe:
         return traffic_probe()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        rc = self_launch(a, argv)
+        if rc != 0:
+            raise SystemExit(rc)
+        return
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    if a.stub_engine:
+        from visualcloze_amd import parallel as par
+        par.init_distributed("gloo")
+        wl = WORKLOADS[a.workload]
+        elapsed = timed_region(StubJob(rank), a.steps, a.warmup)
+        N = sum((h // 2) * (w // 2) for h, w in wl["row_latents"])
+        rec = result_record(a, wl, world, elapsed, 512, N, bcast_s=0.0, weight_bytes=0)
+        rec["data"] = "stub engine (driver test, no GPU)"
+        if rank == 0:
+            print(json.dumps(rec), flush=True)
+        par.barrier()
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
     from visualcloze_amd import hip
     hip.require_gpu()                       # fails loudly: there is no CPU path to fall back to
     torch.cuda.set_device(local)
@@ -503,6 +564,7 @@ def main(argv=None):
     eng.fuse_vt = not a.no_fuse_vt
     if a.no_fuse_knorm:
         eng.fuse_knorm = False
+    eng.splitk = not a.no_splitk
     PB = a.per_gpu_batch
     x, kw = make_inputs(dev, wl, seed=par.sample_seed(0, rank * PB), B=PB)   # seed from the global sample index
     job = Job(model, x, kw, wl["steps"], t0=wl.get("t0", 0.0), do_shift=wl.get("do_shift", True))

@@ -6,6 +6,10 @@ SURVEY.md §8's table:
     cfg 3   512-grid 2x3           N = 6144   L = 6656
     cfg 5   384-grid 3x4           N = 6912   L = 7424
     sdedit  cfg 5's upsample stage N = 4096   L = 4608      (one 1024x1024 target, unshifted strength-0.4 grid)
+and for two shapes the pipeline REALLY produces from non-square photographs (visualcloze.py:28-60,312-323: area ~ 384^2, sides
+floored to multiples of 16, every row at the aspect of its first image) - off every 64 / 128 / 256 tile edge:
+    p34     384-grid 2x3 of 3:4 portraits (320x432 px, 540 tokens each)                N = 3240   L = 3752
+    mixed   the same grid with a 4:3 landscape second row (432x320 px: rows 54x120 and 40x162 latent)   L = 3752
 
 Per geometry:
 * a full-WIDTH Flux with 1 double + 1 single block against the oracle on the CPU (bf16 mode = same rounding points,
@@ -36,7 +40,14 @@ GEOMS = {                         # rows of the grid, latent (h, w) of one conca
     "cfg3": (2, (64, 192)),
     "cfg5": (3, (48, 192)),
     "sdedit": (1, (128, 128)),
+    "p34": [(54, 120), (54, 120)],           # per-row latent sizes
+    "mixed": [(54, 120), (40, 162)],
 }
+
+
+def _rows(geom):
+    g = GEOMS[geom]
+    return list(g) if isinstance(g, list) else [g[1]] * g[0]
 N2 = 3456
 L2 = T + N2
 
@@ -48,10 +59,9 @@ def rel_l2(a, b):
 
 def _inputs(geom="cfg2", seed=0):
     from bench import grid_img_ids
-    rows, (h, w) = GEOMS[geom]
     g = torch.Generator().manual_seed(seed)
     r = lambda *s: torch.randn(*s, generator=g)  # noqa: E731
-    ids = grid_img_ids(rows, h, w)
+    ids = grid_img_ids(_rows(geom))
     N = ids.shape[0]
     return dict(x=r(1, N, 64), cond=r(1, N, 320), img_ids=ids[None], txt=r(1, T, 4096), txt_ids=torch.zeros(1, T, 3),
                 y=r(1, 768), txt_mask=torch.ones(1, T, dtype=torch.int32), img_mask=torch.ones(1, N, dtype=torch.int32),
@@ -126,6 +136,39 @@ def test_full_width_one_plus_one_blocks_vs_oracle(small_model, geom):
     assert e32 < max(3e-2, 4 * floor)
 
 
+@pytest.mark.parametrize("qmax,kmax,bounded", [(1.5, 1.5, True), (3.0, 3.0, False)])
+def test_full_width_non_unit_norm_scales_both_sides_of_the_logit_bound(qmax, kmax, bounded):
+    """Which attention instantiation runs is a property of the WEIGHTS: attn64_kernel<true> (no running max) while
+    16.65 * max|query_norm.scale| * max|key_norm.scale| <= 100 (model.prepare; every other full-size test and the bench use unit
+    scales and therefore always take it), attn64_kernel<false> (running max) beyond - a real checkpoint may sit on either side.
+    One full-width evaluation (cfg 2 geometry, 1 + 1 blocks) with NON-UNIT scales on each side of the switch against the oracle
+    (layers.py:63-84; bounds as test_full_width_one_plus_one_blocks_vs_oracle)."""
+    import oracle.flux_oracle as O
+    from tests.helpers import parity_log
+    m = _build(1, 1, seed=7)
+    g = torch.Generator(device=DEV).manual_seed(11)
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            if name.endswith("norm.scale"):
+                hi = qmax if "query_norm" in name else kmax
+                p.copy_(0.5 + (hi - 0.5) * torch.rand(p.shape, device=DEV, generator=g).to(p.dtype))
+                p[0] = hi
+    sd = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    inp = _inputs("cfg2", seed=9)
+    t = torch.tensor([0.62])
+    got = _call(m, inp, t)
+    eng = m.engine()
+    assert (0.0 < eng.W.logit_bound <= 100.0) == bounded, eng.W.logit_bound
+    assert eng.attention_variant(eng.workspace(T, inp["x"].shape[1], 1, 1)) == 12
+    want_bf16, want_fp32 = _oracle_pair(sd, O.FluxGeometry(depth=1, depth_single_blocks=1), inp, t)
+    floor, e16, e32 = rel_l2(want_bf16, want_fp32), rel_l2(got, want_bf16), rel_l2(got, want_fp32)
+    parity_log(f"[1+1 blocks, cfg2, norm scales up to {qmax} / {kmax}: logit bound {eng.W.logit_bound:.1f} -> attn64_kernel<{str(bounded).lower()}>] "
+               f"HIP vs bf16 oracle {e16:.3e}, vs fp32 oracle {e32:.3e}, oracle bf16-vs-fp32 floor {floor:.3e}")
+    assert e16 < 1.5e-2 and e32 < max(3e-2, 4 * floor)
+    del m
+    torch.cuda.empty_cache()
+
+
 def test_full_width_batch_of_two_equals_per_sample(small_model):
     """A per-GPU batch at full width (cfg 2 geometry, B = 2, different text / guidance per sample): one stacked launch
     sequence - batch-strided qkv rows, the key norm of both samples in the GEMM's epilogue with per-sample RoPE rows, V^T per
@@ -146,8 +189,7 @@ def test_full_width_batch_of_two_equals_per_sample(small_model):
 @pytest.mark.parametrize("geom", list(GEOMS))
 def test_attention_properties(geom):
     from visualcloze_amd import hip
-    rows, (h, w) = GEOMS[geom]
-    L = T + rows * (h // 2) * (w // 2)
+    L = T + sum((h // 2) * (w // 2) for h, w in _rows(geom))
     Lp = (L + 63) // 64 * 64
     g = torch.Generator().manual_seed(5)
     qkv = (torch.randn(L, 3 * D, generator=g)).to(torch.bfloat16).to(DEV)
@@ -359,12 +401,13 @@ def procedural_small_model():
     return _build_procedural(1, 1)
 
 
-@pytest.mark.parametrize("case", ["cfg2", "sdedit", "cfg5"])
+@pytest.mark.parametrize("case", ["cfg2", "sdedit", "cfg5", "cfg5_50"])
 def test_full_width_trajectory_vs_oracle(procedural_small_model, case):
     """The WHOLE loop at full width against the oracle's own trajectories (transport/integrators.py:106-120,
     transport/transport.py:384): cfg 2's 30-point shifted grid = 29 evaluations at L = 3968, and the SDEdit stage's 10
     points from strength 0.4 = 9 evaluations at L = 4608, and cfg 5's 29 evaluations at L = 7424 (the largest BASELINE geometry;
-    its own fixture file), D = 3072, 1 + 1 blocks.  The fused sampler's intermediate and
+    its own fixture file) - and cfg 5 as BASELINE.json quotes it, 50 solver points = 49 evaluations (`cfg5_50`) -, D = 3072,
+    1 + 1 blocks.  The fused sampler's intermediate and
     FINAL latents are held to the bf16-merged oracle (same rounding points) and the fp32-ref oracle (exact reference
     semantics), with bounds stated against `floor` = the oracle's own bf16-vs-fp32 deviation on the same state:
         HIP vs bf16 oracle <= floor,   HIP vs fp32 oracle <= 1.5 * floor      (final state and every saved one;
@@ -430,6 +473,45 @@ def test_full_depth_at_both_ends_of_the_time_grid_vs_oracle(procedural_full_mode
                    f"{e32:.3e}, oracle bf16-vs-fp32 floor {floor:.3e}")
         assert torch.isfinite(got).all()
         assert e16 < 1.5 * floor and e32 < 2.0 * floor, (float(t), e16, e32, floor)
+
+
+def test_full_depth_trajectory_vs_oracle(procedural_full_model):
+    """The one combination the other fixtures leave open: a TRAJECTORY through the FULL-DEPTH model.  The first three solver
+    steps of cfg 2's 30-point grid (19 + 38 blocks, 13.1 B procedural parameters, L = 3968), the state fed back after every
+    evaluation (transport/integrators.py:99-120), against the oracle's own two trajectories
+    (`tests/golden/make_fulldepth_times.py --traj 3` -> fulldepth_traj_oracle.npz; each mode steps ITS state).  The fused
+    sampler runs the whole 29-evaluation loop; states 1..3 are compared.  Bounds as for single full-depth evaluations:
+    HIP vs bf16-merged oracle <= 1.5 * floor, vs fp32-ref oracle <= 2 * floor, floor = the oracle's own bf16-vs-fp32
+    deviation on that state."""
+    import numpy as np
+    from tests.helpers import parity_log
+    from visualcloze_amd.transport import Sampler, create_transport
+    path = os.path.join(os.path.dirname(TIMES_FIXTURE), "fulldepth_traj_oracle.npz")
+    if not os.path.exists(path):
+        pytest.skip("fulldepth_traj_oracle.npz not generated (tests/golden/make_fulldepth_times.py --traj 3, ~70 min of CPU)")
+    FT = _traj_module()
+    fx = np.load(path)
+    inp = FT.inputs("cfg2")
+    assert float(fx["x_sum"]) == inp["x"].double().sum().item()
+    m = procedural_full_model
+    fn = Sampler(create_transport()).sample_ode(sampling_method="euler", num_steps=30, do_shift=True, time_shifting_factor=1,
+                                                 return_trajectory=True)
+    kw = dict(_kw(inp), guidance=inp["guidance"].to(DEV))     # f32 guidance: the value both oracle modes were run with
+    tr = fn(inp["x"].to(DEV, torch.bfloat16), m.forward, kw)
+    torch.cuda.synchronize()
+    assert tr.shape[0] == 30 and torch.isfinite(tr.float()).all()
+    K = len(fx["t"]) - 1
+    from visualcloze_amd.transport import model_times, solver_time_grid
+    t = solver_time_grid(30, inp["x"].shape[1], 0, 1, True, 1)
+    assert np.array_equal(t[:K + 1].numpy(), fx["t"])                                            # same grid points ...
+    assert np.allclose(model_times(t, tr[0])[:K].double().numpy(), fx["bf16_model_t"], atol=0, rtol=0)   # ... same Flux times
+    for k in range(1, K + 1):
+        b16 = torch.tensor(fx[f"bf16_{k}"]).view(torch.bfloat16).float()
+        f32 = torch.tensor(fx[f"fp32_{k}"].astype("float32"))
+        floor, e16, e32 = rel_l2(b16, f32), rel_l2(tr[k], b16), rel_l2(tr[k], f32)
+        parity_log(f"[trajectory through the FULL-DEPTH model 19+38, cfg2] state {k}/{K}: HIP vs bf16-merged oracle {e16:.3e}, vs fp32-ref "
+                   f"oracle {e32:.3e}, oracle bf16-vs-fp32 floor {floor:.3e}")
+        assert e16 < 1.5 * floor and e32 < 2.0 * floor, (k, e16, e32, floor)
 
 
 @pytest.mark.parametrize("geom", ["cfg3", "cfg5"])

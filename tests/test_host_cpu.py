@@ -251,3 +251,45 @@ def test_procedural_torch_equals_numpy():
     n = (1 << 24) + 5
     assert torch.equal(ptensor((n,), 77), ptensor_torch((n,), 77))
     assert torch.equal(ptensor((33, 7), 5, q=6).to(torch.bfloat16), ptensor_torch((33, 7), 5, q=6, dtype=torch.bfloat16))
+
+
+def test_compat_install_aliases_the_reference_import_names(tmp_path):
+    """visualcloze_amd.compat.install(): the reference's own `from models.model import Flux, FluxLoraWrapper, FluxParams`
+    (models/util.py:11) and `from transport import Sampler, create_transport` (visualcloze.py:12) resolve to the MI355X
+    implementations with no source edit.  Exercised on a stand-in tree with the reference's import lines and its
+    `load_flow_model` construction (models/util.py:384-404), in a child interpreter (sys.modules is process state), through
+    both entry points: install() in code and `python -m visualcloze_amd.compat script.py`."""
+    import subprocess
+    import sys
+    import textwrap
+    (tmp_path / "models").mkdir()
+    (tmp_path / "models" / "__init__.py").write_text("")
+    (tmp_path / "models" / "util.py").write_text(textwrap.dedent("""
+        import torch
+        from models.model import Flux, FluxLoraWrapper, FluxParams
+        PARAMS = FluxParams(in_channels=384, out_channels=64, vec_in_dim=32, context_in_dim=64, hidden_size=256, mlp_ratio=4.0, num_heads=2,
+                            depth=1, depth_single_blocks=1, axes_dim=[16, 56, 56], theta=10_000, qkv_bias=True, guidance_embed=True)
+        def load_flow_model(name, device="cpu", lora_rank=128, lora_scale=1.0):
+            return FluxLoraWrapper(params=PARAMS, lora_rank=lora_rank, lora_scale=lora_scale).to(torch.bfloat16)
+    """))
+    (tmp_path / "pipeline_like.py").write_text(textwrap.dedent("""
+        from models.util import load_flow_model
+        from transport import Sampler, create_transport
+        import visualcloze_amd.model as M, visualcloze_amd.transport as T
+        m = load_flow_model("flux-dev-fill-lora", lora_rank=8)
+        assert type(m) is M.FluxLoraWrapper and Sampler is T.Sampler and create_transport is T.create_transport
+        fn = Sampler(create_transport("Linear", "velocity", do_shift=True)).sample_ode(sampling_method="euler", num_steps=4, atol=1e-6,
+                                                                                     rtol=1e-3, reverse=False, do_shift=True, time_shifting_factor=1)
+        assert callable(fn) and "double_blocks.0.img_attn.qkv.lora_A.weight" in m.state_dict()
+        print("drop-in ok")
+    """))
+    env = dict(os.environ, PYTHONPATH=REPO)
+    code = f"import sys; sys.path.insert(0, {str(tmp_path)!r}); import visualcloze_amd.compat as c; c.install(); import pipeline_like"
+    for cmd in ([sys.executable, "-c", code], [sys.executable, "-m", "visualcloze_amd.compat", str(tmp_path / "pipeline_like.py")]):
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+        assert r.returncode == 0 and "drop-in ok" in r.stdout, r.stdout + r.stderr
+    # too late: the name is taken by another module already
+    code = (f"import sys, types; sys.modules['transport'] = types.ModuleType('transport'); import visualcloze_amd.compat as c\n"
+            "try:\n    c.install()\nexcept RuntimeError as e:\n    print('refused:', e)")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert "refused:" in r.stdout and "already imported" in r.stdout, r.stdout + r.stderr

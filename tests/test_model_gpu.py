@@ -570,3 +570,18 @@ def test_two_stage_chain_generate_then_sdedit_upsample(model):
     # strength >= 1: the resized image is returned untouched (visualcloze.py:180-181)
     same = pipeline.upsample_image(m, ae, t5, clip, crops[1], (64, 48), ct5, cclip, rng, strength=1.0)
     assert same.shape == (3, 48, 64)
+    # TWO masked cells: refined together (one graph replay per solver step for both, the default) == one after the other as
+    # the reference loops (visualcloze.py:450-465) - same draws in the same order; per target equal up to the bf16 noise of
+    # another GEMM tile plan (the bar of test_full_width_batch_of_two_equals_per_sample)
+    masks2 = [c(torch.zeros(1, 1, H, W)), c(torch.ones(1, 1, H, W))]
+    up2 = [(c(ptensor((16, 6, 8), 231 + 2 * k, q=5)), c(ptensor((16, 6, 8), 232 + 2 * k, q=5))) for k in range(2)]
+    args2 = (m, ae, t5, clip, rows, masks2, t5_ids, clip_ids, 5, 2, [True, True])
+    kw2 = dict(target_size=(70, 50), content_t5_ids=ct5, content_clip_ids=cclip, encode_noise=enoise, upsample_encode_noise=up2, **kw)
+    together = pipeline.generate_and_upsample(*args2, **kw2)
+    serial = pipeline.generate_and_upsample(*args2, batch_targets=False, **kw2)
+    torch.cuda.synchronize()
+    assert len(together) == len(serial) == 2
+    for a2, b2 in zip(together, serial):
+        assert a2.shape == b2.shape == (3, 48, 64)
+        assert ((a2 - b2).norm() / b2.norm()).item() < 1e-2
+    assert not torch.equal(serial[0], serial[1])

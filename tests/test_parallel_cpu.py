@@ -155,6 +155,27 @@ def test_bench_driver_world8_gloo_stub_engine(tmp_path):
     assert rec["n_gpus"] == 8 and rec["metric"] == "denoising-steps/sec" and rec["higher_is_better"] is True
 
 
+def test_bench_bare_gpus_flag_launches_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT WORLD_SIZE in the environment (the form the round-end driver used for --gpus 1) must not
+    exit with an error: bench.main re-runs itself under `torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr
+    127.0.0.1`, both ranks rendezvous (gloo, stub engine: no GPU here), rank 0 prints the one JSON line of the contract."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    code = "import sys; sys.path.insert(0, %r); import bench; bench.main(['--gpus', '2', '--steps', '5', '--warmup', '1', '--stub-engine'])" % REPO
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout + r.stderr                      # ONE line, from rank 0 of the child job
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["steps"] == 5 and rec["config"]["parallelism"] == "dp2"
+    assert rec["value"] <= 2 * 5 / (5 * 0.004) * 1.01                # whole-job steps over the SLOWEST rank's time (rank 1: 4 ms / step)
+    # a WORLD_SIZE that contradicts --gpus is still an error, not a silent single-rank run
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--stub-engine"], env=dict(env, WORLD_SIZE="1"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
 def test_cpulist_parser():
     from visualcloze_amd import parallel as par
     assert par.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]

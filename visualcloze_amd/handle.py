@@ -19,6 +19,26 @@ def _f32(a) -> np.ndarray:
                                 dtype=np.float32)
 
 
+class _HostCopies:
+    """Host copies of small DEVICE inputs (ids, guidance) that vc_flux_prepare takes as host arrays, remembered per argument
+    while the caller keeps handing over the SAME tensor object at the same version: a D2H copy synchronises the stream, i.e.
+    drains every queued solver step - once per grid that is nothing, once per 3-evaluation sample (cfg 1) it left the GPU idle
+    for 2 - 6 % of the run.  The tensor is held strongly, so its address cannot be recycled while the entry lives."""
+
+    def __init__(self):
+        self._c: Dict[str, tuple] = {}
+
+    def f32(self, key: str, t) -> np.ndarray:
+        if not torch.is_tensor(t) or not t.is_cuda:
+            return _f32(t)
+        e = self._c.get(key)
+        if e is not None and e[0] is t and e[1] == t._version:
+            return e[2]
+        a = _f32(t)
+        self._c[key] = (t, t._version, a)
+        return a
+
+
 def _fp(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(C.POINTER(C.c_float))
 
@@ -57,6 +77,7 @@ class FluxHandle:
         self._ws: Dict[tuple, torch.Tensor] = {}
         self._opts: Dict[str, int] = {}
         self.geom: Optional[Tuple[int, int, int, int]] = None
+        self._host = _HostCopies()
         # the storage order of the bound qkv rows (head-permuted or natural) and the logit bound are PROPERTIES OF THE
         # WEIGHTS, not knobs: a handle built directly must un-permute exactly as model.handle()'s does
         self.set_options()
@@ -116,8 +137,11 @@ class FluxHandle:
         B, T = txt.shape[0], txt.shape[1]
         N = img_ids.shape[-2]
         txt, y = txt.contiguous(), y.contiguous()
-        g = None if guidance is None else _f32(guidance.reshape(-1).expand(B) if guidance.numel() == 1 else guidance.reshape(B))
-        ii, ti = _f32(img_ids.reshape(B, N, 3)), _f32(txt_ids.reshape(B, T, 3))
+        g = None
+        if guidance is not None:
+            g = self._host.f32("guidance", guidance).reshape(-1)
+            g = np.ascontiguousarray(np.broadcast_to(g, (B,)) if g.size == 1 else g.reshape(B))
+        ii, ti = self._host.f32("img_ids", img_ids).reshape(B, N, 3), self._host.f32("txt_ids", txt_ids).reshape(B, T, 3)
         kv = None if kv_len is None or all(int(v) == T + N for v in kv_len) else np.asarray([int(v) for v in kv_len], np.int32)
         gp = None
         if kv_gap is not None and any(hi > lo for lo, hi in kv_gap):

@@ -64,6 +64,36 @@ def sdedit_upsample(model, noise: torch.Tensor, latent: torch.Tensor, blank_late
 
 
 @torch.no_grad()
+def sdedit_upsample_batch(model, noises: Sequence[torch.Tensor], latents: Sequence[torch.Tensor],
+                          blank_latents: Sequence[torch.Tensor], txt: torch.Tensor, vec: torch.Tensor, cfg: float = 30.0,
+                          steps: int = 10, strength: float = 0.4, solver: str = "euler") -> List[torch.Tensor]:
+    """`sdedit_upsample` for K targets of ONE size and prompt advanced TOGETHER: the reference refines the masked cells of a
+    grid one after the other (visualcloze.py:450-465), each an independent ODE solve over the same (T, N), so they stack into
+    a per-GPU batch - one graph replay per solver step moves all of them (chunks of <= 4) and the GEMMs see M = K * L rows:
+    at L = 4608 that is +14 % (K = 2) / +17 % (K = 4) evaluations per second over one target at a time
+    (profiles/r04a_per_gpu_batch_probe.json).  Per target the result equals the one-at-a-time call up to the bf16 noise of
+    another GEMM tile plan (tests/test_model_gpu.py).  txt [1,T,4096] / vec [1,768]: the shared content prompt."""
+    K = len(noises)
+    if K == 0:
+        return []
+    dev = latents[0].device
+    h, w = latents[0].shape[-2:]
+    if any(t.shape[-2:] != (h, w) for t in list(noises) + list(latents) + list(blank_latents)):
+        raise ValueError("sdedit_upsample_batch: all targets must share one latent size")
+    img, img_ids, img_mask = packing.prepare_grid([[n] for n in noises])
+    lat_tok, _, _ = packing.prepare_grid([[l] for l in latents])
+    x0 = hip.sdedit_mix(img, lat_tok, strength)                                        # :221, all targets at once
+    ones = torch.ones(1, 1, 8 * h, 8 * w, dtype=torch.bfloat16, device=dev)
+    cond = torch.cat([packing.pack_cond([b], [ones]) for b in blank_latents], dim=0)
+    fn = Sampler(create_transport("Linear", "velocity", do_shift=True)).sample_ode(
+        sampling_method=solver, num_steps=steps, atol=1e-6, rtol=1e-3, reverse=False, do_shift=False,
+        time_shifting_factor=1.0, strength=strength)
+    kw = _kwargs(img_ids, img_mask, txt.expand(K, -1, -1), vec.expand(K, -1), cond, cfg, dev)
+    sample = fn(x0, model.forward, kw)[-1]
+    return [packing.unpack_rows(sample[k:k + 1], [(h, w)])[0] for k in range(K)]
+
+
+@torch.no_grad()
 def generate_grid(model, ae, t5, clip, row_images: List[torch.Tensor], row_masks: List[torch.Tensor],
                   t5_ids: torch.Tensor, clip_ids: torch.Tensor, seed: int, cfg: float = 30.0, steps: int = 30,
                   encode_noise: Optional[List[torch.Tensor]] = None, decode_rows: Optional[Sequence[int]] = None,
@@ -147,17 +177,52 @@ def upsample_image(model, ae, t5, clip, image, target_size, t5_ids: torch.Tensor
 
 
 @torch.no_grad()
+def upsample_images(model, ae, t5, clip, images: Sequence, target_size, t5_ids: torch.Tensor, clip_ids: torch.Tensor,
+                    rng: torch.Generator, cfg: float = 30.0, steps: int = 10, strength: float = 0.4,
+                    encode_noise: Optional[Sequence] = None, solver: str = "euler") -> List[torch.Tensor]:
+    """`upsample_image` for several images of one grid in ONE batched SDEdit solve (`sdedit_upsample_batch`).  Host work
+    (resize), the VAE encodes and every random draw happen per image in the reference's order - image k: encode(image),
+    encode(blank), noise from `rng` (visualcloze.py:200-217) - so each target starts from exactly the state the
+    one-at-a-time loop gives it; the prompt is encoded once (it is the same for every target, :458)."""
+    import numpy as np
+    dev = next(ae.parameters()).device
+    size = upsampling_size(target_size)
+    pxs = []
+    for image in images:
+        if torch.is_tensor(image):
+            image = to_uint8_image(image)
+        image = image.convert("RGB").resize(size)                                      # :179
+        pxs.append(torch.from_numpy(np.asarray(image, dtype=np.uint8).copy()).permute(2, 0, 1).float().div(255.0))
+    if strength >= 1.0:
+        return [px.to(dev) for px in pxs]                                              # :180-181
+    lat, blank, noise = [], [], []
+    for k, px in enumerate(pxs):
+        px = ((px - 0.5) / 0.5).to(dev, torch.bfloat16)
+        n_img, n_blank = (None, None) if encode_noise is None or encode_noise[k] is None else encode_noise[k]
+        nz = lambda n: None if n is None else n[None] if n.dim() == 3 else n  # noqa: E731
+        lat.append(ae.encode(px[None], noise=nz(n_img)))
+        blank.append(ae.encode(torch.zeros_like(px)[None], noise=nz(n_blank)))
+        noise.append(torch.randn([1, 16, lat[-1].shape[-2], lat[-1].shape[-1]], device=dev, generator=rng).to(torch.bfloat16))
+    txt = t5(t5_ids)
+    vec, _ = clip(clip_ids)
+    zs = sdedit_upsample_batch(model, noise, lat, blank, txt, vec, cfg=cfg, steps=steps, strength=strength, solver=solver)
+    return [((ae.decode(z)[0].float() + 1.0) / 2.0).clamp_(0.0, 1.0) for z in zs]     # :238-240
+
+
+@torch.no_grad()
 def generate_and_upsample(model, ae, t5, clip, row_images: List[torch.Tensor], row_masks: List[torch.Tensor],
                           t5_ids: torch.Tensor, clip_ids: torch.Tensor, seed: int, grid_w: int, mask_position: Sequence[bool],
                           target_size=None, content_t5_ids: Optional[torch.Tensor] = None,
                           content_clip_ids: Optional[torch.Tensor] = None, cfg: float = 30.0, steps: int = 30,
                           upsampling_steps: int = 10, upsampling_noise: float = 0.4, is_upsampling: bool = True,
                           encode_noise: Optional[List[torch.Tensor]] = None, upsample_encode_noise=None,
-                          solver: str = "euler", time_shifting_factor=1):
+                          solver: str = "euler", time_shifting_factor=1, batch_targets: bool = True):
     """Both stages of `process_images` chained (visualcloze.py:363-465): the grid is generated, its LAST row is decoded and
     quantised to 8 bits as `to_pil_image` does, every cell of that row whose `mask_position` is set is cropped
     (:452,461) and - with `is_upsampling` - refined by `upsample_image` at `target_size`, all noise coming from ONE
-    generator seeded with `seed` (:394,456).  Returns the output images as [3, h, w] tensors in [0, 1]."""
+    generator seeded with `seed` (:394,456).  `batch_targets` (default): the masked cells are refined TOGETHER, one graph replay
+    per solver step for all of them (`upsample_images`; same draws in the same order, per-target results equal up to bf16
+    noise); False = one after the other as the reference loops.  Returns the output images as [3, h, w] tensors in [0, 1]."""
     dev = row_images[0].device
     rng = torch.Generator(device=dev).manual_seed(int(seed))
     last = len(row_images) - 1
@@ -166,6 +231,12 @@ def generate_and_upsample(model, ae, t5, clip, row_images: List[torch.Tensor], r
                         rng=rng)[0]
     pil = to_uint8_image(row)                                                          # :437-439
     ret_w, ret_h = pil.width, pil.height
+    cells = [pil.crop((i * ret_w // grid_w, 0, (i + 1) * ret_w // grid_w, ret_h)) for i, m in enumerate(mask_position) if m]   # :452,461
+    ct5 = content_t5_ids if content_t5_ids is not None else t5_ids
+    cclip = content_clip_ids if content_clip_ids is not None else clip_ids
+    if is_upsampling and batch_targets and len(cells) > 1:
+        return upsample_images(model, ae, t5, clip, cells, target_size, ct5, cclip, rng, cfg=cfg, steps=upsampling_steps,
+                               strength=upsampling_noise, encode_noise=upsample_encode_noise, solver=solver)
     outs, k = [], 0
     for i, masked in enumerate(mask_position):
         if not masked:

@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--steps", type=int, default=29)
     ap.add_argument("--attn", action="store_true", help="also time the attention launches in situ (Python-ordered plan)")
     ap.add_argument("--opt", action="append", default=[])
+    ap.add_argument("--per-gpu-batch", type=int, default=1)
     a = ap.parse_args()
     hip.require_gpu()
     dev = torch.device("cuda", 0)
@@ -49,7 +50,7 @@ def main():
     wl = bench.WORKLOADS[a.workload]
     model, _ = bench.build_model(dev, 0, 1)
     eng = model.prepare(free_parameters=True)
-    x, kw = bench.make_inputs(dev, wl, seed=0)
+    x, kw = bench.make_inputs(dev, wl, seed=0, B=a.per_gpu_batch)
     builds = [(b.split("=")[0], b.split("=")[-1]) for b in a.builds]
     opts = {}
     for o in a.opt:
@@ -57,7 +58,8 @@ def main():
         k, v = kv.split("=")
         opts.setdefault(who, {})[k] = int(v)
     base_opts = dict(attn_variant=eng.attn_variant, tile_cfg=eng.tile_cfg, fuse_qnorm=eng.fuse_qnorm, fuse_vt=eng.fuse_vt,
-                     fuse_knorm=eng.fuse_knorm, bounded_softmax=eng.bounded_softmax, mlp_first=eng.mlp_first)
+                     fuse_knorm=eng.fuse_knorm, bounded_softmax=eng.bounded_softmax, mlp_first=eng.mlp_first,
+                     splitk=eng.splitk)
     jobs, libs = {}, {}
     for libname, alias in builds:
         libs[alias] = load(libname)

@@ -658,7 +658,11 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
 #pragma unroll
     for (int e = 0; e < 4; ++e) { v[2 * e] = lo_bf(tw[e]); v[2 * e + 1] = hi_bf(tw[e]); }
     u32x4 o = tw;
+#ifdef VC_GEMM_NO_GELU      // analysis builds only (tools/step_ab.py): what ANY cheaper GELU could win at most - the math left out
+    if (false) {
+#else
     if (EPI == VC_EPI_GELU) {
+#endif
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const f32x2 g = gelu_tanh2(f32x2{v[2 * e], v[2 * e + 1]});

@@ -6,7 +6,8 @@ import os
 import re
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DOCS = ["DESIGN.md", "README.md", "INTEGRATION.md", os.path.join("profiles", "README.md"), os.path.join("tools", "README.md")]
+DOCS = ["DESIGN.md", "README.md", "INTEGRATION.md", os.path.join("profiles", "README.md"), os.path.join("tools", "README.md"),
+        os.path.join("profiles", "DESIGN_r01_r03_narrative.md")]
 
 
 def _exists(name: str) -> bool:
@@ -31,7 +32,7 @@ def test_cited_profile_files_exist():
 
 def test_cited_tools_exist():
     missing = []
-    for doc in ("DESIGN.md", os.path.join("tools", "README.md"), os.path.join("profiles", "README.md")):
+    for doc in ("DESIGN.md", os.path.join("tools", "README.md"), os.path.join("profiles", "README.md"), os.path.join("profiles", "DESIGN_r01_r03_narrative.md")):
         txt = open(os.path.join(REPO, doc)).read()
         for m in re.finditer(r"((?:tests/)?tools)/([A-Za-z0-9_/\-]+\.(?:py|sh|hip))", txt):
             if not os.path.exists(os.path.join(REPO, m.group(1), m.group(2))):

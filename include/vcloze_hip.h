@@ -80,6 +80,10 @@ typedef struct VcGemmProblem {
   const float* kn_rope;
   int64_t kn_rope_bstride;
   int32_t kn_heads, kn_pad_;
+  /* VcGemmArgs.batch = Z > 1: Z independent GEMMs of this shape in ONE launch (blockIdx.y) - instance z reads A + z * a_zstride,
+   * W + z * w_zstride and writes C + z * c_zstride (elements, multiples of 8): the per-head S = Q K^T and O = P V products of an
+   * attention whose head_dim the fused kernel does not cover (T5: 64 heads x d_kv 64; CLIP) as two launches per layer. */
+  int64_t a_zstride, w_zstride, c_zstride;
 } VcGemmProblem;
 
 #define VC_GEMM_MAX_PROBLEMS 4
@@ -98,7 +102,8 @@ typedef struct VcGemmArgs {
    * to f32 summation order.  Not for VC_EPI_QKV.  sk_*: filled by the launcher. */
   void* splitk_ws;
   int64_t splitk_ws_bytes;
-  int32_t sk_full, sk_rem, sk_S, sk_pad_;
+  int32_t sk_full, sk_rem, sk_S;
+  int32_t batch;            /* 0 / 1: one GEMM per problem; Z > 1: see VcGemmProblem.a_zstride (VC_EPI_BIAS, the 128x128 tile) */
 } VcGemmArgs;
 #define VC_GEMM_SPLITK_WS_BYTES (256LL * 256 * 192 * 4)   /* one 256x192 f32 tile per work item of one round of 256 CUs */
 

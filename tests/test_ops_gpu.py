@@ -391,6 +391,36 @@ def test_gemm_splitk_taken_by_the_cost_model_at_product_shapes(hip, M, K):
     assert d.max().item() <= 2 ** -5 * outs[2].float().abs().max().item()
 
 
+@pytest.mark.parametrize("L,H,dh", [(512, 64, 64), (128, 12, 64), (77 + 51, 3, 128), (40, 2, 64)])
+def test_gemm_batched_instances_per_head_products(hip, L, H, dh):
+    """VcGemmArgs.batch = H: the per-head S_h = Q_h K_h^T and O_h = S_h V_h products of the T5 / CLIP attention (head_dim 64:
+    not the fused kernel's) as ONE launch each - instance h reads its dh columns of q / k and writes its [L, L] slab, then
+    S_h V_h^T into its dh columns of O - bit-identical to the H separate launches it replaces."""
+    q, k, v = rnd(L, H * dh, seed=1), rnd(L, H * dh, seed=2), rnd(L, H * dh, seed=3)
+    s1 = torch.full((H * L, L), float("nan"), dtype=torch.bfloat16, device=DEV)
+    p = hip.make_problem(q[:, :dh], k[:, :dh], None, s1[:L])
+    p.a_zstride, p.w_zstride, p.c_zstride = dh, dh, L * s1.stride(0)
+    hip.gemm(p, batch=H)
+    s2 = torch.empty_like(s1)
+    for h in range(H):
+        hip.gemm(hip.make_problem(q[:, h * dh:(h + 1) * dh], k[:, h * dh:(h + 1) * dh], None, s2[h * L:(h + 1) * L]), tile_cfg=1)
+    torch.cuda.synchronize()
+    assert torch.equal(s1, s2)
+    check(s1.view(H, L, L), torch.einsum("lhd,mhd->hlm", q.float().view(L, H, dh), k.float().view(L, H, dh)))
+    if L % 64 == 0:
+        sm = (torch.softmax(s1.float().view(H, L, L) * dh ** -0.5, -1)).to(torch.bfloat16).view(H * L, L).contiguous()
+        vt = v.view(L, H, dh).permute(1, 2, 0).contiguous().view(H * dh, L)
+        o1 = torch.full((L, H * dh), float("nan"), dtype=torch.bfloat16, device=DEV)
+        p = hip.make_problem(sm[:L], vt[:dh], None, o1[:, :dh])
+        p.a_zstride, p.w_zstride, p.c_zstride = L * sm.stride(0), dh * vt.stride(0), dh
+        hip.gemm(p, batch=H)
+        torch.cuda.synchronize()
+        ref = torch.einsum("hlm,mhd->lhd", sm.float().view(H, L, L), v.float().view(L, H, dh)).reshape(L, H * dh)
+        check(o1, ref.to(torch.bfloat16).float())
+    with pytest.raises(hip.VclozeHipError, match="batch"):
+        hip.gemm(p, epi=hip.EPI_GELU, batch=H)
+
+
 def test_gemm_rejects_bad_arguments(hip):
     a, w = rnd(8, 100), rnd(16, 100)
     with pytest.raises(hip.VclozeHipError):          # K not a multiple of 64

@@ -38,7 +38,7 @@ constexpr int BK = 64;
 // one - into two ring slots that live ABOVE the epilogue's LDS staging area, and A(0) follows as soon as the staging area
 // has been read back; a new workgroup would pay dispatch + offsets + the full HBM latency of its first tiles instead
 // (6.0 k cycles of prologue + 1.2-3.8 k of dispatch gap per 90 k-cycle round at K = 3072).
-template <int BM, int BN, int WM, int WN, int EPI, int PP, bool CONV = false, bool PERSIST = false, bool SPLITK = false>
+template <int BM, int BN, int WM, int WN, int EPI, int PP, bool CONV = false, bool PERSIST = false, bool SPLITK = false, bool ZB = false>
 __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_kernel(const VcGemmArgs args) {
   static_assert(!SPLITK || (PP == 2 && !CONV && !PERSIST), "split-K slices run on the plain loader-wave schedule");
   static_assert(!CONV || PP == 2, "the implicit-convolution A operand is gathered by loader waves");
@@ -112,6 +112,11 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
     const int tn = (id % in_group) / gsz;
     t.m0 = t.P.m_begin + tm * BM;     // m_begin: rows below it belong to the other launch of a split call
     t.n0 = tn * BN;
+    if constexpr (ZB) {               // VcGemmArgs.batch: instance blockIdx.y of Z independent GEMMs of this shape
+      t.P.A = (const bf16_t*)t.P.A + (long)blockIdx.y * t.P.a_zstride;
+      t.P.W = (const bf16_t*)t.P.W + (long)blockIdx.y * t.P.w_zstride;
+      t.P.C = (bf16_t*)t.P.C + (long)blockIdx.y * t.P.c_zstride;
+    }
     return t;
   };
   // ---- staging source offsets (elements), one per 16-B chunk this thread copies ----
@@ -816,6 +821,21 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const VcGemmArgs arg
   *(u32x4*)((bf16_t*)P.C + crow + n) = o;
 }
 
+// VcGemmArgs.batch = Z > 1: Z instances of every problem, grid (tiles, Z), the 128x128 tile with the plain bias epilogue
+hipError_t launch_zbatch(const VcGemmArgs& a, int total_tiles, hipStream_t s) {
+  constexpr int BM = 128, BN = 128, NT = 4 * 64, LDS_STAGES = 2 * (BM + BN) * BK * 2, LDS_EPI = BM * (BN * 2 + 16);
+  constexpr int LDS = LDS_STAGES > LDS_EPI ? LDS_STAGES : LDS_EPI;
+  void (*fn)(const VcGemmArgs) = gemm_bf16_kernel<BM, BN, 2, 2, VC_EPI_BIAS, 0, false, false, false, true>;
+  static VcOncePerDevice attr_done;
+  if (attr_done.need()) {
+    hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return e;
+    attr_done.mark();
+  }
+  hipLaunchKernelGGL(fn, dim3(total_tiles, a.batch), dim3(NT), LDS, s, a);
+  return hipGetLastError();
+}
+
 // First launch of the remainder: sk_rem * sk_S work items of the 256x192 loader-wave kernel, each over K / sk_S, no epilogue
 hipError_t launch_splitk_slices(const VcGemmArgs& a, hipStream_t s) {
   constexpr int BM = 256, BN = 192, NT = 12 * 64, LDS = (2 * BM + 3 * BN) * BK * 2;
@@ -976,6 +996,12 @@ int launch_tiles(VcGemmArgs a, int tile_cfg, int pp, bool want_persist, hipStrea
   if (np == 0) return VC_OK;
   a.nprob = np;
   a.sk_full = total; a.sk_rem = 0; a.sk_S = 1;
+  if (a.batch > 1) {
+    if (tile_cfg != 1 || pp != 0 || a.epi != VC_EPI_BIAS) { snprintf(err, errlen, "gemm: batch > 1 runs on the 128x128 tile with VC_EPI_BIAS"); return VC_ERR_ARG; }
+    const hipError_t ez = launch_zbatch(a, total, s);
+    if (ez != hipSuccess) { snprintf(err, errlen, "gemm batch launch: %s", hipGetErrorString(ez)); return VC_ERR_HIP; }
+    return VC_OK;
+  }
   if (splitk_S > 1) {      // the tiles beyond the last whole round of the CUs run as splitk_S K-slices each (plan_gemm decided)
     const int n_cu = vc_cu_count();
     const int full = total / n_cu * n_cu, rem = total - full;
@@ -1047,6 +1073,16 @@ static int validate_gemm(VcGemmArgs& a, char* err, int errlen) {
                p.vt_row0, p.vt_lpad, (long)p.vt_bstride); return VC_ERR_ARG; }
   }
   if (a.epi < 0 || a.epi > VC_EPI_QKV) { snprintf(err, errlen, "gemm: unknown epilogue %d", a.epi); return VC_ERR_ARG; }
+  if (a.batch < 0 || a.batch > 65535) { snprintf(err, errlen, "gemm: batch must be 0..65535"); return VC_ERR_ARG; }
+  if (a.batch > 1) {
+    if (a.epi != VC_EPI_BIAS) { snprintf(err, errlen, "gemm: batch > 1 supports VC_EPI_BIAS only"); return VC_ERR_ARG; }
+    for (int i = 0; i < a.nprob; ++i) {
+      const VcGemmProblem& p = a.p[i];
+      if (p.a_zstride % 8 || p.w_zstride % 8 || p.c_zstride % 8 || p.a_zstride < 0 || p.w_zstride < 0 || p.c_zstride < 0 || p.a_rpb || p.c_rpb ||
+          (uint64_t)a.batch * (uint64_t)p.a_zstride >= (1ull << 40) || (uint64_t)a.batch * (uint64_t)p.w_zstride >= (1ull << 40)) {
+        snprintf(err, errlen, "gemm: batch strides must be non-negative multiples of 8 elements (plain rows only)"); return VC_ERR_ARG; }
+    }
+  }
   return VC_OK;
 }
 
@@ -1057,6 +1093,7 @@ static GemmPlan plan_gemm(const VcGemmArgs& a, int tile_cfg) {
   const int force_sk = (tile_cfg >> 16) & 15;          // tests / A-B: VC_GEMM_SPLITK(S)
   const bool no_split = (tile_cfg & VC_GEMM_NO_SPLIT) != 0, no_splitk = (tile_cfg & VC_GEMM_NO_SPLITK) != 0;
   tile_cfg &= 63;
+  if (a.batch > 1) return GemmPlan{0, 1, 0, 0, 0};          // Z instances per problem: the 128x128 tile (grid (tiles, Z))
   const long n_cus = vc_cu_count();
   auto sk_plan = [&](int S) {
     const long total = tiles_of(a, 4), rem = total % n_cus;

@@ -46,6 +46,7 @@ class GemmProblem(C.Structure):
         ("vt", C.c_void_p), ("vt_bstride", C.c_int64),
         ("vt_col0", C.c_int32), ("vt_rpb", C.c_int32), ("vt_row0", C.c_int32), ("vt_lpad", C.c_int32),
         ("kn_scale", C.c_void_p), ("kn_rope", C.c_void_p), ("kn_rope_bstride", C.c_int64), ("kn_heads", C.c_int32), ("kn_pad_", C.c_int32),
+        ("a_zstride", C.c_int64), ("w_zstride", C.c_int64), ("c_zstride", C.c_int64),
     ]
 
 
@@ -54,7 +55,7 @@ class GemmArgs(C.Structure):
         ("p", GemmProblem * 4), ("nprob", C.c_int32), ("epi", C.c_int32),
         ("step_ptr", C.c_void_p), ("gate_step_stride", C.c_int64), ("debug_ts", C.c_void_p),
         ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64),
-        ("sk_full", C.c_int32), ("sk_rem", C.c_int32), ("sk_S", C.c_int32), ("sk_pad_", C.c_int32),
+        ("sk_full", C.c_int32), ("sk_rem", C.c_int32), ("sk_S", C.c_int32), ("batch", C.c_int32),
     ]
 
 
@@ -295,8 +296,11 @@ def splitk_workspace(device) -> torch.Tensor:
     return torch.empty(GEMM_SPLITK_WS_BYTES, dtype=torch.uint8, device=device)
 
 
-def gemm(problems, epi=EPI_BIAS, tile_cfg=0, step_ptr=None, gate_step_stride=0, stream=None, debug_ts=None, splitk_ws=None) -> None:
+def gemm(problems, epi=EPI_BIAS, tile_cfg=0, step_ptr=None, gate_step_stride=0, stream=None, debug_ts=None, splitk_ws=None,
+         batch=0) -> None:
+    """`batch` = Z > 1: Z independent GEMMs per problem in one launch; set the problem's a_zstride / w_zstride / c_zstride."""
     args = GemmArgs()
+    args.batch = batch
     if splitk_ws is not None:
         args.splitk_ws, args.splitk_ws_bytes = splitk_ws.data_ptr(), splitk_ws.numel() * splitk_ws.element_size()
     if isinstance(problems, GemmProblem):

@@ -112,6 +112,28 @@ def test_unmerged_lora_mode_vs_reference_bf16_run(golden):
         assert rel_l2(tr[i], refb[i]) < 2 * TOL_GOLDEN
 
 
+def test_f32_parameters_are_never_merged_in_place(golden):
+    """A model whose parameters are F32 (the default dtype of the holders; the pipeline casts to bf16, a test or a fine-tune may
+    not): `merged_linear` forms W + s * B @ A in f32 - and `W.float()` of an f32 parameter IS the parameter, so an in-place
+    add wrote the LoRA delta into the module's own weight, again on every re-prepare (advisor r03).  The state dict must
+    survive any number of prepares bit for bit, the output must not drift, and it matches the bf16-parameter model."""
+    from tests.helpers import tiny_model
+    from tests.procedural import tiny_inputs
+    m, _ = tiny_model(dtype=torch.float32)
+    before = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    inp = tiny_inputs(B=1)
+    t = torch.tensor([0.7])
+    a = _fwd(m, inp, t).float().cpu()
+    m.set_lora_scale(0.5); m.prepare()
+    m.set_lora_scale(1.0); m.prepare(); m.invalidate_engine()
+    b = _fwd(m, inp, t).float().cpu()
+    assert all(torch.equal(v, before[k]) for k, v in m.state_dict().items())
+    assert torch.equal(a, b)
+    assert rel_l2(a, golden["flux_b1"]) < TOL_GOLDEN
+    m16, _ = tiny_model()
+    assert rel_l2(a, _fwd(m16, inp, t)) < 1e-2        # (bf16 parameters: the norm scales are rounded at load, nothing else differs)
+
+
 def test_forward_bf16_guidance_rounding(model):
     """guidance created in bf16 (visualcloze.py:413): 1000*30 rounds to 29952 before the sinusoid."""
     from tests.procedural import tiny_inputs

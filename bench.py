@@ -191,7 +191,7 @@ def flops_per_eval(T, N, D=3072, H=24, mlp=12288, depth=19, single=38, in_ch=384
     return lin, attn
 
 
-PMC_FILE = "profiles/r03_pmc_summary.json"
+PMC_FILE = "profiles/r04_pmc_summary.json"
 
 
 def pmc_traffic(kernel):
@@ -199,10 +199,13 @@ def pmc_traffic(kernel):
     (FETCH_SIZE and WRITE_SIZE in separate --pmc runs, KiB units; FETCH_SIZE x2 on gfx950 for wide coalesced reads,
     MI355X_MICROARCH.md §HBM) - hardware counters cannot be sampled from inside bench.py, so this field is a file
     lookup (`measured_in_this_run: false`), null when the file does not hold the kernel."""
-    for rel in (PMC_FILE, "profiles/r02_pmc_summary.json"):
+    for rel in (PMC_FILE, "profiles/r03_pmc_summary.json", "profiles/r02_pmc_summary.json"):
         try:
             d = json.load(open(os.path.join(REPO, rel)))
-            k = d[kernel] if kernel in d else d[kernel.replace(", false, false>", ", false>")]    # (round-2 files: one template argument fewer)
+            name = kernel
+            while name not in d and name.endswith(", false>"):       # (older files: fewer trailing template arguments)
+                name = name[:-len(", false>")] + ">"
+            k = d[name]
             fetch, write = 2.0 * k["FETCH_SIZE"] * 1024.0, k["WRITE_SIZE"] * 1024.0
             return dict(fetch_bytes=round(fetch), write_bytes=round(write), total_bytes=round(fetch + write),
                         unit="bytes/launch", measured_in_this_run=False,
@@ -328,7 +331,7 @@ def roofline_gemm(job, iters=3):
     n = len(launches)
     achieved = flops / (ms * 1e-3) / 1e12
     return dict(bound="mfma", achieved=round(achieved, 1), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
-                frac=round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), traffic=pmc_traffic("gemm_bf16_kernel<256, 192, 4, 2, 2, 2, false, false>"),
+                frac=round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), traffic=pmc_traffic("gemm_bf16_kernel<256, 192, 4, 2, 2, 2, false, false, false, false>"),
                 kernel="gemm_bf16_kernel<EPI_GATE_RES>", launches_per_eval=n,
                 flops_per_launch=flops / n, avg_launch_us=round(ms * 1e3 / n, 2))
 

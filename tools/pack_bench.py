@@ -30,12 +30,15 @@ def timed(fn, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--only", default=None, help="substring of the shape tag: run that shape alone (the PMC passes use 'streaming')")
     a = ap.parse_args()
     hip.require_gpu()
     dev = "cuda:0"
     out = []
     for tag, (C, h, w) in (("cfg3 row (16 x 64 x 192)", (16, 64, 192)), ("p34 row (16 x 54 x 120)", (16, 54, 120)),
                            ("streaming map (16 x 1024 x 2048)", (16, 1024, 2048))):
+        if a.only and a.only not in tag:
+            continue
         lat = torch.randn(C, h, w, device=dev).to(torch.bfloat16)
         n = (h // 2) * (w // 2)
         cond = torch.empty(n, 320, dtype=torch.bfloat16, device=dev)

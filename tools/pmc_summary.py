@@ -22,7 +22,7 @@ def main(paths):
         with open(p) as f:
             for r in csv.DictReader(f):
                 n = short(r["Kernel_Name"])
-                if not any(k in n for k in ("gemm_bf16", "attn", "qknorm", "ln_modulate")):
+                if not any(k in n for k in ("gemm_bf16", "attn", "qknorm", "ln_modulate", "splitk", "pack_")):
                     continue
                 per_dispatch[(n, r["Dispatch_Id"])][r["Counter_Name"]] = float(r["Counter_Value"])
                 per_dispatch[(n, r["Dispatch_Id"])]["_dur_ns"] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])

@@ -7,8 +7,8 @@ the whole 19 + 38-block model (13.1 B parameters, D = 3072, L = 512 + 3456, LoRA
 
 in both oracle modes (bf16 / merged LoRA = the HIP path's rounding points; fp32 / un-merged = exact reference semantics)
 -> tests/golden/fulldepth_times_oracle.npz.  tests/golden/fulldepth_cfg2_oracle.npz holds the same comparison at t = 0.62.
-`--geom cfg3 | cfg5`: ONE evaluation at t = 0.62 of the same model on the 512-grid 2x3 (L = 6656) / 384-grid 3x4 (L = 7424)
-geometry -> fulldepth_<geom>_oracle.npz (every second image token).  About 45 min on 8 cores (a large geometry: ~40 min); weights are kept as bf16 on the host (26 GB) and widened one tensor at a time.
+`--geom cfg3 | cfg5 | p34`: ONE evaluation at t = 0.62 of the same model on the 512-grid 2x3 (L = 6656) / 384-grid 3x4 (L = 7424) /
+non-square 2x3 grid of 3:4 portraits (L = 3752: off every tile edge) geometry -> fulldepth_<geom>_oracle.npz (every second image token).  About 45 min on 8 cores (a large geometry: ~40 min); weights are kept as bf16 on the host (26 GB) and widened one tensor at a time.
 
     python tests/golden/make_fulldepth_times.py
 """
@@ -47,6 +47,8 @@ def flux_times():
 GEOMS = {      # the other full-depth fixtures: one evaluation at t = 0.62 on the two largest BASELINE geometries
     "cfg3": dict(rows=2, row_latent=(64, 192)),      # 512-grid 2x3, L = 512 + 6144
     "cfg5": dict(rows=3, row_latent=(48, 192)),      # 384-grid 3x4, L = 512 + 6912
+    # a shape the pipeline really produces (visualcloze.py:28-60): 2x3 grid of 3:4 portraits, 320x432 px each, L = 512 + 3240
+    "p34": dict(rows=2, row_latent=(54, 120)),
 }
 TOKEN_STRIDE = 2      # (the large geometries are stored for every second image token)
 

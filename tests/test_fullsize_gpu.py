@@ -514,10 +514,11 @@ def test_full_depth_trajectory_vs_oracle(procedural_full_model):
         assert e16 < 1.5 * floor and e32 < 2.0 * floor, (k, e16, e32, floor)
 
 
-@pytest.mark.parametrize("geom", ["cfg3", "cfg5"])
+@pytest.mark.parametrize("geom", ["cfg3", "cfg5", "p34"])
 def test_full_depth_on_the_large_geometries_vs_oracle(procedural_full_model, geom):
     """The full 19 + 38-block model on the two LARGEST BASELINE geometries (cfg 3: 512-grid 2x3, L = 6656; cfg 5: 384-grid
-    3x4, L = 7424 - other attention tails, other tile counts, other RoPE grids than cfg 2), one evaluation at t = 0.62,
+    3x4, L = 7424 - other attention tails, other tile counts, other RoPE grids than cfg 2) and on a NON-SQUARE shape the pipeline
+    really produces (p34: 2x3 grid of 3:4 portraits, L = 3752, off every tile edge), one evaluation at t = 0.62,
     procedural weights, against the committed oracle outputs of `tests/golden/make_fulldepth_times.py --geom <geom>`
     (every second image token); bounds as at cfg 2: <= 1.5 * floor vs the bf16-merged oracle, <= 2 * floor vs fp32-ref."""
     import importlib.util

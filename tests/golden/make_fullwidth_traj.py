@@ -6,6 +6,7 @@ D = 3072 / H = 24 / T = 512 with 1 DoubleStreamBlock + 1 SingleStreamBlock and L
     sdedit  1024^2 target  N = 4096  L = 4608   10 points from strength 0.4, no shift = 9 evaluations (visualcloze.py:184-234)
     cfg5    384-grid 3x4   N = 6912  L = 7424   30 points, shifted grid; only with --only cfg5 -> fullwidth_traj_cfg5.npz
     cfg5_50 the same geometry and inputs, BASELINE's own 50 points = 49 evaluations; --only cfg5_50 -> fullwidth_traj_cfg5_50.npz
+    p34     2x3 grid of 3:4 portraits (non-square: N = 3240, L = 3752), 30 points; --only p34 -> fullwidth_traj_p34.npz
 
 For each: the bf16 / merged-LoRA oracle (same rounding points as the HIP path; bf16 state as visualcloze.py:399) and the
 fp32 / un-merged oracle (exact reference semantics) -> tests/golden/fullwidth_traj.npz: final latents, a few intermediate
@@ -40,6 +41,9 @@ CASES = {      # seed: base of the procedural input draws (fixed per case, so th
     # BASELINE cfg 5 as it is quoted: 50 solver points = 49 evaluations (mu = 1.62667) on the same geometry and inputs
     "cfg5_50": dict(rows=3, row_latent=(48, 192), points=50, do_shift=True, strength=None, keep=(1, 25, 49), seed=1020,
                     file="fullwidth_traj_cfg5_50.npz", final_stride=2),
+    # a shape the pipeline really produces (visualcloze.py:28-60): 2x3 grid of 3:4 portraits, N = 3240, L = 3752 - off every tile edge
+    "p34": dict(rows=2, row_latent=(54, 120), points=30, do_shift=True, strength=None, keep=(1, 15, 29), seed=1040,
+                file="fullwidth_traj_p34.npz"),
 }
 
 

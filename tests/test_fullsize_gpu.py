@@ -401,12 +401,13 @@ def procedural_small_model():
     return _build_procedural(1, 1)
 
 
-@pytest.mark.parametrize("case", ["cfg2", "sdedit", "cfg5", "cfg5_50"])
+@pytest.mark.parametrize("case", ["cfg2", "sdedit", "cfg5", "cfg5_50", "p34"])
 def test_full_width_trajectory_vs_oracle(procedural_small_model, case):
     """The WHOLE loop at full width against the oracle's own trajectories (transport/integrators.py:106-120,
     transport/transport.py:384): cfg 2's 30-point shifted grid = 29 evaluations at L = 3968, and the SDEdit stage's 10
     points from strength 0.4 = 9 evaluations at L = 4608, and cfg 5's 29 evaluations at L = 7424 (the largest BASELINE geometry;
-    its own fixture file) - and cfg 5 as BASELINE.json quotes it, 50 solver points = 49 evaluations (`cfg5_50`) -, D = 3072,
+    its own fixture file) - and cfg 5 as BASELINE.json quotes it, 50 solver points = 49 evaluations (`cfg5_50`), and a NON-SQUARE grid
+    the pipeline really produces (`p34`: 2x3 of 3:4 portraits, L = 3752, 29 evaluations) -, D = 3072,
     1 + 1 blocks.  The fused sampler's intermediate and
     FINAL latents are held to the bf16-merged oracle (same rounding points) and the fp32-ref oracle (exact reference
     semantics), with bounds stated against `floor` = the oracle's own bf16-vs-fp32 deviation on the same state:
@@ -595,6 +596,29 @@ def test_race_screen_repeated_launches_are_bit_identical():
             if first is None:
                 first = x.clone()
             assert torch.equal(first, x), f"GATE_RES cfg 36: launch {it} differs"
+    # the split-K remainder as the SDEdit stage runs it (L = 4608: 256 whole tiles + 32 tiles x 8 K-slices + the reduce launch),
+    # chosen by the launcher itself, gate + residual in place: slices racing the reduce, or a reduce reading a stale partial of
+    # the previous launch in the shared scratch, would show up here
+    Ls = 4608
+    a5 = torch.randn(Ls, 4 * D, generator=g).to(torch.bfloat16).to(DEV)
+    res5 = torch.randn(Ls, D, generator=g).to(torch.bfloat16).to(DEV)
+    ws = hip.splitk_workspace(DEV)
+    a5b = (a5.float() * 0.5).to(torch.bfloat16)           # a second problem through the SAME scratch between the repeats
+    first = None
+    for it in range(24):
+        x = res5.clone()
+        y = res5.clone()
+        hip.gemm(hip.make_problem(a5, w4, b[:D], x, res=x, gate=gate), epi=hip.EPI_GATE_RES, tile_cfg=0, splitk_ws=ws)
+        hip.gemm(hip.make_problem(a5b, w4, b[:D], y, res=y, gate=gate), epi=hip.EPI_GATE_RES, tile_cfg=0, splitk_ws=ws)
+        if it % 8 == 7:
+            torch.cuda.synchronize()
+            if first is None:
+                first = (x.clone(), y.clone())
+                one = res5.clone()
+                hip.gemm(hip.make_problem(a5, w4, b[:D], one, res=one, gate=gate), epi=hip.EPI_GATE_RES, tile_cfg=hip.GEMM_NO_SPLITK, splitk_ws=ws)
+                torch.cuda.synchronize()
+                assert not torch.equal(one, x) and rel_l2(x, one) < 2e-3        # the split WAS taken; same function
+            assert torch.equal(first[0], x) and torch.equal(first[1], y), f"split-K GATE_RES: launch {it} differs"
     qkv = torch.randn(L2, 3 * D, generator=g).to(torch.bfloat16).to(DEV)
     vt = qkv[:, 2 * D:].reshape(L2, H, 128).permute(1, 2, 0).contiguous()
     for variant in (0, 1, 2, 3, 7, 8, 12):

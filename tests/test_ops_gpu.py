@@ -766,19 +766,22 @@ def test_attention_randomised_sweep(hip):
 def test_gemm_randomised_shape_sweep(hip):
     """Seeded sweep over ragged shapes for the two tiles the cost model picks (128x128, 256x192 + loader waves): M not a
     multiple of any tile, N only a multiple of 8 (bias / staging slices that end mid-tile), K = 64 ... 1024 (1 to 16
-    K-tiles: prologue-only, ring wrap-around), with and without bias, every epilogue, plus a 3-problem grouped launch."""
+    K-tiles: prologue-only, ring wrap-around), with and without bias, every epilogue, plus a 3-problem grouped launch; each
+    problem also under a forced split-K plan with a random slice count (slices of unequal length, down to one K-tile)."""
     g = torch.Generator().manual_seed(2024)
     ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))  # noqa: E731
+    sk_ws = hip.splitk_workspace(DEV)
     for it in range(14):
         M, N, K = ri(1, 700), 8 * ri(1, 60), 64 * ri(1, 16)
         epi = it % 4
         a, w = rnd(M, K, seed=100 + it), rnd(N, K, scale=K ** -0.5, seed=200 + it)
         bias = rnd(N, seed=300 + it) if it % 3 else None
         res, gate = rnd(M, N, seed=400 + it), rnd(N, seed=500 + it)
-        for cfg in (1, 36, 0):
+        S = min(ri(2, 8), K // 64)            # a forced split-K plan on the same problem (skipped when K holds a single K-tile)
+        for cfg in (1, 36, 0) + ((hip.GEMM_SPLITK(S),) if S >= 2 else ()):
             out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
             p = hip.make_problem(a, w, bias, out, res=res if epi == 2 else None, gate=gate if epi == 2 else None)
-            hip.gemm(p, epi=epi, tile_cfg=cfg)
+            hip.gemm(p, epi=epi, tile_cfg=cfg, splitk_ws=sk_ws)
             torch.cuda.synchronize()
             check(out, R.gemm_ref(a, w, bias if bias is not None else torch.zeros(N, dtype=torch.bfloat16, device=DEV), epi, res, gate))
     # grouped: three problems of different M / N sharing K
@@ -789,10 +792,10 @@ def test_gemm_randomised_shape_sweep(hip):
         o = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
         keep.append((a, w, b))
         probs.append(hip.make_problem(a, w, b, o)); outs.append(o); refs.append(R.gemm_ref(a, w, b, 0))
-    for cfg in (1, 36):
+    for cfg in (1, 36, hip.GEMM_SPLITK(3)):
         for o in outs:
             o.fill_(float("nan"))
-        hip.gemm(probs, epi=0, tile_cfg=cfg)
+        hip.gemm(probs, epi=0, tile_cfg=cfg, splitk_ws=sk_ws)
         torch.cuda.synchronize()
         for o, r in zip(outs, refs):
             check(o, r)

@@ -21,6 +21,13 @@
 
 namespace {
 
+// LDS-DMA with a SCALAR base and a 32-bit per-lane byte offset: LDS destination = lds_wave_base (wave-uniform) + lane * 16.
+// M0 is written right here (one wait state before the DMA reads it).
+VC_DEV void glds16_saddr(const char* sbase, uint32_t voff, void* lds_wave_base) {
+  const uint32_t lds_off = (uint32_t)(uintptr_t)(lptr_t)lds_wave_base;
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_off) : "memory", "m0");
+}
+
 constexpr int BK = 64;
 // raster: ids walk GROUP_M m-tiles, then the n-tiles (an XCD's 32 resident workgroups = GROUP_M x 32/GROUP_M tiles)
 #ifndef VC_GEMM_GROUP_M
@@ -124,6 +131,16 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
   const int swave = PP == 2 ? (wave - NCW) & 3 : wave;
   // loader-wave kernels run these inside the loader branch (and, PERSIST, at the seam between two tiles) only, each time into
   // registers that die with their last piece: nothing of them is live in a compute wave's K loop
+  // BYTE_OFF (the loader-wave kernels): the offsets are 32-bit BYTE offsets against a scalar base - A against the operand, W
+  // against the first row of the block's n-tile (the stacked modulation matrix alone is 6.5 GB) - so that every LDS-DMA piece is
+  // `global_load_lds v_off, s[base]` with the K position folded into the scalar base: no vector instruction per piece in the
+  // loader waves, which issue on the SIMDs the compute waves feed the matrix pipe from (element offsets against a bf16 pointer
+  // made hipcc form a 64-bit address per piece: one v_lshl_add_u64 for each of the 14 pieces of a K-tile).
+#ifndef VC_GEMM_NO_SADDR      // (A/B builds: round 3's per-piece 64-bit vector addresses)
+  constexpr bool BYTE_OFF = PP == 2 && !CONV;
+#else
+  constexpr bool BYTE_OFF = false;
+#endif
   auto staging_offsets_a = [&](uint32_t (&ao)[A_IT], const VcGemmProblem& Q, int m0q, int st) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
@@ -132,6 +149,7 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
       const int grow = min(m0q + row, Q.M - 1);
       ao[i] = (Q.a_rpb > 0 ? (uint32_t)(grow / Q.a_rpb) * (uint32_t)Q.a_bstride + (uint32_t)(grow % Q.a_rpb) * (uint32_t)Q.lda
                            : (uint32_t)grow * (uint32_t)Q.lda) + slot * 8;
+      if constexpr (BYTE_OFF) ao[i] *= 2u;              // (validate_gemm: the A operand of a loader-wave launch stays below 4 GB)
     }
   };
   auto staging_offsets_b = [&](uint32_t (&bo)[B_IT], const VcGemmProblem& Q, int n0q, int st) {
@@ -140,7 +158,8 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
       const int c = i * NS + st;
       const int row = c >> 3, slot = (c & 7) ^ (row & 7);
       const int grow = min(n0q + row, Q.N - 1);
-      bo[i] = (uint32_t)grow * (uint32_t)Q.ldw + slot * 8;
+      if constexpr (BYTE_OFF) bo[i] = ((uint32_t)(grow - n0q) * (uint32_t)Q.ldw + slot * 8) * 2u;     // relative to row n0q: < BN * ldw * 2
+      else bo[i] = (uint32_t)grow * (uint32_t)Q.ldw + slot * 8;
     }
   };
 
@@ -159,6 +178,8 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
   }
   const bf16_t* __restrict__ Ab = (const bf16_t*)P.A + (long)kt_lo * BK;
   const bf16_t* __restrict__ Wb = (const bf16_t*)P.W + (long)kt_lo * BK;
+  const char* __restrict__ Abytes = (const char*)Ab;                                   // BYTE_OFF bases (scalar)
+  const char* __restrict__ Wbytes = (const char*)(Wb + (long)n0 * P.ldw);
   uint32_t a_off[A_IT], b_off[B_IT];
   auto staging_offsets = [&]() { staging_offsets_a(a_off, P, m0, stid); staging_offsets_b(b_off, P, n0, stid); };
   if constexpr (PP != 2) staging_offsets();
@@ -216,11 +237,33 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
   auto wslot = [&](int slot) { return PERSIST ? (slot == 2 ? W_RING0 : W_HI + slot * B_BYTES) : W_RING0 + slot * B_BYTES; };
   auto stage_a_piece = [&](int slot, int k0, int i) {
     if constexpr (CONV) glds16(conv_src(i), smem + slot * A_BYTES + (i * NS + swave * 64) * 16);   // (conv_set_k(k0) done by the caller)
+    else if constexpr (BYTE_OFF) {
+      const char* ak = Abytes + (long)k0 * 2;
+      // the instruction itself is asm: left to hipcc, (base + offset) is re-associated per piece into VGPR pairs + k, or the
+      // zero-extension of the offset is hoisted out of the block where instruction selection would fold it - either way one
+      // 64-bit VALU add per piece
+      glds16_saddr(ak, a_off[i], smem + slot * A_BYTES + (i * NS + swave * 64) * 16);
+    }
     else glds16(Ab + a_off[i] + k0, smem + slot * A_BYTES + (i * NS + swave * 64) * 16);
   };
-  auto stage_w_piece = [&](int slot, int k0, int i) { glds16(Wb + b_off[i] + k0, smem + wslot(slot) + (i * NS + swave * 64) * 16); };
+  auto stage_w_piece = [&](int slot, int k0, int i) {
+    if constexpr (BYTE_OFF) {
+      const char* wk = Wbytes + (long)k0 * 2;
+      glds16_saddr(wk, b_off[i], smem + wslot(slot) + (i * NS + swave * 64) * 16);
+    }
+    else glds16(Wb + b_off[i] + k0, smem + wslot(slot) + (i * NS + swave * 64) * 16);
+  };
 
   // ---- fragment read offsets ----
+  // (x + j * 2048) ^ 64 == (x ^ 64) + j * 2048 (bit 6 belongs to the 16-B-slot swizzle inside a 128-B row, j * 2048 is whole
+  // rows): written the second way the K-slice-1 fragments of an operand share ONE base register and take their row offsets as
+  // ds_read immediates; the first way hipcc kept one pre-XORed register per fragment and a v_add per fragment and K-tile - vector
+  // instructions in the MEMORY segment, i.e. beside the partner wave's MFMAs on the same SIMD
+#ifdef VC_GEMM_FRAG_XOR_PER_FRAGMENT      // (A/B builds: round 3's form)
+#define FRAG_AT(x, off, kk) (((x) + (off)) ^ ((kk) * 64))
+#else
+#define FRAG_AT(x, off, kk) ((((x) ^ ((kk) * 64))) + (off))
+#endif
   const int fr = lane & 15, fq = lane >> 4;
   const int sw0 = ((fq ^ (lane & 7)) << 4);  // kk=0 slot; kk=1 is sw0 ^ 64
   const int a_rd = (wm * TM + fr) * 128 + sw0;
@@ -365,9 +408,9 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
 #endif
           {
 #pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(base_a + ((a_rd + i * 16 * 128) ^ (kk * 64)));
+            for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(base_a + FRAG_AT(a_rd, i * 16 * 128, kk));
 #pragma unroll
-            for (int j = 0; j < NI; ++j) bfr[j] = *(const bf16x8*)(base_b + ((b_rd + j * 16 * 128) ^ (kk * 64)));
+            for (int j = 0; j < NI; ++j) bfr[j] = *(const bf16x8*)(base_b + FRAG_AT(b_rd, j * 16 * 128, kk));
           }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           bar();
@@ -565,13 +608,13 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
       asm volatile("" : "+v"(st));     // (nothing of this is to be hoisted above the K loop)
       uint32_t bn[B_IT];
       staging_offsets_b(bn, tile_next.P, tile_next.n0, st);
-      const bf16_t* Wn = (const bf16_t*)tile_next.P.W;
+      const char* Wn = BYTE_OFF ? (const char*)((const bf16_t*)tile_next.P.W + (long)tile_next.n0 * tile_next.P.ldw) : (const char*)tile_next.P.W;
       const int nkn = tile_next.P.K / BK;
 #pragma unroll
       for (int d = 0; d < 2; ++d)
         if (d < nkn) {
 #pragma unroll
-          for (int i = 0; i < B_IT; ++i) glds16(Wn + bn[i] + d * BK, smem + wslot(d) + (i * NS + swave * 64) * 16);
+          for (int i = 0; i < B_IT; ++i) glds16((Wn + d * BK * 2) + (BYTE_OFF ? (long)bn[i] : 2L * bn[i]), smem + wslot(d) + (i * NS + swave * 64) * 16);
         }
     }
   }
@@ -737,9 +780,9 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
       asm volatile("" : "+v"(st));
       uint32_t an[A_IT];
       staging_offsets_a(an, tile_next.P, tile_next.m0, st);
-      const bf16_t* An = (const bf16_t*)tile_next.P.A;
+      const char* An = (const char*)tile_next.P.A;
 #pragma unroll
-      for (int i = 0; i < A_IT; ++i) glds16(An + an[i], smem + (i * NS + swave * 64) * 16);
+      for (int i = 0; i < A_IT; ++i) glds16(An + (BYTE_OFF ? (long)an[i] : 2L * an[i]), smem + (i * NS + swave * 64) * 16);
     }
     id_cur += id_step;
   }
@@ -1060,6 +1103,10 @@ static int validate_gemm(VcGemmArgs& a, char* err, int errlen) {
     if ((p.a_rpb > 0 ? (uint64_t)((p.M + p.a_rpb - 1) / p.a_rpb) * (uint64_t)p.a_bstride : 0) >= (1ull << 32) ||
         (uint64_t)(p.a_rpb > 0 ? p.a_rpb : p.M) * (uint64_t)p.lda >= (1ull << 32) || (uint64_t)p.N * (uint64_t)p.ldw >= (1ull << 32) || (p.ldw != 0 && p.ldw < p.K) || p.ldw % 8) {
       snprintf(err, errlen, "gemm: operand exceeds 32-bit element offsets"); return VC_ERR_ARG; }
+    // the loader-wave kernels address A with 32-bit BYTE offsets against the operand, W with byte offsets against its n-tile
+    if ((p.a_rpb > 0 ? (uint64_t)((p.M + p.a_rpb - 1) / p.a_rpb) * (uint64_t)p.a_bstride : (uint64_t)p.M * (uint64_t)p.lda) >= (1ull << 31) ||
+        (uint64_t)288 * (uint64_t)p.ldw >= (1ull << 31)) {
+      snprintf(err, errlen, "gemm: A operand of 4 GB or more (or a W row stride beyond 7 M elements) is not supported"); return VC_ERR_ARG; }
     if (a.epi == VC_EPI_GATE_RES && (!p.res || !p.gate || p.rows_per_batch <= 0 || p.ldres % 8 || p.gate_bstride % 8 || a.gate_step_stride % 8)) {
       snprintf(err, errlen, "gemm: gate/residual epilogue needs res, gate, rows_per_batch"); return VC_ERR_ARG; }
     if (a.epi == VC_EPI_QKV && p.kn_heads != 0 && (p.kn_heads < 0 || p.N != 384 * p.kn_heads || (p.vt && p.vt_col0 != 256 * p.kn_heads) ||

@@ -91,6 +91,14 @@ VC_DEV void glds16(const void* g, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
 }
 
+// the same with a SCALAR base and a 32-bit per-lane byte offset (`global_load_lds v_off, s[base]`), M0 written in the same
+// statement (one wait state before the DMA reads it): where the builtin is handed base + (scalar + lane offset) hipcc adds the
+// scalar part per piece in the vector ALU - on SIMDs whose issue slots feed the matrix pipe
+VC_DEV void glds16_saddr(const char* sbase, uint32_t voff, void* lds_wave_base) {
+  const uint32_t lds_off = (uint32_t)(uintptr_t)(lptr_t)lds_wave_base;
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_off) : "memory", "m0");
+}
+
 // XCD-aware bijective block remap: hardware places block b on XCD b%8; give every XCD a contiguous
 // chunk of logical ids so neighbouring tiles share that XCD's L2 (speed only, never correctness).
 VC_DEV int xcd_remap(int bid, int nb) {

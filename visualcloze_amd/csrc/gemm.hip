@@ -21,13 +21,6 @@
 
 namespace {
 
-// LDS-DMA with a SCALAR base and a 32-bit per-lane byte offset: LDS destination = lds_wave_base (wave-uniform) + lane * 16.
-// M0 is written right here (one wait state before the DMA reads it).
-VC_DEV void glds16_saddr(const char* sbase, uint32_t voff, void* lds_wave_base) {
-  const uint32_t lds_off = (uint32_t)(uintptr_t)(lptr_t)lds_wave_base;
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_off) : "memory", "m0");
-}
-
 constexpr int BK = 64;
 // raster: ids walk GROUP_M m-tiles, then the n-tiles (an XCD's 32 resident workgroups = GROUP_M x 32/GROUP_M tiles)
 #ifndef VC_GEMM_GROUP_M

@@ -16,6 +16,7 @@
 // so each lane ends up with 4 consecutive n of one row m -> 8-byte epilogue stores.
 // Up to two problems per launch ("grouped": img + txt streams of a DoubleStreamBlock share a grid).
 #include <string.h>
+#include <type_traits>
 #include "common.h"
 #include "vcloze_internal.h"
 
@@ -385,43 +386,92 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
       bar();
       VC_PHASE_STAMP(1);
       if (grp == 1) bar();
-      int ws = 0;                                       // W slot of tile kt
-#ifdef VC_GEMM_NO_LDSREAD   // analysis builds only (tools/gemm_power.py): the fragments of K-slice 0 feed every MFMA
-      bf16x8 af[MI], bfr[NI];
-#endif
-      for (int kt = 0; kt < nk; ++kt) {
-        const char* base_a = smem + (kt & 1) * A_BYTES;
-        const char* base_b = smem + wslot(ws) - A_BYTES;                 // b_rd already carries +A_BYTES
+#if !defined(VC_GEMM_NO_LDSREAD) && !defined(VC_GEMM_NO_MFMA) && !defined(VC_GEMM_NO_SLOT_UNROLL)
+      // The K loop unrolled over the ring period (A: 2 slots, W: 3 slots -> 6 K-tiles), so that every fragment address is ONE of
+      // six lane-constant base registers + an immediate: no vector instruction at all in the MEMORY segment, which runs beside
+      // the partner wave's MFMAs (with the slot offsets in scalar registers it was 5 v_add per K-tile, 11 before round 4).
+      // b_hi: the W slots 1 and 2 lie beyond the 16-bit ds_read immediate of b_rd.
+      if constexpr (!PERSIST) {
+        uint32_t a_k[2] = {(uint32_t)a_rd, (uint32_t)a_rd ^ 64u}, b_lo[2] = {(uint32_t)b_rd, (uint32_t)b_rd ^ 64u}, b_hi[2];
+        constexpr int HI = B_BYTES * 2;              // (slot 1 starts at W_RING0 + B_BYTES; b_rd already carries A_BYTES)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-#ifdef VC_GEMM_NO_LDSREAD
-          if (kt == 0 && kk == 0)
-#else
-          bf16x8 af[MI], bfr[NI];
-#endif
-          {
+          b_hi[kk] = b_lo[kk] + HI;
+          asm volatile("" : "+v"(a_k[kk]), "+v"(b_lo[kk]), "+v"(b_hi[kk]));      // opaque: not to be re-derived from one another in the loop
+        }
+        auto ktile = [&](auto AS, auto WS) {
+          constexpr int as = decltype(AS)::value, wsl = decltype(WS)::value;
+          constexpr int a_c = as * A_BYTES;
+          constexpr int w_c = W_RING0 + wsl * B_BYTES - A_BYTES - (wsl > 0 ? HI : 0);
+          static_assert(a_c + (MI - 1) * 2048 < 65536 && w_c >= 0 && w_c + (NI - 1) * 2048 < 65536, "fragment offsets must fit the ds_read immediate");
 #pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(base_a + FRAG_AT(a_rd, i * 16 * 128, kk));
+          for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[MI], bfr[NI];
+            const uint32_t wb = wsl > 0 ? b_hi[kk] : b_lo[kk];
 #pragma unroll
-            for (int j = 0; j < NI; ++j) bfr[j] = *(const bf16x8*)(base_b + FRAG_AT(b_rd, j * 16 * 128, kk));
+            for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(smem + a_k[kk] + (a_c + i * 16 * 128));
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bfr[j] = *(const bf16x8*)(smem + wb + (w_c + j * 16 * 128));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            bar();
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+              for (int j = 0; j < NI; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+            bar();
           }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          bar();
+        };
+        using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>; using S2 = std::integral_constant<int, 2>;
+        for (int kt = 0;;) {
+          ktile(S0{}, S0{}); if (++kt >= nk) break;
+          ktile(S1{}, S1{}); if (++kt >= nk) break;
+          ktile(S0{}, S2{}); if (++kt >= nk) break;
+          ktile(S1{}, S0{}); if (++kt >= nk) break;
+          ktile(S0{}, S1{}); if (++kt >= nk) break;
+          ktile(S1{}, S2{}); if (++kt >= nk) break;
+        }
+      } else
+#endif
+      {
+      int ws = 0;                                       // W slot of tile kt
+#ifdef VC_GEMM_NO_LDSREAD   // analysis builds only (tools/gemm_power.py): the fragments of K-slice 0 feed every MFMA
+        bf16x8 af[MI], bfr[NI];
+#endif
+        for (int kt = 0; kt < nk; ++kt) {
+          const char* base_a = smem + (kt & 1) * A_BYTES;
+          const char* base_b = smem + wslot(ws) - A_BYTES;                 // b_rd already carries +A_BYTES
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) {
+#ifdef VC_GEMM_NO_LDSREAD
+            if (kt == 0 && kk == 0)
+#else
+            bf16x8 af[MI], bfr[NI];
+#endif
+            {
+#pragma unroll
+              for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(base_a + FRAG_AT(a_rd, i * 16 * 128, kk));
+#pragma unroll
+              for (int j = 0; j < NI; ++j) bfr[j] = *(const bf16x8*)(base_b + FRAG_AT(b_rd, j * 16 * 128, kk));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            bar();
 #ifdef VC_GEMM_NO_MFMA
 #pragma unroll
-          for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(af[i]));
+            for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(af[i]));
 #pragma unroll
-          for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(bfr[j]));
+            for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(bfr[j]));
 #else
 #pragma unroll
-          for (int i = 0; i < MI; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < NI; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+              for (int j = 0; j < NI; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
 #endif
-          bar();
+            bar();
+          }
+          ws = ws == WD ? 0 : ws + 1;
         }
-        ws = ws == WD ? 0 : ws + 1;
       }
       if (grp == 0) bar();
     }

@@ -412,7 +412,9 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
             for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(smem + a_k[kk] + (a_c + i * 16 * 128));
 #pragma unroll
             for (int j = 0; j < NI; ++j) bfr[j] = *(const bf16x8*)(smem + wb + (w_c + j * 16 * 128));
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // lgkmcnt(0) as a builtin: the compiler's counter model sees the fragments landed (after an asm wait it re-inserted
+            // lgkmcnt(5) ... (0) between the first MFMAs - trivially satisfied, measured +-0.00 % either way)
+            __builtin_amdgcn_s_waitcnt(0xc07f);
             bar();
 #pragma unroll
             for (int i = 0; i < MI; ++i)

@@ -320,26 +320,18 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
         // QKNorm (RMS over the 128 dims of the head: this lane's 64 + its partner's in the other half-wave; layers.py:63-84)
         // and RoPE (math.py:112-117) on the raw projection output, then the softmax scale; rounding points of the
         // reference: (x * rrms) -> bf16, * scale -> bf16; the rotated value is rounded ONCE, with the scale folded in
-        // the token's (cos, sin) row and the scale are requested NOW, beside the query row itself: one memory round trip per
-        // query block instead of two (they used to be loaded after the cross-lane reduction below had finished)
-        const bf16_t* gsc = (tok < a.split ? a.q_scale : a.q_scale2) + hh * 8;
-        const float* rp = a.rope + (long)b * a.rope_bstride + (long)tok * 128 + hh * 8;
-        u32x4 gws[8];
-        f32x4 c0s[8], c1s[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) { gws[t] = *(const u32x4*)(gsc + t * 16); c0s[t] = *(const f32x4*)(rp + t * 16); c1s[t] = *(const f32x4*)(rp + t * 16 + 4); }
-#pragma unroll
-        for (int t = 0; t < 8; ++t) asm volatile("" : "+v"(gws[t]), "+v"(c0s[t]), "+v"(c1s[t]));     // (not to be sunk below the reduction again)
         float ss = 0.f;
 #pragma unroll
         for (int t = 0; t < 8; ++t)
 #pragma unroll
           for (int e = 0; e < 4; ++e) { const float x0 = lo_bf(raw[t][e]), x1 = hi_bf(raw[t][e]); ss += x0 * x0; ss += x1 * x1; }
         const float rrms = 1.0f / sqrtf(xsum32(ss) * (1.0f / 128.0f) + 1e-6f);
+        const bf16_t* gsc = (tok < a.split ? a.q_scale : a.q_scale2) + hh * 8;
+        const float* rp = a.rope + (long)b * a.rope_bstride + (long)tok * 128 + hh * 8;
         sfor<0, 8>([&](auto T) {
           constexpr int t = decltype(T)::value;
-          const u32x4 gw = gws[t];
-          const f32x4 c0 = c0s[t], c1 = c1s[t];
+          const u32x4 gw = *(const u32x4*)(gsc + t * 16);
+          const f32x4 c0 = *(const f32x4*)(rp + t * 16), c1 = *(const f32x4*)(rp + t * 16 + 4);
           const float cs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
           sfor<0, 4>([&](auto E) {
             constexpr int e = decltype(E)::value;

@@ -337,8 +337,8 @@ def roofline_gemm(job, iters=3):
 
 
 def roofline_attention(job, iters=3):
-    """The attention kernel AS THE PRODUCT RUNS IT (variant by size; with variant 12: QKNorm + RoPE of the queries in the
-    kernel's prologue, tail split + merge), timed IN SITU: HIP events bracket each of the 57 attention launches inside
+    """The attention kernel AS THE PRODUCT RUNS IT (variant by size; with variant 12: finished, prescaled query rows from the
+    qkv GEMM's epilogue, tail split), timed IN SITU: HIP events bracket each of the 57 attention launches inside
     whole evaluations of the product's launch plan, so every launch finds the caches as the step graph leaves them (its q / k
     rows and V^T just written by the qkv GEMM and the K pre-pass on other XCDs, the GEMMs' weights streaming through L2 / MALL
     before and after).  `isolated_us` = the same launch with the same arguments back to back on hot caches, for comparison
@@ -347,9 +347,10 @@ def roofline_attention(job, iters=3):
     eng, ws = job.eng, job.ws
     s = job.s
     v = eng.attention_variant(ws)
-    fused_q = bool(v & 8) and eng.fuse_qnorm
+    fused_q = bool(v & 8) and bool(eng.fuse_qnorm)
+    q_done = eng._qn_in_gemm(ws)                # the qkv GEMM's epilogue left finished, prescaled query rows
     sc = eng.W.w["single_blocks.0.norm.query_norm.scale"]
-    qn = (sc, None, 0, ws.ROPE) if fused_q else None
+    qn = (sc, None, 0, ws.ROPE) if fused_q and not q_done else None
     bound = eng.W.logit_bound if eng.bounded_softmax else 0.0
     # attention64.hip runs attn64_kernel<true> (no running max) when the weights' norm scales bound the logits by <= 100
     template = ("attn64_kernel<true> (bounded logits: no running max)" if 0.0 < bound <= 100.0 else "attn64_kernel<false> (running max)") if v & 8 else "attn_fwd_kernel"
@@ -368,7 +369,7 @@ def roofline_attention(job, iters=3):
 
         def iso():
             hip.attention(ws.QKV, ws.VT, ws.CAT[:, :eng.D], ws.L, eng.H, variant=v, stream=s, B=ws.B, scratch=eng.attn_scratch,
-                          q_norm=qn, logit_bound=bound)          # the SAME instantiation the product launches
+                          q_norm=qn, logit_bound=bound, q_prescaled=q_done)          # the SAME instantiation the product launches
         iso()
         e0, e1 = hip.Event(), hip.Event()
         e0.record(s)
@@ -378,7 +379,7 @@ def roofline_attention(job, iters=3):
         ms_iso = e0.elapsed_ms(e1) / (iters * 10)
     fl = 4.0 * ws.L * ws.L * eng.D * ws.B
     return dict(kernel=(template + " + attn64_merge_kernel") if v & 8 else template, variant=v, logit_bound=round(bound, 3),
-                query_norm_in_kernel=fused_q, timed="in situ: HIP events around each attention launch inside product-plan "
+                query_norm="qkv GEMM epilogue (prescaled)" if q_done else ("attention prologue" if fused_q else "pre-pass"), timed="in situ: HIP events around each attention launch inside product-plan "
                 "evaluations", launches_timed=len(situ), avg_launch_us=round(ms * 1e3, 2),
                 median_launch_us=round(situ[len(situ) // 2] * 1e3, 2), isolated_us=round(ms_iso * 1e3, 2),
                 achieved=round(fl / ms / 1e9, 1), unit="TFLOP/s", frac=round(fl / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4))

@@ -21,7 +21,7 @@ extern "C" {
 #define VC_ERR_HIP (-2)
 #define VC_ERR_STATE (-3)
 
-#define VC_ABI_VERSION 7
+#define VC_ABI_VERSION 8
 int vc_abi_version(void);
 const char* vc_last_error(void);
 /* sizeof(VcGemmProblem), sizeof(VcGemmArgs), sizeof(VcLnStream), sizeof(VcAttention), sizeof(VcFluxConfig),
@@ -66,20 +66,22 @@ typedef struct VcGemmProblem {
   void* vt;
   int64_t vt_bstride;
   int32_t vt_col0, vt_rpb, vt_row0, vt_lpad;
-  /* VC_EPI_QKV, kn_heads = H > 0 (N = 3 * 128 * H): W's rows / bias arrive HEAD-PERMUTED so that every key head lies inside
-   * one 192-column tile - permuted column p is logical column (t = p / 192, j = p % 192)
-   *     p < 192 H:   j < 128 ?  128 H + 128 t + j  (key head t)  :  64 t + j - 128  (query columns)
-   *     p < 256 H:   p - 128 H                                      (the other half of the query columns)
-   *     else:        p                                              (V, as before; vt_col0 = 256 H)
-   * and C is written at the logical columns ("B L (K H D)", layers.py:166,236) by any tile shape.  With kn_scale != NULL
-   * (forces the 256x192 tile) the epilogue ALSO applies QKNorm with kn_scale [128] bf16 and RoPE from kn_rope
-   * ([B?][L][64][2] f32, row vt_row0 + m % vt_rpb of batch element m / vt_rpb) to every key head before the row leaves
-   * (layers.py:63-84, math.py:112-117): bit-identical to vc_qknorm_rope_vt(parts = VC_QKN_K) over the plain output, which
-   * is then not needed - the "QKV + RoPE fused projection" (q: VcAttention.q_scale; V: vt). */
+  /* VC_EPI_QKV, kn_heads = H > 0 (N = 3 * 128 * H): W's rows / bias arrive HEAD-PERMUTED so that every 192-column tile holds one
+   * whole query or key head and half a value head - permuted column p is logical column (t = p / 192, j = p % 192)
+   *     j < 128:   128 t + j             (t < H: query head t; t >= H: key head t - H)
+   *     else:      256 H + 64 t + j - 128 (V columns 64 t .. 64 t + 63; vt_col0 = 256 H)
+   * and C is written at the logical columns ("B L (K H D)", layers.py:166,236) by any tile shape (only the 256x192 tile writes V^T
+   * in whole 16-B runs).  With kn_scale and / or qn_scale != NULL (forces the 256x192 tile) the epilogue ALSO applies QKNorm with
+   * kn_scale / qn_scale [128] bf16 and RoPE from kn_rope ([B?][L][64][2] f32, row vt_row0 + m % vt_rpb of batch element
+   * m / vt_rpb) to every key / query head before the row leaves (layers.py:63-84, math.py:112-117): bit-identical to
+   * vc_qknorm_rope_vt(parts = VC_QKN_K / VC_QKN_Q) over the plain output, which is then not needed - the "QKV + RoPE fused
+   * projection".  qn_prescale != 0: the query heads leave multiplied by 128^-0.5 * log2(e) before their one rounding
+   * (= parts | VC_QKN_QPRE), the form VcAttention.q_prescaled reads. */
   const void* kn_scale;
   const float* kn_rope;
   int64_t kn_rope_bstride;
-  int32_t kn_heads, kn_pad_;
+  int32_t kn_heads, qn_prescale;
+  const void* qn_scale;
   /* VcGemmArgs.batch = Z > 1: Z independent GEMMs of this shape in ONE launch (blockIdx.y) - instance z reads A + z * a_zstride,
    * W + z * w_zstride and writes C + z * c_zstride (elements, multiples of 8): the per-head S = Q K^T and O = P V products of an
    * attention whose head_dim the fused kernel does not cover (T5: 64 heads x d_kv 64; CLIP) as two launches per layer. */
@@ -159,10 +161,11 @@ int vc_ln_modulate2(const VcLnStream* a, const VcLnStream* b, int64_t mod_bstrid
  * Token rows < split use (q_scale, k_scale), rows >= split use (q_scale2, k_scale2): the text and image
  * streams of a DoubleStreamBlock own separate QKNorm scales (layers.py:167,174); NULL scale2 = one set.
  * parts: bit 0 = the q rows, bit 1 = the k rows, bit 2 = V -> vt; 7 = everything.  6 when the attention call
- * normalises the queries itself (VcAttention.q_scale). */
+ * normalises the queries itself (VcAttention.q_scale).  Bit 3 (VC_QKN_QPRE, with bit 0): the softmax scale is folded into q. */
 #define VC_QKN_Q 1
 #define VC_QKN_K 2
 #define VC_QKN_VT 4
+#define VC_QKN_QPRE 8   /* with VC_QKN_Q: the query rows leave multiplied by 128^-0.5 * log2(e) (VcAttention.q_prescaled) */
 int vc_qknorm_rope_vt(void* qkv, int64_t ld, int64_t bstride, const void* q_scale, const void* k_scale,
                       const void* q_scale2, const void* k_scale2, int32_t split, const float* rope,
                       int64_t rope_bstride, void* vt, int32_t B, int32_t L, int32_t Lpad, int32_t H, int32_t parts,
@@ -180,12 +183,15 @@ int vc_qknorm_rope_vt(void* qkv, int64_t ld, int64_t bstride, const void* q_scal
  * (attention64.hip), persistent; q * 128^-0.5 log2(e) is rounded to bf16 when the queries are loaded.
  * +4 (7, 12) = TAIL SPLIT: the items beyond the last full round of resident workgroups are cut along the keys into one
  * equal chunk per workgroup; partial (O, m, l) go to `scratch` (>= vc_attention_scratch_bytes(), device memory,
- * contents undefined afterwards) and a second kernel on the same stream merges them.  Same softmax, different f32
+ * contents undefined afterwards) and are merged behind them.  Same softmax, different f32
  * summation order for those rows.  The launcher drops the split when scratch is NULL / too small, kv_len is given, or
  * it would not shorten the critical path.  12 is the default of the host engine.
  * q_scale != NULL (variants 8, 12 only): the q columns of qkv hold the RAW projection output and QKNorm + RoPE
  * (layers.py:75-84, math.py:112-117) are applied to the 64 query rows a wave loads, with q_scale / q_scale2 / split /
- * rope / rope_bstride as in vc_qknorm_rope_vt (which is then called with parts = VC_QKN_K | VC_QKN_VT). */
+ * rope / rope_bstride as in vc_qknorm_rope_vt (which is then called with parts = VC_QKN_K | VC_QKN_VT).
+ * q_prescaled != 0 (variants 8, 12 only; excludes q_scale): the q columns already hold QK-normed, rotated queries TIMES
+ * 128^-0.5 * log2(e), rounded once (VcGemmProblem.qn_prescale / VC_QKN_QPRE): the kernel loads them straight into its MFMA
+ * operand registers - no per-item prologue arithmetic. */
 typedef struct VcAttention {
   const void* qkv; int64_t ld, bstride;
   const void* vt; void* out; int64_t ldo, out_bstride;
@@ -199,7 +205,7 @@ typedef struct VcAttention {
    * * max|key_norm.scale| is a property of the model's weights.  For logit_bound <= 100 the kernel then runs its softmax
    * with a fixed reference point 0 (no running max: same function, 4 of 68 MFMAs and the row-max VALU work per tile
    * saved); 0 = unknown: online softmax with running max. */
-  float logit_bound; int32_t pad_;
+  float logit_bound; int32_t q_prescaled;
 } VcAttention;
 int vc_attention(const VcAttention* a, void* stream);
 int64_t vc_attention_scratch_bytes(void);

@@ -60,11 +60,12 @@ def test_forward_b1_vs_golden_and_oracle(model, golden):
     assert rel_l2(got, _oracle(sd, inp, torch.tensor([0.7]))) < TOL_ORACLE
 
 
-@pytest.mark.parametrize("variant,fuse", [(12, True), (12, False), (8, True), (3, False), (7, False)])
+@pytest.mark.parametrize("variant,fuse", [(12, 2), (12, True), (12, False), (8, 2), (8, True), (3, False), (7, False)])
 def test_forward_every_attention_route_vs_golden(golden, variant, fuse):
     """The engine picks the attention kernel by size (tiny grids -> the 32-queries-per-wave kernel); here every route is
-    forced on the tiny model: the one-wave-per-SIMD kernel with and without the in-kernel query norm, with and without the
-    tail split, and the round-1 kernel - each against the reference's own forward (B = 1 and ragged B = 2)."""
+    forced on the tiny model: the one-wave-per-SIMD kernel with the query norm in the qkv GEMM's epilogue (2, the product's
+    route), in the attention kernel's prologue (True) and in the pre-pass (False), with and without the tail split, and the
+    round-1 kernel - each against the reference's own forward (B = 1 and ragged B = 2)."""
     from tests.helpers import tiny_model
     from tests.procedural import tiny_inputs
     m, sd = tiny_model()

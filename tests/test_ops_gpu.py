@@ -180,7 +180,7 @@ def test_gemm_persistent_grouped_qkv_epilogue(hip, cfg):
     check(v1[..., :L].permute(0, 3, 1, 2).reshape(B * L, D), want[:, 2 * D:])
     q2, v2 = run(hip.GEMM_PERSIST)                         # the launcher's own plan (may split): bf16-equal
     check(q2[:, :2 * D], want[:, :2 * D])
-    # and with head-permuted weights + the key norm in the epilogue (vkind 3 tiles leave the epilogue early inside the tile loop)
+    # and with head-permuted weights + the key norm in the epilogue (the head tiles leave the epilogue early inside the tile loop)
     perm = hip.qkv_head_permutation(H).to(DEV)
     ks = (1 + 0.1 * rnd(128, seed=8)).to(torch.bfloat16)
     rope = torch.stack([rope_table(L), rope_table(L).flip(0)]).contiguous()
@@ -201,12 +201,13 @@ def test_gemm_persistent_grouped_qkv_epilogue(hip, cfg):
 
 
 @pytest.mark.parametrize("cfg", [0, 1, 2, 4, 5, 19, 34, 36])
-@pytest.mark.parametrize("geom", [(2, 16, 24, 2), (1, 64, 320, 3), (2, 5, 27, 1), (1, 136, 700, 6)])
-def test_gemm_head_permuted_qkv_and_key_norm_in_the_epilogue(hip, cfg, geom):
-    """VcGemmProblem.kn_heads: qkv weights whose rows are head-permuted (every key head inside one 192-column tile) give the
-    SAME C (q | k | v at their logical columns) and the same V^T as the natural order, on every tile shape; with kn_scale
-    the 256x192 epilogue also applies QKNorm + RoPE to the key heads - bit-identical to GEMM + vc_qknorm_rope_vt(parts = K).
-    Two streams with their own key scales, batch-strided C rows, two batch elements, row counts off every tile edge."""
+@pytest.mark.parametrize("geom", [(2, 16, 24, 2), (1, 64, 320, 3), (2, 5, 27, 1), (1, 136, 700, 6), (1, 520, 1800, 10)])
+def test_gemm_head_permuted_qkv_and_norms_in_the_epilogue(hip, cfg, geom):
+    """VcGemmProblem.kn_heads: qkv weights whose rows are head-permuted (every 192-column tile = one whole query or key head +
+    64 V columns) give the SAME C (q | k | v at their logical columns) and the same V^T as the natural order, on every tile
+    shape; with kn_scale / qn_scale the 256x192 epilogue also applies QKNorm + RoPE to the key / query heads - bit-identical to
+    GEMM + vc_qknorm_rope_vt(parts = K / Q | K), and with qn_prescale to parts | QPRE (the softmax scale folded into q).
+    Two streams with their own scales, batch-strided C rows, two batch elements, row counts off every tile edge."""
     B, T, N, H = geom
     D, L = 128 * H, T + N
     Lp = (L + 63) // 64 * 64
@@ -214,31 +215,50 @@ def test_gemm_head_permuted_qkv_and_key_norm_in_the_epilogue(hip, cfg, geom):
     wi, wt = rnd(3 * D, D, scale=D ** -0.5, seed=3), rnd(3 * D, D, scale=D ** -0.5, seed=4)
     bi, bt = rnd(3 * D, seed=5), rnd(3 * D, seed=6)
     ks_i, ks_t = (1 + 0.1 * rnd(128, seed=8)).to(torch.bfloat16), (1 + 0.1 * rnd(128, seed=9)).to(torch.bfloat16)
-    qs = torch.ones(128, dtype=torch.bfloat16, device=DEV)
+    qs_i, qs_t = (1 + 0.1 * rnd(128, seed=10)).to(torch.bfloat16), (1 + 0.1 * rnd(128, seed=11)).to(torch.bfloat16)
     rope = torch.stack([rope_table(L), rope_table(L).flip(0)][:B]).contiguous()
     perm = hip.qkv_head_permutation(H).to(DEV)
+    assert sorted(perm.tolist()) == list(range(3 * D))
 
-    def run(permuted, fused, tile):
+    def run(permuted, tile, k=False, q=False, pre=False, with_vt=True):
         qkv = torch.full((B * L, 3 * D), float("nan"), dtype=torch.bfloat16, device=DEV)
         vt = torch.full((B, H, 128, Lp), 7.0, dtype=torch.bfloat16, device=DEV)
-        kw = dict(c_bstride=L * 3 * D, vt=vt, vt_col0=2 * D)
-        kn_i = dict(kn_heads=H, kn_scale=ks_i if fused else None, kn_rope=rope if fused else None) if permuted else {}
-        kn_t = dict(kn_heads=H, kn_scale=ks_t if fused else None, kn_rope=rope if fused else None) if permuted else {}
+        kw = dict(c_bstride=L * 3 * D, **(dict(vt=vt, vt_col0=2 * D) if with_vt else {}))
+        fused = k or q
+        kn_i = dict(kn_heads=H, kn_scale=ks_i if k else None, qn_scale=qs_i if q else None, qn_prescale=pre, kn_rope=rope if fused else None) if permuted else {}
+        kn_t = dict(kn_heads=H, kn_scale=ks_t if k else None, qn_scale=qs_t if q else None, qn_prescale=pre, kn_rope=rope if fused else None) if permuted else {}
         w1, b1, w2, b2 = (wi[perm].contiguous(), bi[perm].contiguous(), wt[perm].contiguous(), bt[perm].contiguous()) if permuted else (wi, bi, wt, bt)
         hip.gemm([hip.make_problem(xi, w1, b1, qkv[T:], M=B * N, c_rpb=N, vt_rpb=N, vt_row0=T, **kw, **kn_i),
                   hip.make_problem(xt, w2, b2, qkv[:T], M=B * T, c_rpb=T, vt_rpb=T, vt_row0=0, **kw, **kn_t)], epi=hip.EPI_QKV, tile_cfg=tile)
         torch.cuda.synchronize()
         return qkv, vt
-    plain, vt0 = run(False, False, cfg | hip.GEMM_NO_SPLIT)
-    permd, vt1 = run(True, False, cfg | hip.GEMM_NO_SPLIT)
+    tile = cfg | hip.GEMM_NO_SPLIT
+    plain, vt0 = run(False, tile)
+    permd, vt1 = run(True, tile)
     assert torch.equal(permd[:, :2 * D], plain[:, :2 * D]) and torch.equal(vt1, vt0)
     assert bool(torch.isnan(permd[:, 2 * D:].float()).all()) and torch.isfinite(permd[:, :2 * D].float()).all()
-    fused, vt2 = run(True, True, cfg | hip.GEMM_NO_SPLIT)          # (kn_scale forces the 256x192 tile whatever cfg asks for)
-    want = plain.clone()
-    hip.qknorm_rope_vt(want, qs, ks_t, rope, vt0.clone(), L, H, q_scale2=qs, k_scale2=ks_i, split=T, B=B, parts=hip.QKN_K)
-    torch.cuda.synchronize()
-    assert torch.equal(fused[:, :2 * D], want[:, :2 * D]) and torch.equal(vt2, vt0)
-    assert not torch.equal(fused[:, D:2 * D], plain[:, D:2 * D])
+    allc, vtn = run(True, tile, with_vt=False)                     # no vt: V lands in C at its logical columns
+    assert torch.equal(allc[:, :2 * D], plain[:, :2 * D]) and bool((vtn == 7.0).all())
+    assert torch.equal(allc[:, 2 * D:].reshape(B, L, H, 128).permute(0, 2, 3, 1), vt0[..., :L])
+
+    def prepass(parts):
+        want = plain.clone()
+        hip.qknorm_rope_vt(want, qs_t, ks_t, rope, vt0.clone(), L, H, q_scale2=qs_i, k_scale2=ks_i, split=T, B=B, parts=parts)
+        torch.cuda.synchronize()
+        return want
+    # (kn_scale / qn_scale force the 256x192 tile whatever cfg asks for)
+    for kq, pre, parts in (((True, False), False, hip.QKN_K), ((False, True), False, hip.QKN_Q), ((True, True), False, hip.QKN_Q | hip.QKN_K),
+                           ((True, True), True, hip.QKN_Q | hip.QKN_K | hip.QKN_QPRE)):
+        fused, vt2 = run(True, tile, k=kq[0], q=kq[1], pre=pre)
+        want = prepass(parts)
+        assert torch.equal(fused[:, :2 * D], want[:, :2 * D]) and torch.equal(vt2, vt0), (kq, pre)
+        assert not torch.equal(fused[:, :2 * D], plain[:, :2 * D])
+    # the prescaled queries are the plain ones times 128^-0.5 * log2(e), rounded once
+    a, b_ = prepass(hip.QKN_Q | hip.QKN_QPRE)[:, :D].float(), prepass(hip.QKN_Q)[:, :D].float()
+    c = 128 ** -0.5 * 1.4426950408889634
+    assert (a - b_ * c).abs().max().item() <= 2 ** -8 * (b_.abs().max().item() * c) + 1e-12
+    with pytest.raises(hip.VclozeHipError):
+        hip.qknorm_rope_vt(plain.clone(), qs_t, ks_t, rope, vt0.clone(), L, H, B=B, parts=hip.QKN_K | hip.QKN_QPRE)
 
 
 def test_gemm_transpose_detecting(hip):
@@ -566,6 +586,53 @@ def test_attention_with_in_kernel_query_norm(hip, variant, L, H, extra, kv_len, 
         check(o2[b * L:(b + 1) * L], R.attention_ref(qref, kref, v, kv_len))
     with pytest.raises(hip.VclozeHipError):                                # only the one-wave-per-SIMD kernel has it
         hip.attention(w2, vt, o2, L, H, variant=3, B=B, q_norm=(qs, qs2, split, rope))
+
+
+@pytest.mark.parametrize("variant", [8, 12])
+@pytest.mark.parametrize("L,H,extra,kv_len,split,B", [(64, 2, 0, None, 0, 1), (40, 2, 0, None, 16, 1), (200, 3, 256, None, 0, 1),
+                                                      (333, 2, 0, 301, 128, 1), (1, 1, 0, None, 0, 1), (1664, 4, 0, None, 512, 1),
+                                                      (300, 2, 0, None, 44, 2), (3968, 8, 0, None, 512, 1)])
+def test_attention_with_prescaled_queries(hip, variant, L, H, extra, kv_len, split, B):
+    """VcAttention.q_prescaled: the q columns already hold QK-normed, rotated queries times 128^-0.5 * log2(e) (the qkv GEMM's
+    epilogue with qn_prescale, here the pre-pass with QKN_QPRE - bit-identical, see the GEMM test) and variants 8 / 12 load
+    them straight into their MFMA operand registers.  Same function as the in-kernel query norm (one rounding of the scaled,
+    rotated value on both routes; they differ in f32 summation order of the RMS only) and as the torch reference."""
+    ld = 3 * H * 128 + extra
+    qkv = rnd(B * L, ld, seed=7)
+    qs, ks = (1 + 0.1 * rnd(128, seed=8)).to(torch.bfloat16), (1 + 0.1 * rnd(128, seed=9)).to(torch.bfloat16)
+    qs2, ks2 = (1 + 0.1 * rnd(128, seed=10)).to(torch.bfloat16), (1 + 0.1 * rnd(128, seed=11)).to(torch.bfloat16)
+    rope = torch.stack([rope_table(L)] + [rope_table(L).flip(0)] * (B - 1)).contiguous() if B > 1 else rope_table(L)
+    Lpad = (L + 63) // 64 * 64
+    vt = torch.zeros((B, H, 128, Lpad), dtype=torch.bfloat16, device=DEV)
+    kvl = None if kv_len is None else torch.tensor([kv_len] * B, dtype=torch.int32, device=DEV)
+    w1 = qkv.clone()      # route 1: the queries inside the attention kernel
+    hip.qknorm_rope_vt(w1, qs, ks, rope, vt, L, H, q_scale2=qs2, k_scale2=ks2, split=split, B=B, parts=hip.QKN_K | hip.QKN_VT)
+    o1 = torch.full((B * L, H * 128), float("nan"), dtype=torch.bfloat16, device=DEV)
+    hip.attention(w1, vt, o1, L, H, kv_len=kvl, variant=variant, B=B, q_norm=(qs, qs2, split, rope))
+    w2 = qkv.clone()      # route 2: finished, prescaled query rows
+    hip.qknorm_rope_vt(w2, qs, ks, rope, vt, L, H, q_scale2=qs2, k_scale2=ks2, split=split, B=B, parts=hip.QKN_Q | hip.QKN_K | hip.QKN_VT | hip.QKN_QPRE)
+    o2 = torch.full((B * L, H * 128), float("nan"), dtype=torch.bfloat16, device=DEV)
+    hip.attention(w2, vt, o2, L, H, kv_len=kvl, variant=variant, B=B, q_prescaled=True)
+    torch.cuda.synchronize()
+    assert torch.equal(w2[:, H * 128:2 * H * 128], w1[:, H * 128:2 * H * 128])
+    check(o2, o1.float(), tol=4e-3)
+    if L <= 1664:
+        for b in range(B):
+            rb = rope[b] if B > 1 else rope
+            x = qkv[b * L:(b + 1) * L]
+            qa, ka, _ = R.qknorm_rope_ref(x, qs, ks, rb, H)
+            qb_, kb_, _ = R.qknorm_rope_ref(x, qs2, ks2, rb, H)
+            qref, kref = torch.cat([qa[:split], qb_[split:]]), torch.cat([ka[:split], kb_[split:]])
+            v = x[:, 2 * H * 128: 3 * H * 128].float().reshape(L, H, 128)
+            check(o2[b * L:(b + 1) * L], R.attention_ref(qref, kref, v, kv_len))
+    o3 = torch.full((B * L, H * 128), float("nan"), dtype=torch.bfloat16, device=DEV)
+    hip.attention(w2, vt, o3, L, H, kv_len=kvl, variant=variant, B=B, q_prescaled=True, logit_bound=16.65 * 1.5 * 1.5)
+    torch.cuda.synchronize()
+    check(o3, o2.float(), tol=1e-2)                                        # the bounded-softmax instantiation
+    with pytest.raises(hip.VclozeHipError):                                # only the one-wave-per-SIMD kernel has it
+        hip.attention(w2, vt, o2, L, H, variant=3, B=B, q_prescaled=True)
+    with pytest.raises(hip.VclozeHipError):                                # finished rows are not normalised again
+        hip.attention(w2, vt, o2, L, H, variant=variant, B=B, q_prescaled=True, q_norm=(qs, qs2, split, rope))
 
 
 @pytest.mark.parametrize("variant", [0, 3, 8, 12])

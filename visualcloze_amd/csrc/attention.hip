@@ -405,6 +405,7 @@ int vc_attention_launch(const VcAttention& A, hipStream_t s, char* err, int errl
   if (A.q_scale && !(variant & 8)) { snprintf(err, errlen, "attention: in-kernel QKNorm + RoPE of the queries (q_scale) exists for variants 8 / 12 only"); return VC_ERR_ARG; }
   if (A.kv_gap && !kv_len) { snprintf(err, errlen, "attention: kv_gap needs kv_len"); return VC_ERR_ARG; }
   if (A.q_scale && !A.rope) { snprintf(err, errlen, "attention: q_scale given without a rope table"); return VC_ERR_ARG; }
+  if (A.q_prescaled && (!(variant & 8) || A.q_scale)) { snprintf(err, errlen, "attention: q_prescaled exists for variants 8 / 12 and excludes q_scale"); return VC_ERR_ARG; }
   AttnArgs a;
   a.qkv = (const bf16_t*)qkv; a.vt = (const bf16_t*)vt; a.out = (bf16_t*)out; a.kv_len = kv_len;
   a.kv_gap = kv_len ? A.kv_gap : nullptr;

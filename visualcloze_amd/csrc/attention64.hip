@@ -59,6 +59,7 @@ struct Attn64Args {
   float* part;
   // optional in-kernel QKNorm + RoPE of the query rows (q_scale != nullptr): as vc_qknorm_rope_vt
   const bf16_t* q_scale; const bf16_t* q_scale2; const float* rope; int64_t rope_bstride; int32_t split;
+  int32_t q_pre;        // the q columns hold normalised, rotated queries times 128^-0.5 * log2(e) (VcAttention.q_prescaled)
   uint64_t* debug_ts;   // profiling builds only (-DVC_ATTN_TIMESTAMPS): per workgroup (start, end, tiles)
 };
 // BOUNDED (VcAttention.logit_bound): the caller guarantees |c q.k| <= bound (log2 domain) for every query / key pair - with
@@ -309,6 +310,16 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) dma_k(I2{}, kt0 + 2, i);
     const int q0 = qb_i * QB + wave * QW;
+    if (a.q_pre) {
+      // the projection's epilogue left QKNorm, RoPE and the softmax scale in the rows (VcGemmProblem.qn_prescale): the
+      // fragments go from HBM straight into the MFMA operand registers - no arithmetic per work item
+      sfor<0, 2>([&](auto QBc) {
+        constexpr int qb = decltype(QBc)::value;
+        const int tok = min(q0 + qb * 32 + lq, L - 1);
+        const bf16_t* qp = qbase + (long)tok * a.ld + hh * 8;
+        sfor<0, 8>([&](auto T) { constexpr int t = decltype(T)::value; load_q<A_Q + (qb * 8 + t) * 4, t * 32>(qp); });
+      });
+    } else
     sfor<0, 2>([&](auto QBc) {
       constexpr int qb = decltype(QBc)::value;
       const int tok = min(q0 + qb * 32 + lq, L - 1);
@@ -769,6 +780,7 @@ int vc_attention64_launch(const VcAttention& A, bool tail_split, int n_cu, uint6
   a.B = B; a.L = L; a.Lpad = A.Lpad; a.H = H;
   a.q_scale = (const bf16_t*)A.q_scale; a.q_scale2 = (const bf16_t*)(A.q_scale2 ? A.q_scale2 : A.q_scale);
   a.rope = A.rope; a.rope_bstride = A.rope_bstride; a.split = A.q_scale2 ? A.split : L;
+  a.q_pre = A.q_prescaled != 0;
   a.qblocks = (L + QB - 1) / QB;
   a.items = a.qblocks * H * B;
   a.full_rounds = -1; a.tail_items = 0; a.tail_units = 0; a.part = (float*)scratch;

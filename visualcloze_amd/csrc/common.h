@@ -62,7 +62,12 @@ VC_DEV float silu_f(float x) {
 // (lane & 15 = position in the row).  ONE definition for the pre-pass kernels (norm.hip) and the qkv GEMM's epilogue
 // (gemm.hip), with floating-point contraction OFF: every product and sum is rounded as written (what torch's separate
 // mul / add kernels do), so the call sites give the same bits whatever the compiler would fuse around them.
-VC_DEV u32x4 qknorm_rope8(const u32x4 w, const float (&g)[8], const float (&cs)[8]) {
+//
+// `post` multiplies the rotated value before its ONE rounding to bf16: 1.0f (exact: the reference's q / k) or VC_QK_PRESCALE,
+// the softmax scale 128^-0.5 * log2(e) folded into the QUERY rows, which the one-wave-per-SIMD attention kernel then loads
+// straight into its MFMA operand registers (VcAttention.q_prescaled).
+#define VC_QK_PRESCALE (0.08838834764831845f * 1.4426950408889634f)
+VC_DEV u32x4 qknorm_rope8(const u32x4 w, const float (&g)[8], const float (&cs)[8], const float post = 1.0f) {
 #pragma clang fp contract(off)
   float x[8];
 #pragma unroll
@@ -79,7 +84,7 @@ VC_DEV u32x4 qknorm_rope8(const u32x4 w, const float (&g)[8], const float (&cs)[
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const float co = cs[2 * e], si = cs[2 * e + 1];
-    o[e] = pack2bf(co * x[2 * e] - si * x[2 * e + 1], si * x[2 * e] + co * x[2 * e + 1]);
+    o[e] = pack2bf((co * x[2 * e] - si * x[2 * e + 1]) * post, (si * x[2 * e] + co * x[2 * e + 1]) * post);
   }
   return o;
 }

@@ -57,7 +57,7 @@ struct Flux : Buffers {
   std::vector<SingleW> sgl;
   int64_t final_mod = 0;
   // options
-  int attn_variant = -1, tile_cfg = 0, fuse_qnorm = 1, fuse_vt = 1, qkv_heads = 0, fuse_knorm = 0, logit_bound_milli = 0, mlp_first = 0, splitk = 1, n_cu = 256;
+  int attn_variant = -1, tile_cfg = 0, fuse_qnorm = 2, fuse_vt = 1, qkv_heads = 0, fuse_knorm = 0, logit_bound_milli = 0, mlp_first = 0, splitk = 1, n_cu = 256;
   // prepared geometry + workspace carve-up
   bool prepared = false;
   int B = 0, T = 0, N = 0, L = 0, Lp = 0, S = 0;
@@ -220,17 +220,20 @@ int resolve(Flux& f, Err e) {
 
 // ---------------------------------------------------------------- launch helpers
 // qkv projections: with fuse_vt the V third leaves the GEMM transposed into VT (EPI_QKV); with head-permuted weights (option
-// qkv_heads) C receives the logical columns and, with fuse_knorm, the key heads leave QK-normed and rotated: no pre-pass left
+// qkv_heads) C receives the logical columns and, with fuse_knorm, the key heads leave QK-normed and rotated - and with fuse_qnorm
+// the query heads too, times the softmax scale (VcGemmProblem.qn_prescale): no pre-pass, no prologue arithmetic in the attention
 int attention_variant(const Flux& f);
 // (where the one-wave-per-SIMD attention kernel runs: small geometries keep ONE pre-pass launch for q and k - the fused
 // epilogue needs the 256x192 tile, which their short M does not fill)
 bool kn_in_gemm(const Flux& f) { return f.fuse_knorm && f.qkv_heads > 0 && (attention_variant(f) & 8); }
+bool qn_in_gemm(const Flux& f) { return kn_in_gemm(f) && f.fuse_qnorm >= 2; }
 int qkv_epi(const Flux& f) { return f.fuse_vt || f.qkv_heads > 0 ? VC_EPI_QKV : VC_EPI_BIAS; }
-void with_vt(Flux& f, VcGemmProblem& p, int rows, int row0, const void* k_scale) {
+void with_vt(Flux& f, VcGemmProblem& p, int rows, int row0, const void* q_scale, const void* k_scale) {
   if (f.fuse_vt) { p.vt = f.VT; p.vt_bstride = (int64_t)f.H * 128 * f.Lp; p.vt_col0 = 2 * f.D; p.vt_lpad = f.Lp; }
   if (f.qkv_heads > 0) {
     p.kn_heads = f.qkv_heads;
     if (kn_in_gemm(f)) { p.kn_scale = k_scale; p.kn_rope = f.ROPE; p.kn_rope_bstride = (int64_t)f.L * 128; }
+    if (qn_in_gemm(f)) { p.qn_scale = q_scale; p.qn_prescale = 1; }
   }
   if (f.fuse_vt || f.qkv_heads > 0) { p.vt_rpb = rows; p.vt_row0 = row0; }
 }
@@ -282,7 +285,7 @@ int attention_variant(const Flux& f) {
 // QKNorm + RoPE (+ V^T) and the joint attention over QKV -> CAT[:, :D] (layers.py:165-185 / 236-241)
 int attention(Flux& f, const Ctx& c, const void* q1, const void* k1, const void* q2, const void* k2, int split, Err e) {
   const int variant = attention_variant(f);
-  const bool fused_q = (variant & 8) && f.fuse_qnorm;
+  const bool fused_q = (variant & 8) && f.fuse_qnorm, q_done = qn_in_gemm(f);     // q_done: by the projection's epilogue, prescaled
   const int64_t ld = 3 * f.D, ldo = f.D + f.mlp;
   const int parts = (kn_in_gemm(f) ? 0 : VC_QKN_K) | (fused_q ? 0 : VC_QKN_Q) | (f.fuse_vt ? 0 : VC_QKN_VT);
   if (parts)
@@ -296,7 +299,8 @@ int attention(Flux& f, const Ctx& c, const void* q1, const void* k1, const void*
   a.kv_gap = f.gapped ? f.KVGAP : nullptr;
   a.B = f.B; a.L = f.L; a.Lpad = f.Lp; a.H = f.H; a.variant = variant;
   a.scratch = f.ATT_SCRATCH; a.scratch_bytes = f.att_scratch_bytes;
-  if (fused_q) { a.q_scale = q1; a.q_scale2 = q2; a.split = split; a.rope = f.ROPE; a.rope_bstride = (int64_t)f.L * 128; }
+  if (q_done) a.q_prescaled = 1;
+  else if (fused_q) { a.q_scale = q1; a.q_scale2 = q2; a.split = split; a.rope = f.ROPE; a.rope_bstride = (int64_t)f.L * 128; }
   a.logit_bound = (float)f.logit_bound_milli * 1e-3f;
   return vc_attention_launch(a, c.s, e.buf, e.len);
 }
@@ -314,7 +318,7 @@ int double_block(Flux& f, const Ctx& c, const DoubleW& w, Err e) {
     VcGemmProblem p[2] = {prob(XH_I, D, w.qkv[0], f.QKV + (int64_t)T * ldq, ldq, B * N), prob(XH_T, D, w.qkv[1], f.QKV, ldq, B * T)};
     p[0].c_rpb = N; p[1].c_rpb = T;
     p[0].c_bstride = p[1].c_bstride = (int64_t)L * ldq;
-    with_vt(f, p[0], N, T, w.ks[0]); with_vt(f, p[1], T, 0, w.ks[1]);
+    with_vt(f, p[0], N, T, w.qs[0], w.ks[0]); with_vt(f, p[1], T, 0, w.qs[1], w.ks[1]);
     TRY(gemm(f, p, 2, qkv_epi(f), nullptr, 0, c.s, e));
   }
   TRY(attention(f, c, w.qs[1], w.ks[1], w.qs[0], w.ks[0], T, e));   // rows < T: the text stream's scales
@@ -348,7 +352,7 @@ int single_block(Flux& f, const Ctx& c, const SingleW& w, Err e) {
   TRY(ln1(f, c, w.mod, e));
   {
     VcGemmProblem p = prob(f.XH, D, w.qkv, f.QKV, 3 * D, M);
-    with_vt(f, p, f.L, 0, w.ks);
+    with_vt(f, p, f.L, 0, w.qs, w.ks);
     TRY(gemm(f, &p, 1, qkv_epi(f), nullptr, 0, c.s, e));
   }
   // the attention kernel runs right behind the projection that wrote its operands, and the MLP-up GEMM right in front of the
@@ -550,7 +554,7 @@ int vc_flux_set_option_impl(void* handle, const char* name, int32_t value, char*
   if (!name) FAIL(VC_ERR_ARG, "flux_set_option: null name");
   if (!strcmp(name, "attn_variant")) f.attn_variant = value;
   else if (!strcmp(name, "tile_cfg")) f.tile_cfg = value;
-  else if (!strcmp(name, "fuse_qnorm")) f.fuse_qnorm = value != 0;
+  else if (!strcmp(name, "fuse_qnorm")) f.fuse_qnorm = value < 0 ? 0 : value > 2 ? 2 : value;
   else if (!strcmp(name, "fuse_vt")) f.fuse_vt = value != 0;
   else if (!strcmp(name, "qkv_heads")) {      // the bound qkv weights (linear1's first 3D rows) are head-permuted (vcloze_hip.h)
     if (value != 0 && value != f.H) FAIL(VC_ERR_ARG, "flux_set_option: qkv_heads must be 0 or num_heads = %d", f.H);

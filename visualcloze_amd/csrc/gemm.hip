@@ -600,23 +600,34 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
   // leaves as 16-B runs of 8 consecutive tokens per (head, dim) row of vt; a tile that straddles vt_col0 (or unaligned
   // row geometry) takes the ordinary path and scatters its V elements one by one (test geometries only).
   constexpr int EPT_LD = BM * 2 + 16;
-  // EPI_QKV with kn_heads = H > 0: the weight rows (output columns) arrive HEAD-PERMUTED (vcloze_hip.h): H blocks of
-  // [K head h (128) | 64 query columns], the other half of the query columns, V - every K head then lies inside ONE 192-wide
-  // tile, and with kn_scale the epilogue applies QKNorm + RoPE to it (layers.py:63-84, math.py:112-117) before the row
-  // leaves: the "QKV + RoPE fused projection".  C is always written at the LOGICAL columns (q | k | v).
-  int vkind = 0;
+  // EPI_QKV with kn_heads = H > 0: the weight rows (output columns) arrive HEAD-PERMUTED (vcloze_hip.h): 2H blocks of
+  // [head t (128): query head t for t < H, key head t - H after | V columns 64 t .. 64 t + 63] - every 192-wide tile holds ONE
+  // whole query or key head, and with qn_scale / kn_scale the epilogue applies QKNorm + RoPE to it (layers.py:63-84,
+  // math.py:112-117) before the row leaves: the "QKV + RoPE fused projection"; its 64 V columns leave transposed into vt.  C is
+  // always written at the LOGICAL columns (q | k | v).  A 192- or 128-wide tile holds at most ONE run of 64 V columns, at tile
+  // column v_lo; its staging image (vkind 4) is [BM] rows of 256 + 16 B for the other columns (in place), then the V run -
+  // transposed, [64][BM * 2 + 16 B], when vt takes whole 16-B runs (vfast), else [BM] rows of 128 + 16 B (192-wide tiles only).
+  // Every other case (vkind 5) maps each 16-B chunk of the generic pass 2 to its logical place.
+  int vkind = 0, v_lo = -1;
   const int knH = EPI == VC_EPI_QKV ? P.kn_heads : 0;
+  constexpr bool MIXED = EPI == VC_EPI_QKV && (BN == 192 || BN == 128);
+  constexpr int EPH_LD = 128 * 2 + 16, EPV_LD = 64 * 2 + 16, EPV0 = BM * EPH_LD;
+  bool vfast = false;
   auto qkv_col = [&](int n) {        // permuted column (multiple of 8) -> logical column
-    if (n < 192 * knH) { const int t = n / 192, j = n - 192 * t; return j < 128 ? 128 * knH + 128 * t + j : 64 * t + j - 128; }
-    return n < 256 * knH ? n - 128 * knH : n;
+    const int t = n / 192, j = n - 192 * t;
+    return j < 128 ? 128 * t + j : 256 * knH + 64 * t + j - 128;
   };
   if constexpr (EPI == VC_EPI_QKV) {
-    if (P.vt) {
-      const bool aligned = ((P.vt_rpb | P.vt_row0 | P.vt_lpad | (int)(P.vt_bstride & 7)) & 7) == 0;
+    const bool aligned = P.vt && ((P.vt_rpb | P.vt_row0 | P.vt_lpad | (int)(P.vt_bstride & 7)) & 7) == 0;
+    if (knH > 0) {
+      vkind = 5;
+      if (BN == 192) { vkind = 4; v_lo = 128; vfast = aligned; }
+      else if (BN == 128 && aligned && n0 % 384 != 0) { vkind = 4; v_lo = n0 % 384 == 128 ? 0 : 64; vfast = true; }
+    } else if (P.vt) {
       vkind = n0 >= P.vt_col0 ? (aligned ? 1 : 2) : (n0 + BN > P.vt_col0 ? 2 : 0);
     }
-    if (BN == 192 && knH > 0 && P.kn_scale && n0 < 192 * knH) vkind = 3;     // [K head | 64 q columns] tile, norm in here
     vkind = __builtin_amdgcn_readfirstlane(vkind);
+    v_lo = __builtin_amdgcn_readfirstlane(v_lo);
   }
   const bf16_t* __restrict__ bias = (const bf16_t*)P.bias;
 #pragma unroll
@@ -639,6 +650,15 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
       if (EPI == VC_EPI_QKV && vkind == 1) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) *(bf16_t*)(smem + (col + e) * EPT_LD + row * 2) = (bf16_t)(o[e >> 1] >> (16 * (e & 1)));
+      } else if (MIXED && vkind == 4) {
+        if (col < v_lo || col >= v_lo + 64) {
+          *(u32x2*)(smem + row * EPH_LD + col * 2) = o;
+        } else if (vfast) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) *(bf16_t*)(smem + EPV0 + (col - v_lo + e) * EPT_LD + row * 2) = (bf16_t)(o[e >> 1] >> (16 * (e & 1)));
+        } else {
+          *(u32x2*)(smem + EPV0 + row * EPV_LD + (col - v_lo) * 2) = o;
+        }
       } else {
         *(u32x2*)(smem + row * EP_LD + col * 2) = o;
       }
@@ -702,37 +722,73 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
   bf16_t* __restrict__ C = (bf16_t*)P.C;
   const bf16_t* __restrict__ res = (const bf16_t*)P.res;
   const bf16_t* __restrict__ gate = (const bf16_t*)P.gate;
-  if constexpr (EPI == VC_EPI_QKV && BN == 192) {
-    if (vkind == 3) {
-      // columns 0..127 of the tile = K head t: 16 lanes own one row (8 elements each) - RMS over the 128 by 4 xor-shuffles,
-      // scale, RoPE on the interleaved pairs with the token's f32 (cos, sin) row; qknorm_rope8 (common.h) is the one
-      // definition the pre-pass kernels of norm.hip use too: same bits as GEMM + pre-pass.  Columns 128..191 = 64 query
-      // columns, copied.
-      const int t = n0 / 192;
-      const bf16_t* __restrict__ ksc = (const bf16_t*)P.kn_scale;
-      const u32x4 sw = *(const u32x4*)(ksc + (etid & 15) * 8);
-      float g[8];
+  if constexpr (MIXED) {
+    if (vkind == 4) {
+      // 192-wide tile: columns 0..127 = head t: 16 lanes own one row (8 elements each) - RMS over the 128 by 4 xor-shuffles,
+      // scale, RoPE on the interleaved pairs with the token's f32 (cos, sin) row; qknorm_rope8 (common.h) is the one definition
+      // the pre-pass kernels of norm.hip use too: same bits as GEMM + pre-pass.  A head whose scale is NULL leaves as it is, and
+      // so do the 64 columns of a 128-wide tile that are not its V run.
+      const int t = (n0 + v_lo) / 192;                   // the 192-block the V run (and, BN == 192, the head) belongs to
+      const bf16_t* __restrict__ hsc = BN == 192 ? (const bf16_t*)(t < knH ? P.qn_scale : P.kn_scale) : nullptr;
+      const float post = (t < knH && P.qn_prescale) ? VC_QK_PRESCALE : 1.0f;
+      float g[8] = {};
+      if (hsc) {
+        const u32x4 sw = *(const u32x4*)(hsc + (etid & 15) * 8);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { g[2 * e] = lo_bf(sw[e]); g[2 * e + 1] = hi_bf(sw[e]); }
+        for (int e = 0; e < 4; ++e) { g[2 * e] = lo_bf(sw[e]); g[2 * e + 1] = hi_bf(sw[e]); }
+      }
       for (int c = etid; c < BM * 16; c += NT) {          // NT % 16 == 0: a row's 16 lanes stay together
         const int row = c >> 4, sub = c & 15;
+        if (BN == 128 && sub * 8 >= v_lo && sub * 8 < v_lo + 64) continue;      // (never with a head to normalise)
         const int m = min(m0 + row, M - 1);
-        const u32x4 tw = *(const u32x4*)(smem + row * EP_LD + sub * 16);
-        const int b = m / P.vt_rpb;
-        const float* rp = P.kn_rope + (long)b * P.kn_rope_bstride + (long)(P.vt_row0 + (m - b * P.vt_rpb)) * 128 + sub * 8;
-        const f32x4 c0 = *(const f32x4*)rp;
-        const f32x4 c1 = *(const f32x4*)(rp + 4);
-        const float cs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
-        const u32x4 o = qknorm_rope8(tw, g, cs);
+        u32x4 o = *(const u32x4*)(smem + row * EPH_LD + sub * 16);
+        if (hsc) {
+          const int b = m / P.vt_rpb;
+          const float* rp = P.kn_rope + (long)b * P.kn_rope_bstride + (long)(P.vt_row0 + (m - b * P.vt_rpb)) * 128 + sub * 8;
+          const f32x4 c0 = *(const f32x4*)rp;
+          const f32x4 c1 = *(const f32x4*)(rp + 4);
+          const float cs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+          o = qknorm_rope8(o, g, cs, post);
+        }
         const long crow = P.c_rpb > 0 ? (long)(m / P.c_rpb) * P.c_bstride + (long)(m % P.c_rpb) * P.ldc : (long)m * P.ldc;
-        if (m0 + row < M) *(u32x4*)(C + crow + 128 * knH + 128 * t + sub * 8) = o;
+        if (m0 + row < M) *(u32x4*)(C + crow + qkv_col(n0 + sub * 8)) = o;
       }
-      for (int c = etid; c < BM * 8; c += NT) {
-        const int row = c >> 3, sub = c & 7;
-        const int m = m0 + row;
-        if (m >= M) continue;
-        const long crow = P.c_rpb > 0 ? (long)(m / P.c_rpb) * P.c_bstride + (long)(m % P.c_rpb) * P.ldc : (long)m * P.ldc;
-        *(u32x4*)(C + crow + 64 * t + sub * 8) = *(const u32x4*)(smem + row * EP_LD + 256 + sub * 16);
+      // the V run: V columns 64 t .. 64 t + 63
+      bf16_t* __restrict__ vtp = (bf16_t*)P.vt;
+      if (vfast) {         // a lane moves 8 consecutive tokens of one V column = 16 B of one vt row
+        constexpr int CPRT = BM / 8;
+#pragma unroll 2
+        for (int c = etid; c < 64 * CPRT; c += NT) {
+          const int trow = c / CPRT, cc = c % CPRT;
+          const int m = m0 + cc * 8;
+          if (m >= M) continue;
+          const u32x4 tw = *(const u32x4*)(smem + EPV0 + trow * EPT_LD + cc * 16);
+          const int b = m / P.vt_rpb;
+          bf16_t* d = vtp + (long)b * P.vt_bstride + (long)(64 * t + trow) * P.vt_lpad + P.vt_row0 + (m - b * P.vt_rpb);
+          if (m + 8 <= M) {
+            *(u32x4*)d = tw;               // vt_rpb % 8 == 0 and m % 8 == 0: the 8 tokens share a batch element
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (m + e < M) d[e] = (bf16_t)(tw[e >> 1] >> (16 * (e & 1)));     // (same batch element: M ends it)
+          }
+        }
+      } else {
+        for (int c = etid; c < BM * 8; c += NT) {
+          const int row = c >> 3, sub = c & 7;
+          const int m = m0 + row;
+          if (m >= M) continue;
+          const u32x4 tw = *(const u32x4*)(smem + EPV0 + row * EPV_LD + sub * 16);
+          if (vtp) {        // 8 V columns of one token: 8 rows of vt
+            const int b = m / P.vt_rpb;
+            bf16_t* d = vtp + (long)b * P.vt_bstride + (long)(64 * t + sub * 8) * P.vt_lpad + P.vt_row0 + (m - b * P.vt_rpb);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d[(long)e * P.vt_lpad] = (bf16_t)(tw[e >> 1] >> (16 * (e & 1)));
+          } else {
+            const long crow = P.c_rpb > 0 ? (long)(m / P.c_rpb) * P.c_bstride + (long)(m % P.c_rpb) * P.ldc : (long)m * P.ldc;
+            *(u32x4*)(C + crow + 256 * knH + 64 * t + sub * 8) = tw;
+          }
+        }
       }
       VC_PHASE_STAMP(4);
       return;
@@ -783,14 +839,15 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
         o[e] = pack2bf(sum[0], sum[1]);
       }
     }
-    if (EPI == VC_EPI_QKV && vkind == 2 && n >= P.vt_col0) {   // 8 V columns of one token: 8 rows of vt
+    const int nl = EPI == VC_EPI_QKV && knH > 0 ? qkv_col(n) : n;      // logical column of this 16-B chunk
+    if (EPI == VC_EPI_QKV && P.vt && (vkind == 2 || knH > 0) && nl >= P.vt_col0) {   // 8 V columns of one token: 8 rows of vt
       const int b = m / P.vt_rpb;
-      bf16_t* d = (bf16_t*)P.vt + (long)b * P.vt_bstride + (long)(n - P.vt_col0) * P.vt_lpad + P.vt_row0 + (m - b * P.vt_rpb);
+      bf16_t* d = (bf16_t*)P.vt + (long)b * P.vt_bstride + (long)(nl - P.vt_col0) * P.vt_lpad + P.vt_row0 + (m - b * P.vt_rpb);
 #pragma unroll
       for (int e = 0; e < 8; ++e) d[(long)e * P.vt_lpad] = (bf16_t)(o[e >> 1] >> (16 * (e & 1)));
       continue;
     }
-    *(u32x4*)(C + crow + (EPI == VC_EPI_QKV && knH > 0 ? qkv_col(n) : n)) = o;
+    *(u32x4*)(C + crow + nl) = o;
   }
   VC_PHASE_STAMP(4);
   };   // epilogue
@@ -956,10 +1013,13 @@ hipError_t launch_cfg(const VcGemmArgs& a, int total_tiles, hipStream_t s) {
   constexpr int NT = (WM * WN + (PP == 2 ? 4 : 0)) * 64;
   constexpr int LDS_STAGES = (PP == 2 ? 2 * BM + 3 * BN : 2 * (BM + BN)) * BK * 2, LDS_EPI = BM * (BN * 2 + 16);
   constexpr int LDS_EPIT = BN * (BM * 2 + 16);      // EPI_QKV stages V tiles transposed
+  // ... and a head-permuted 192- / 128-wide tile as [BM] rows of 128 columns + its 64 V columns, transposed or (unaligned vt) row-major
+  constexpr int LDS_EPIM = (BN == 192 || BN == 128) ? BM * (128 * 2 + 16) + (64 * (BM * 2 + 16) > BM * (64 * 2 + 16) ? 64 * (BM * 2 + 16) : BM * (64 * 2 + 16)) : 0;
   constexpr int LDS0 = LDS_STAGES > LDS_EPI ? LDS_STAGES : LDS_EPI;
-  constexpr int LDS1 = LDS0 > LDS_EPIT ? LDS0 : LDS_EPIT;
+  constexpr int LDS1a = LDS0 > LDS_EPIT ? LDS0 : LDS_EPIT;
+  constexpr int LDS1 = LDS1a > LDS_EPIM ? LDS1a : LDS_EPIM;
   // PERSIST: W ring slots 0 and 1 sit at the top of the 160 KB, above both staging images (and above slot 2)
-  static_assert(!PERSIST || (160 * 1024 - 2 * BN * BK * 2 >= LDS_EPI && 160 * 1024 - 2 * BN * BK * 2 >= LDS_EPIT &&
+  static_assert(!PERSIST || (160 * 1024 - 2 * BN * BK * 2 >= LDS_EPI && 160 * 1024 - 2 * BN * BK * 2 >= LDS_EPIT && 160 * 1024 - 2 * BN * BK * 2 >= LDS_EPIM &&
                              160 * 1024 - 2 * BN * BK * 2 >= (2 * BM + BN) * BK * 2), "no room for the next tile's W(0), W(1)");
   constexpr int LDS = PERSIST ? 160 * 1024 : LDS1;
   static_assert(LDS <= 160 * 1024, "tile does not fit the 160 KB LDS of a gfx950 CU");
@@ -1154,11 +1214,13 @@ static int validate_gemm(VcGemmArgs& a, char* err, int errlen) {
       snprintf(err, errlen, "gemm: A operand of 4 GB or more (or a W row stride beyond 7 M elements) is not supported"); return VC_ERR_ARG; }
     if (a.epi == VC_EPI_GATE_RES && (!p.res || !p.gate || p.rows_per_batch <= 0 || p.ldres % 8 || p.gate_bstride % 8 || a.gate_step_stride % 8)) {
       snprintf(err, errlen, "gemm: gate/residual epilogue needs res, gate, rows_per_batch"); return VC_ERR_ARG; }
-    if (a.epi == VC_EPI_QKV && p.kn_heads != 0 && (p.kn_heads < 0 || p.N != 384 * p.kn_heads || (p.vt && p.vt_col0 != 256 * p.kn_heads) ||
-                                                  (p.kn_scale && (!p.kn_rope || p.vt_rpb <= 0 || p.vt_row0 < 0 || p.kn_rope_bstride < 0)))) {
-      snprintf(err, errlen, "gemm: head-permuted qkv needs N = 3 * 128 * kn_heads (N=%d kn_heads=%d), vt_col0 = 2 * 128 * kn_heads, and with "
-                            "kn_scale a rope table + the row geometry vt_rpb / vt_row0", p.N, p.kn_heads); return VC_ERR_ARG; }
-    if (a.epi != VC_EPI_QKV && (p.kn_heads != 0 || p.kn_scale)) { snprintf(err, errlen, "gemm: kn_heads / kn_scale belong to VC_EPI_QKV"); return VC_ERR_ARG; }
+    if (a.epi == VC_EPI_QKV && p.kn_heads != 0 && (p.kn_heads < 0 || p.N != 384 * p.kn_heads || (p.vt && p.vt_col0 != 256 * p.kn_heads) || p.vt_rpb <= 0 ||
+                                                  ((p.kn_scale || p.qn_scale) && (!p.kn_rope || p.vt_row0 < 0 || p.kn_rope_bstride < 0)))) {
+      snprintf(err, errlen, "gemm: head-permuted qkv needs N = 3 * 128 * kn_heads (N=%d kn_heads=%d), vt_col0 = 2 * 128 * kn_heads, the row geometry "
+                            "vt_rpb / vt_row0, and with kn_scale / qn_scale a rope table", p.N, p.kn_heads); return VC_ERR_ARG; }
+    if ((a.epi != VC_EPI_QKV || p.kn_heads == 0) && (p.kn_heads != 0 || p.kn_scale || p.qn_scale || p.qn_prescale)) {
+      snprintf(err, errlen, "gemm: kn_heads / kn_scale / qn_scale belong to VC_EPI_QKV with head-permuted weights"); return VC_ERR_ARG; }
+    if (p.qn_prescale && !p.qn_scale) { snprintf(err, errlen, "gemm: qn_prescale without qn_scale"); return VC_ERR_ARG; }
     if (a.epi == VC_EPI_QKV && p.vt && (p.vt_rpb <= 0 || p.vt_col0 < 0 || p.vt_col0 % 8 || p.vt_col0 >= p.N || p.vt_row0 < 0 ||
                                         p.vt_lpad < p.vt_row0 + p.vt_rpb || p.vt_bstride < (int64_t)(p.N - p.vt_col0) * p.vt_lpad)) {
       snprintf(err, errlen, "gemm: bad V^T description (vt_col0=%d vt_rpb=%d vt_row0=%d vt_lpad=%d vt_bstride=%ld)", p.vt_col0, p.vt_rpb,
@@ -1194,8 +1256,8 @@ static GemmPlan plan_gemm(const VcGemmArgs& a, int tile_cfg) {
     return pl;
   };
   if (force_sk >= 2) return sk_plan(force_sk > 8 ? 8 : force_sk);
-  for (int i = 0; i < a.nprob; ++i)      // K heads are normalised inside the epilogue: every K head must lie in one 192-wide tile
-    if (a.epi == VC_EPI_QKV && a.p[i].kn_scale) return GemmPlan{0, 4, tile_cfg != 0 && ((tile_cfg >> 4) & 3) != 2 ? (tile_cfg >> 4) & 3 : 2, 0, 0};
+  for (int i = 0; i < a.nprob; ++i)      // heads are normalised inside the epilogue: every head must lie in one 192-wide tile
+    if (a.epi == VC_EPI_QKV && (a.p[i].kn_scale || a.p[i].qn_scale)) return GemmPlan{0, 4, tile_cfg != 0 && ((tile_cfg >> 4) & 3) != 2 ? (tile_cfg >> 4) & 3 : 2, 0, 0};
   if (tile_cfg != 0) return GemmPlan{0, tile_cfg & 15, (tile_cfg >> 4) & 3, 0, 0};
   const TilePlan whole = best_tile(a);
   // SPLIT-K REMAINDER: the 256x192 tiles are R whole rounds of the CUs plus r tiles - run those r as r * S slices of K / S

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_vt_kernel(bf16_t* __restrict_
     const f32x4 c0 = *(const f32x4*)rp;
     const f32x4 c1 = *(const f32x4*)(rp + 4);
     const float cs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
-    const u32x4 o = qknorm_rope8(w, g, cs);
+    const u32x4 o = qknorm_rope8(w, g, cs, (which == 0 && (parts & 8)) ? VC_QK_PRESCALE : 1.0f);
     if (ok) *(u32x4*)ptr = o;
   }
 
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_rows_kernel(bf16_t* __restric
     for (int hh = 0; hh < HG; ++hh) w[hh] = (h0 + hh < H) ? *(const u32x4*)(base + hh * 128) : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
     for (int hh = 0; hh < HG; ++hh) {
-      const u32x4 o = qknorm_rope8(w[hh], g, cs);
+      const u32x4 o = qknorm_rope8(w[hh], g, cs, (which == 0 && (parts & 8)) ? VC_QK_PRESCALE : 1.0f);
       if (h0 + hh < H) *(u32x4*)(base + hh * 128) = o;
     }
   }
@@ -231,7 +231,8 @@ int vc_qknorm_rope_vt_launch(void* qkv, int64_t ld, int64_t bstride, const void*
                              const void* q_scale2, const void* k_scale2, int32_t split, const float* rope, int64_t rope_bstride, void* vt, int32_t B, int32_t L, int32_t Lpad,
                              int32_t H, int32_t parts, hipStream_t s, char* err, int errlen) {
   if (!qkv || !q_scale || !k_scale || !rope || !vt) { snprintf(err, errlen, "qknorm_rope_vt: null pointer"); return VC_ERR_ARG; }
-  if (parts <= 0 || parts > 7) { snprintf(err, errlen, "qknorm_rope_vt: parts=%d must be a non-empty subset of VC_QKN_Q | VC_QKN_K | VC_QKN_VT", parts); return VC_ERR_ARG; }
+  if (parts <= 0 || parts > 15 || !(parts & 7) || ((parts & VC_QKN_QPRE) && !(parts & VC_QKN_Q))) {
+    snprintf(err, errlen, "qknorm_rope_vt: parts=%d must be a non-empty subset of VC_QKN_Q | VC_QKN_K | VC_QKN_VT (+ VC_QKN_QPRE with VC_QKN_Q)", parts); return VC_ERR_ARG; }
   if (!q_scale2 || !k_scale2) { q_scale2 = q_scale; k_scale2 = k_scale; split = L; }
   if (B <= 0 || L <= 0 || H <= 0) { snprintf(err, errlen, "qknorm_rope_vt: empty problem"); return VC_ERR_ARG; }
   if (Lpad < L || Lpad % 64 || ld % 8 || bstride % 8) { snprintf(err, errlen, "qknorm_rope_vt: Lpad=%d must be a multiple of 64 >= L=%d; ld, bstride multiples of 8", Lpad, L); return VC_ERR_ARG; }

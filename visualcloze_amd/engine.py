@@ -18,8 +18,8 @@ HBM layout per geometry (B samples, T text tokens, N image tokens, L = T+N, D hi
   X    [B*L, D]      joint residual stream of the SingleStream blocks: per sample text rows first, then image rows
                      (= the reference's cat((txt, img), 1)); filled from XT/XI once per evaluation
   XH   [B*L, D]      LayerNorm+modulate output (GEMM A operand); XH[:B*N] / XH[B*N:] serve the two streams
-  QKV  [B*L, 3D]     "B L (K H D)" rows in joint order; k is QK-normed + RoPE'd in place (q inside the attention kernel
-                     with variants 8 / 12); the V third is not materialised when the qkv GEMM writes V^T itself (fuse_vt)
+  QKV  [B*L, 3D]     "B L (K H D)" rows in joint order; q and k arrive QK-normed + RoPE'd from the qkv GEMM's epilogue (q times
+                     the softmax scale) where the one-wave-per-SIMD attention runs; the V third is not materialised (fuse_vt)
   VT   [B, H, 128, Lp]  V transposed per head, Lp = L rounded up to 64 (attention B operand is key-contiguous)
   CAT  [B*L, D+4D]   attn | gelu(mlp) = linear2's input (SingleStreamBlock); CAT[:, :D] is also the DoubleStream
                      attention output (joint order), whose rows the proj GEMMs read batch-strided
@@ -130,7 +130,9 @@ class FluxEngine:
         self.attn_variant = None
         self.n_cu = hip.device_cus(dev)
         self.attn_scratch = hip.attention_scratch(dev)
-        self.fuse_qnorm = True     # variants 8 / 12: QKNorm + RoPE of the queries inside the attention kernel
+        # query QKNorm + RoPE: 2 = in the qkv GEMM's epilogue, with the softmax scale (where the key heads are normalised there
+        # too); 1 = inside the attention kernel (variants 8 / 12), on the rows a wave loads; 0 = by the pre-pass
+        self.fuse_qnorm = 2
         self.fuse_vt = weights.ref is None   # V^T written by the qkv GEMM's epilogue (EPI_QKV); the pre-pass is then K only
         # QKNorm + RoPE of the key heads inside the qkv GEMM's epilogue (head-permuted weights, VcGemmProblem.kn_scale): with
         # fuse_qnorm and fuse_vt no pre-pass kernel is left between the projection and the attention
@@ -349,7 +351,8 @@ class FluxEngine:
         ws, s = c.ws, c.s
         q1, k1, q2, k2 = scales
         variant = self.attention_variant(ws)
-        fused_q = bool(variant & 8) and self.fuse_qnorm
+        fused_q = bool(variant & 8) and bool(self.fuse_qnorm)
+        q_done = self._qn_in_gemm(ws)      # by the projection's epilogue, prescaled (hip.make_problem(qn_prescale=True))
         parts = (0 if self._kn_in_gemm(ws) else hip.QKN_K) | (0 if fused_q else hip.QKN_Q) | (0 if self._vt_in_gemm() else hip.QKN_VT)
         if parts:
             hip.qknorm_rope_vt(ws.QKV, q1, k1, ws.ROPE, ws.VT, ws.L, self.H, stream=s, q_scale2=q2, k_scale2=k2, split=split, B=ws.B,
@@ -359,8 +362,8 @@ class FluxEngine:
             e0 = hip.Event()
             e0.record(s)
         hip.attention(ws.QKV, ws.VT, c.ATT, ws.L, self.H, kv_len=c.kvl, variant=variant, stream=s, B=ws.B,
-                      scratch=self.attn_scratch, q_norm=(q1, q2, split, ws.ROPE) if fused_q else None, kv_gap=c.kvgap,
-                      logit_bound=self.W.logit_bound if self.bounded_softmax else 0.0)
+                      scratch=self.attn_scratch, q_norm=(q1, q2, split, ws.ROPE) if fused_q and not q_done else None, kv_gap=c.kvgap,
+                      logit_bound=self.W.logit_bound if self.bounded_softmax else 0.0, q_prescaled=q_done)
         if ev is not None:
             e1 = hip.Event()
             e1.record(s)
@@ -375,7 +378,11 @@ class FluxEngine:
         epilogue needs the 256x192 tile, which their short M does not fill (+1.2 ms of GEMM time at L = 1664)."""
         return self.fuse_knorm and self.W.qkv_heads > 0 and self.W.ref is None and bool(self.attention_variant(ws) & 8)
 
-    def _qkv_epi(self, ws: Workspace, rows: int, row0: int, k_scale=None):
+    def _qn_in_gemm(self, ws: Workspace) -> bool:
+        """query QKNorm + RoPE + the softmax scale in the qkv GEMM's epilogue as well: the attention kernel loads finished rows"""
+        return self._kn_in_gemm(ws) and int(self.fuse_qnorm) >= 2
+
+    def _qkv_epi(self, ws: Workspace, rows: int, row0: int, k_scale=None, q_scale=None):
         """(epilogue, problem kwargs) of a qkv projection: with fuse_vt the V third goes straight to ws.VT, transposed; with
         head-permuted weights C receives the logical columns and, with fuse_knorm, the key heads leave normalised + rotated"""
         kw = {}
@@ -385,6 +392,8 @@ class FluxEngine:
             kw.update(kn_heads=self.W.qkv_heads)
             if self._kn_in_gemm(ws):
                 kw.update(kn_scale=k_scale, kn_rope=ws.ROPE)
+            if self._qn_in_gemm(ws):
+                kw.update(qn_scale=q_scale, qn_prescale=True)
         if not kw:
             return hip.EPI_BIAS, {}
         kw.update(vt_rpb=rows, vt_row0=row0)
@@ -397,8 +406,8 @@ class FluxEngine:
         pf = f"double_blocks.{i}"
         im, tm = pf + ".img_mod.lin", pf + ".txt_mod.lin"
         self._ln2(c, im, tm, 0)
-        epi, kv_i = self._qkv_epi(ws, N, T, Wn[pf + ".img_attn.norm.key_norm.scale"])
-        _, kv_t = self._qkv_epi(ws, T, 0, Wn[pf + ".txt_attn.norm.key_norm.scale"])
+        epi, kv_i = self._qkv_epi(ws, N, T, Wn[pf + ".img_attn.norm.key_norm.scale"], Wn[pf + ".img_attn.norm.query_norm.scale"])
+        _, kv_t = self._qkv_epi(ws, T, 0, Wn[pf + ".txt_attn.norm.key_norm.scale"], Wn[pf + ".txt_attn.norm.query_norm.scale"])
         self._gemm([self._prob(pf + ".img_attn.qkv", c.XH_I, ws.QKV[T:], **c.qkv_i, **kv_i),
                     self._prob(pf + ".txt_attn.qkv", c.XH_T, ws.QKV[:T], **c.qkv_t, **kv_t)], epi=epi, s=s)
         self._attention(c, (Wn[pf + ".txt_attn.norm.query_norm.scale"], Wn[pf + ".txt_attn.norm.key_norm.scale"],
@@ -425,7 +434,7 @@ class FluxEngine:
         pf = f"single_blocks.{i}"
         mn = pf + ".modulation.lin"
         self._ln(c, ws.X, mn, 0, ws.XH, ws.L)
-        epi, kv = self._qkv_epi(ws, ws.L, 0, Wn[pf + ".norm.key_norm.scale"])
+        epi, kv = self._qkv_epi(ws, ws.L, 0, Wn[pf + ".norm.key_norm.scale"], Wn[pf + ".norm.query_norm.scale"])
         self._lin(pf + ".linear1.qkv", ws.XH, ws.QKV, epi=epi, s=s, **kv)
         if self.mlp_first:      # (the reference's textual order; the product runs the attention right behind its projection)
             self._lin(pf + ".linear1.mlp", ws.XH, ws.CAT[:, D:], epi=hip.EPI_GELU, s=s)

@@ -97,7 +97,7 @@ class FluxHandle:
         except Exception:
             pass
 
-    def set_options(self, attn_variant=None, tile_cfg=0, fuse_qnorm=True, fuse_vt=True, qkv_heads=None, fuse_knorm=False,
+    def set_options(self, attn_variant=None, tile_cfg=0, fuse_qnorm=2, fuse_vt=True, qkv_heads=None, fuse_knorm=False,
                     logit_bound=0.0, mlp_first=False, splitk=True) -> None:
         import math
         wq = int(getattr(self.W, "qkv_heads", 0) or 0)
@@ -107,7 +107,7 @@ class FluxHandle:
             raise hip.VclozeHipError(f"set_options(qkv_heads={qkv_heads}): the bound qkv weights are stored with qkv_heads={wq} "
                                      "(model.prepare / hip.qkv_head_permutation); the option follows the weights")
         want = dict(attn_variant=-1 if attn_variant is None else int(attn_variant), tile_cfg=int(tile_cfg),
-                    fuse_qnorm=int(bool(fuse_qnorm)), fuse_vt=int(bool(fuse_vt)), qkv_heads=int(qkv_heads),
+                    fuse_qnorm=int(fuse_qnorm), fuse_vt=int(bool(fuse_vt)), qkv_heads=int(qkv_heads),
                     fuse_knorm=int(bool(fuse_knorm)),
                     logit_bound_milli=int(math.ceil(logit_bound * 1000)) if 0 < logit_bound < 2e6 else 0,
                     mlp_first=int(bool(mlp_first)), splitk=int(bool(splitk)))

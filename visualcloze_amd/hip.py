@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VC_HIP_LIB") or os.path.join(_HERE, "lib", "libvcloze_hip.so")   # VC_HIP_LIB: profiling build
 CSRC = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 7                # VC_ABI_VERSION of include/vcloze_hip.h
+ABI_VERSION = 8                # VC_ABI_VERSION of include/vcloze_hip.h
 GEMM_MAX_PROBLEMS = 4          # VC_GEMM_MAX_PROBLEMS: grouped problems per vc_gemm launch
 EPI_BIAS, EPI_GELU, EPI_GATE_RES, EPI_SILU, EPI_QKV = 0, 1, 2, 3, 4
 GEMM_NO_SPLIT = 64             # VC_GEMM_NO_SPLIT: tile_cfg value that keeps an auto-tiled vc_gemm one launch
@@ -45,7 +45,8 @@ class GemmProblem(C.Structure):
         ("tiles_m", C.c_int32), ("tiles_n", C.c_int32), ("tile_start", C.c_int32), ("m_begin", C.c_int32),
         ("vt", C.c_void_p), ("vt_bstride", C.c_int64),
         ("vt_col0", C.c_int32), ("vt_rpb", C.c_int32), ("vt_row0", C.c_int32), ("vt_lpad", C.c_int32),
-        ("kn_scale", C.c_void_p), ("kn_rope", C.c_void_p), ("kn_rope_bstride", C.c_int64), ("kn_heads", C.c_int32), ("kn_pad_", C.c_int32),
+        ("kn_scale", C.c_void_p), ("kn_rope", C.c_void_p), ("kn_rope_bstride", C.c_int64), ("kn_heads", C.c_int32), ("qn_prescale", C.c_int32),
+        ("qn_scale", C.c_void_p),
         ("a_zstride", C.c_int64), ("w_zstride", C.c_int64), ("c_zstride", C.c_int64),
     ]
 
@@ -72,7 +73,7 @@ class Attention(C.Structure):
                 ("B", C.c_int32), ("L", C.c_int32), ("Lpad", C.c_int32), ("H", C.c_int32), ("variant", C.c_int32), ("split", C.c_int32),
                 ("scratch", C.c_void_p), ("scratch_bytes", C.c_int64),
                 ("q_scale", C.c_void_p), ("q_scale2", C.c_void_p), ("rope", C.c_void_p), ("rope_bstride", C.c_int64),
-                ("kv_gap", C.c_void_p), ("logit_bound", C.c_float), ("pad_", C.c_int32)]
+                ("kv_gap", C.c_void_p), ("logit_bound", C.c_float), ("q_prescaled", C.c_int32)]
 
 
 class FluxConfig(C.Structure):
@@ -229,19 +230,19 @@ def _bf16(t: torch.Tensor, name: str) -> None:
 # op wrappers (2-D row-major views; the last dim must be contiguous)
 # ------------------------------------------------------------------------------------------------
 def qkv_head_permutation(H: int) -> torch.Tensor:
-    """Row order of a HEAD-PERMUTED qkv weight [3 * 128 * H, K] (VcGemmProblem.kn_heads): H blocks of [key head h (128 rows) |
-    query rows 64 h .. 64 h + 63], then query rows 64 H .. 128 H - 1, then the V rows.  perm[p] = the original row."""
+    """Row order of a HEAD-PERMUTED qkv weight [3 * 128 * H, K] (VcGemmProblem.kn_heads): 2H blocks of 192 rows = [head t (128
+    rows: query head t for t < H, key head t - H after) | V rows 64 t .. 64 t + 63] - every 192-column GEMM tile then holds one
+    whole query or key head (QKNorm + RoPE in its epilogue) and half a value head.  perm[p] = the original row."""
     D = 128 * H
     idx = []
-    for h in range(H):
-        idx += list(range(D + 128 * h, D + 128 * h + 128)) + list(range(64 * h, 64 * h + 64))
-    idx += list(range(64 * H, D)) + list(range(2 * D, 3 * D))
+    for t in range(2 * H):
+        idx += list(range(128 * t, 128 * t + 128)) + list(range(2 * D + 64 * t, 2 * D + 64 * t + 64))
     return torch.tensor(idx, dtype=torch.long)
 
 
 def make_problem(a, w, bias, out, res=None, gate=None, rows_per_batch=None, gate_bstride=0, M=None,
                  a_rpb=0, a_bstride=0, c_rpb=0, c_bstride=0, vt=None, vt_col0=0, vt_rpb=0, vt_row0=0,
-                 kn_heads=0, kn_scale=None, kn_rope=None) -> GemmProblem:
+                 kn_heads=0, kn_scale=None, kn_rope=None, qn_scale=None, qn_prescale=False) -> GemmProblem:
     """`M` + (a_rpb, a_bstride) / (c_rpb, c_bstride) describe batch-strided rows: `a` / `out` are then views of the
     FIRST batch element's rows (row m of the problem lives at (m // rpb) * bstride + (m % rpb) * ld).
     EPI_QKV: `vt` [B, H, 128, Lpad] receives the columns >= vt_col0 transposed; this problem's rows are tokens
@@ -281,13 +282,18 @@ def make_problem(a, w, bias, out, res=None, gate=None, rows_per_batch=None, gate
         p.kn_heads = kn_heads        # w / bias are head-permuted (qkv_head_permutation); C receives the logical columns
         if vt is None:
             p.vt_rpb, p.vt_row0 = vt_rpb or M, vt_row0
-        if kn_scale is not None:     # ... and QKNorm + RoPE of the key heads happen in the epilogue
-            _bf16(kn_scale, "kn_scale")
+        if kn_scale is not None or qn_scale is not None:     # ... and QKNorm + RoPE of the key / query heads happen in the epilogue
             if kn_rope is None or kn_rope.dtype != torch.float32 or not kn_rope.is_contiguous():
                 raise VclozeHipError("gemm kn_rope: contiguous f32 [B?, L, 64, 2] expected")
-            p.kn_scale, p.kn_rope = kn_scale.data_ptr(), kn_rope.data_ptr()
+            p.kn_rope = kn_rope.data_ptr()
             p.kn_rope_bstride = kn_rope.shape[-3] * 128 if kn_rope.dim() == 4 else 0
-    p._keep = (a, w, bias, out, res, gate, vt, kn_scale, kn_rope)   # the struct carries raw pointers: keep the operands alive with it
+            if kn_scale is not None:
+                _bf16(kn_scale, "kn_scale")
+                p.kn_scale = kn_scale.data_ptr()
+            if qn_scale is not None:     # qn_prescale: the queries leave times 128^-0.5 * log2(e) (attention(q_prescaled=True))
+                _bf16(qn_scale, "qn_scale")
+                p.qn_scale, p.qn_prescale = qn_scale.data_ptr(), int(bool(qn_prescale))
+    p._keep = (a, w, bias, out, res, gate, vt, kn_scale, kn_rope, qn_scale)   # the struct carries raw pointers: keep the operands alive with it
     return p
 
 
@@ -350,7 +356,7 @@ def ln_modulate2(streams, step_ptr=None, mod_step_stride=0, stream=None, mod_bst
                                  _p(step_ptr), mod_step_stride, stream if stream is not None else cur_stream()), "vc_ln_modulate2")
 
 
-QKN_Q, QKN_K, QKN_VT = 1, 2, 4
+QKN_Q, QKN_K, QKN_VT, QKN_QPRE = 1, 2, 4, 8
 
 
 def qknorm_rope_vt(qkv, q_scale, k_scale, rope, vt, L, H, stream=None, q_scale2=None, k_scale2=None, split=0, B=1,
@@ -381,11 +387,12 @@ def attention_scratch(device) -> torch.Tensor:
 
 
 def attention(qkv, vt, out, L, H, kv_len=None, variant=0, stream=None, B=1, scratch=None, q_norm=None, kv_gap=None,
-              logit_bound=0.0):
+              logit_bound=0.0, q_prescaled=False):
     """out: [B*L, >=H*128] rows (B L (H D)), sample-major like qkv; kv_len: optional int32 device tensor [B];
     scratch: uint8 device buffer of >= vc_attention_scratch_bytes() for the tail split (taken from attention_scratch()
     when omitted); q_norm = (q_scale, q_scale2 | None, split, rope): QKNorm + RoPE of the RAW query rows inside the kernel
-    (variants 8 / 12; the pre-pass then runs with parts = QKN_K | QKN_VT)."""
+    (variants 8 / 12; the pre-pass then runs with parts = QKN_K | QKN_VT); q_prescaled: the q columns hold normalised, rotated
+    queries times 128^-0.5 * log2(e) (make_problem(qn_prescale=True) / QKN_QPRE; variants 8 / 12)."""
     _bf16(qkv, "qkv"); _bf16(vt, "vt"); _bf16(out, "out")
     if scratch is None and variant & 4:
         scratch = attention_scratch(qkv.device)
@@ -396,6 +403,7 @@ def attention(qkv, vt, out, L, H, kv_len=None, variant=0, stream=None, B=1, scra
     a.kv_gap = _p(kv_gap)      # int32 [B, 2] device tensor: (lo, hi) of a second masked range (needs kv_len)
     a.B, a.L, a.Lpad, a.H, a.variant = B, L, vt.shape[-1], H, variant
     a.scratch, a.scratch_bytes = _p(scratch), scratch.numel() if scratch is not None else 0
+    a.q_prescaled = int(bool(q_prescaled))
     a.logit_bound = float(logit_bound)   # > 0: |q.k| * 128^-0.5 * log2(e) <= logit_bound guaranteed (variants 8 / 12: no running max)
     if q_norm is not None:
         qs, qs2, split, rope = q_norm

@@ -450,7 +450,7 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
-def timed_region(job, steps, warmup, barrier=None, max_over_ranks=None):
+def timed_region(job, steps, warmup, barrier=None, max_over_ranks=None, board=None):
     """The contract's timing: W untimed steps, barrier + synchronize, EXACTLY K steps, barrier + synchronize, max over
     ranks.  The timed region opens on a sample boundary, so the per-sample precompute of a new grid (txt_in, the vec
     path, all 29 x 1.06 M modulation rows in one GEMM, the RoPE table: `precompute_ms`) is inside it."""
@@ -460,11 +460,15 @@ def timed_region(job, steps, warmup, barrier=None, max_over_ranks=None):
         job.step()
     job.restart_sample()                            # the next step() starts a new grid
     barrier()
+    if board is not None:
+        board.__enter__()                           # a sampler thread reads the board's power / clock nodes while the K steps run
     t0 = time.perf_counter()
     for _ in range(steps):
         job.step()
     barrier()                                       # synchronize + barrier + synchronize
     elapsed = time.perf_counter() - t0
+    if board is not None:
+        board.__exit__(None, None, None)
     return (max_over_ranks or par.max_over_ranks)(elapsed)
 
 
@@ -496,13 +500,10 @@ def self_launch(a, argv):
     """`python bench.py --gpus N` started BARE (no WORLD_SIZE in the environment): re-run this command as N ranks under
     torch.distributed.run on this node - the launch line the task statement gives - and hand its exit code back.  Rank 0 of
     the child job prints the one JSON line on the inherited stdout."""
-    import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
+    # --standalone: torchrun picks (and holds) its own rendezvous port - no probe socket closed before the bind (advisor r04)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--local-addr", "127.0.0.1", os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))   # dmabuf IPC for RCCL
     return subprocess.call(cmd, env=env)
 
@@ -542,6 +543,8 @@ def main(argv=None):
         N = sum((h // 2) * (w // 2) for h, w in wl["row_latents"])
         rec = result_record(a, wl, world, elapsed, 512, N, bcast_s=0.0, weight_bytes=0)
         rec["data"] = "stub engine (driver test, no GPU)"
+        rec["stub"] = True                          # NOT a measurement: the timings are time.sleep (advisor r04)
+        rec["metric"] = "stub-driver-test"
         if rank == 0:
             print(json.dumps(rec), flush=True)
         par.barrier()
@@ -573,8 +576,10 @@ def main(argv=None):
     x, kw = make_inputs(dev, wl, seed=par.sample_seed(0, rank * PB), B=PB)   # seed from the global sample index
     job = Job(model, x, kw, wl["steps"], t0=wl.get("t0", 0.0), do_shift=wl.get("do_shift", True))
 
+    from visualcloze_amd.board import BoardSampler, pci_bus_id_of
+    board = BoardSampler(pci_bus_id_of(local), index=local)       # this rank's GPU: socket power, power cap, shader clock (sysfs hwmon)
     with torch.cuda.stream(eng.stream):
-        elapsed = timed_region(job, a.steps, a.warmup, max_over_ranks=lambda s: par.max_over_ranks(s, dev))
+        elapsed = timed_region(job, a.steps, a.warmup, max_over_ranks=lambda s: par.max_over_ranks(s, dev), board=board)
     with torch.cuda.stream(eng.stream):
         final = job.state().float()
     torch.cuda.synchronize()
@@ -586,6 +591,7 @@ def main(argv=None):
     rec["hbm_resident_gb"] = round(torch.cuda.memory_allocated(dev) / 1e9, 1)        # merged weights + workspaces while sampling
     rec["hbm_peak_gb"] = round(torch.cuda.max_memory_allocated(dev) / 1e9, 1)        # during the one-time LoRA merge
     if rank == 0:
+        rec["board"] = board.summary()              # sampled DURING the timed steps: did this box sit at its power cap?
         rec["precompute_ms"] = round(job.precompute_ms(), 3)
         rec["roofline"] = roofline_gemm(job)
         profiled = any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB"))

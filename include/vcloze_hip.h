@@ -182,8 +182,10 @@ int vc_qknorm_rope_vt(void* qkv, int64_t ld, int64_t bstride, const void* q_scal
  * bit-identical results.  8 = ONE WAVE PER SIMD, 4 waves x 64 queries, software-pipelined inside the wave
  * (attention64.hip), persistent; q * 128^-0.5 log2(e) is rounded to bf16 when the queries are loaded.
  * +4 (7, 12) = TAIL SPLIT: the items beyond the last full round of resident workgroups are cut along the keys into one
- * equal chunk per workgroup; partial (O, m, l) go to `scratch` (>= vc_attention_scratch_bytes(), device memory,
- * contents undefined afterwards) and are merged behind them.  Same softmax, different f32
+ * equal chunk per workgroup; partial (O, m, l) go to `scratch` (>= vc_attention_scratch_bytes(), device memory) and the
+ * workgroup that finishes an item's LAST piece combines them in a fixed order (variant 12; variant 7: a second kernel).  The
+ * first 4096 bytes of `scratch` are arrival counters: ZERO them once before the first call; every call leaves them zero, the
+ * rest undefined.  One scratch serves one stream at a time.  Same softmax, different f32
  * summation order for those rows.  The launcher drops the split when scratch is NULL / too small, kv_len is given, or
  * it would not shorten the critical path.  12 is the default of the host engine.
  * q_scale != NULL (variants 8, 12 only): the q columns of qkv hold the RAW projection output and QKNorm + RoPE

@@ -629,3 +629,10 @@ def test_race_screen_repeated_launches_are_bit_identical():
             hip.attention(qkv, vt, o1, L2, H, variant=variant)
         torch.cuda.synchronize()
         assert torch.equal(o0, o1), f"attention variant {variant} not deterministic"
+        if variant == 12:      # tail pieces combined by each item's LAST ARRIVER: whoever that is, the same bits - and every launch
+            # leaves the arrival counters (the head of the scratch) at zero for the next one
+            assert int(hip.attention_scratch(DEV)[:4096].to(torch.int32).sum().item()) == 0
+            o8 = torch.empty_like(o0)
+            hip.attention(qkv, vt, o8, L2, H, variant=8)                # the same kernel, no item cut: f32 summation order only
+            torch.cuda.synchronize()
+            assert rel_l2(o0, o8) < 4e-3 and not torch.equal(o0, o8)

@@ -293,3 +293,31 @@ def test_compat_install_aliases_the_reference_import_names(tmp_path):
             "try:\n    c.install()\nexcept RuntimeError as e:\n    print('refused:', e)")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert "refused:" in r.stdout and "already imported" in r.stdout, r.stdout + r.stderr
+
+
+def test_board_sampler_reads_hwmon_nodes(tmp_path):
+    """visualcloze_amd.board: power / cap / shader clock of the card with the requested PCI address, sampled by a thread while
+    a `with` block runs (bench.py: the timed steps); a machine without the nodes reports "unavailable" instead of failing."""
+    import time
+    from visualcloze_amd.board import BoardSampler, find_hwmon
+    root = tmp_path / "drm"
+    for i, (pci, uw, hz) in enumerate((("0000:05:00.0", 250_000_000, 2_400_000_000), ("0000:c1:00.0", 1_398_000_000, 1_812_000_000))):
+        dev = tmp_path / "devices" / pci
+        hw = dev / "hwmon" / f"hwmon{i + 3}"
+        hw.mkdir(parents=True)
+        (hw / ("power1_average" if i == 0 else "power1_input")).write_text(f"{uw}\n")
+        (hw / "power1_cap").write_text("1400000000\n")
+        (hw / "freq1_input").write_text(f"{hz}\n")
+        card = root / f"card{i}"
+        card.mkdir(parents=True)
+        (card / "device").symlink_to(dev, target_is_directory=True)
+        (root / f"card{i}-DP-1").mkdir()
+    assert find_hwmon("0000:C1:00.0", root=str(root))["pci"] == "0000:c1:00.0"
+    assert find_hwmon(None, index=0, root=str(root))["pci"] == "0000:05:00.0"
+    with BoardSampler("0000:c1:00.0", hz=200.0, root=str(root)) as b:
+        time.sleep(0.05)
+    r = b.summary()
+    assert r["power_w_avg"] == 1398.0 and r["power_cap_w"] == 1400.0 and r["sclk_mhz_avg"] == 1812.0 and r["samples"] >= 3
+    with BoardSampler(None, root=str(tmp_path / "nothing")) as b:
+        pass
+    assert b.summary()["source"] == "unavailable"

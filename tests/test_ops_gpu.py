@@ -256,7 +256,7 @@ def test_gemm_head_permuted_qkv_and_norms_in_the_epilogue(hip, cfg, geom):
     # the prescaled queries are the plain ones times 128^-0.5 * log2(e), rounded once
     a, b_ = prepass(hip.QKN_Q | hip.QKN_QPRE)[:, :D].float(), prepass(hip.QKN_Q)[:, :D].float()
     c = 128 ** -0.5 * 1.4426950408889634
-    assert (a - b_ * c).abs().max().item() <= 2 ** -8 * (b_.abs().max().item() * c) + 1e-12
+    assert (a - b_ * c).abs().max().item() <= 2 ** -7 * (b_.abs().max().item() * c) + 1e-12      # (b_ itself is a rounded value)
     with pytest.raises(hip.VclozeHipError):
         hip.qknorm_rope_vt(plain.clone(), qs_t, ks_t, rope, vt0.clone(), L, H, B=B, parts=hip.QKN_K | hip.QKN_QPRE)
 

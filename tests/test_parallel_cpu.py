@@ -157,8 +157,8 @@ def test_bench_driver_world8_gloo_stub_engine(tmp_path):
 
 def test_bench_bare_gpus_flag_launches_its_own_ranks():
     """`python bench.py --gpus 2` WITHOUT WORLD_SIZE in the environment (the form the round-end driver used for --gpus 1) must not
-    exit with an error: bench.main re-runs itself under `torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr
-    127.0.0.1`, both ranks rendezvous (gloo, stub engine: no GPU here), rank 0 prints the one JSON line of the contract."""
+    exit with an error: bench.main re-runs itself under `torch.distributed.run --standalone --nnodes=1 --nproc-per-node 2
+    --local-addr 127.0.0.1`, both ranks rendezvous (gloo, stub engine: no GPU here), rank 0 prints the one JSON line of the contract."""
     import json
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["OMP_NUM_THREADS"] = "1"
@@ -169,6 +169,7 @@ def test_bench_bare_gpus_flag_launches_its_own_ranks():
     assert len(lines) == 1, r.stdout + r.stderr                      # ONE line, from rank 0 of the child job
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["steps"] == 5 and rec["config"]["parallelism"] == "dp2"
+    assert rec["stub"] is True and rec["metric"] == "stub-driver-test"      # a --stub-engine line can never be scraped as a measurement
     assert rec["value"] <= 2 * 5 / (5 * 0.004) * 1.01                # whole-job steps over the SLOWEST rank's time (rank 1: 4 ms / step)
     # a WORLD_SIZE that contradicts --gpus is still an error, not a silent single-rank run
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--stub-engine"], env=dict(env, WORLD_SIZE="1"),

@@ -382,7 +382,8 @@ def attention_scratch(device) -> torch.Tensor:
     serialise their use of it."""
     key = str(device)
     if key not in _attn_scratch:
-        _attn_scratch[key] = torch.empty(lib().vc_attention_scratch_bytes(), dtype=torch.uint8, device=device)
+        # zeroed: the first 4096 bytes are the tail split's arrival counters, which every launch leaves at zero again
+        _attn_scratch[key] = torch.zeros(lib().vc_attention_scratch_bytes(), dtype=torch.uint8, device=device)
     return _attn_scratch[key]
 
 

@@ -61,21 +61,27 @@ def grid_img_ids(rows, h=None, w=None):
     return torch.cat(out, 0)
 
 
-def build_model(dev, rank, world, lora_rank=256):
+def build_model(dev, rank, world, lora_rank=256, params=None):
+    """Random-init FLUX.1-Fill-dev + LoRA on `dev`.  The module is constructed on the META device and materialised with
+    to_empty(): no rank runs nn.Linear's default initialisation of 13 B parameters only to overwrite it - rank 0 fills every
+    parameter once (seeded), the other ranks receive them through the one-time broadcast."""
     from visualcloze_amd.model import FLUX_DEV_FILL, FluxLoraWrapper, FluxParams
     old = torch.get_default_dtype()
     torch.set_default_dtype(torch.bfloat16)
     try:
-        with torch.device(dev):
-            model = FluxLoraWrapper(lora_rank=lora_rank, lora_scale=1.0, params=FluxParams(**FLUX_DEV_FILL))
+        with torch.device("meta"):
+            model = FluxLoraWrapper(lora_rank=lora_rank, lora_scale=1.0, params=FluxParams(**(params or FLUX_DEV_FILL)))
     finally:
         torch.set_default_dtype(old)
+    assert not list(model.buffers()), "to_empty() would leave buffers uninitialised"
+    model.to_empty(device=dev)
     model.eval()
     g = torch.Generator(device=dev).manual_seed(1234)
     with torch.no_grad():
         for name, p in model.named_parameters():
             if rank != 0:
-                continue                      # filled by the broadcast below
+                p.zero_()                     # (defined contents; overwritten by the broadcast below)
+                continue
             if name.endswith("norm.scale"):
                 p.fill_(1.0)
             elif name.endswith(".bias"):
@@ -88,7 +94,7 @@ def build_model(dev, rank, world, lora_rank=256):
     return model, bcast_s
 
 
-def make_inputs(dev, wl, seed, B=1):
+def make_inputs(dev, wl, seed, B=1, ctx_dim=4096, vec_dim=768):
     ids = grid_img_ids(wl["row_latents"])
     N = ids.shape[0]
     g = torch.Generator(device="cpu").manual_seed(seed)
@@ -98,9 +104,9 @@ def make_inputs(dev, wl, seed, B=1):
     last = (wl["row_latents"][-1][0] // 2) * (wl["row_latents"][-1][1] // 2)
     mask[N - last + last * 2 // 3:] = 1                               # last cell(s) of the last row masked
     cond[..., 64:] = mask[None, :, None]
-    kw = dict(txt=torch.randn(B, 512, 4096, generator=g).to(dev, torch.bfloat16), txt_ids=torch.zeros(B, 512, 3, device=dev),
+    kw = dict(txt=torch.randn(B, 512, ctx_dim, generator=g).to(dev, torch.bfloat16), txt_ids=torch.zeros(B, 512, 3, device=dev),
               txt_mask=torch.ones(B, 512, dtype=torch.int32, device=dev),
-              y=torch.randn(B, 768, generator=g).to(dev, torch.bfloat16), img_ids=ids[None].repeat(B, 1, 1).to(dev),
+              y=torch.randn(B, vec_dim, generator=g).to(dev, torch.bfloat16), img_ids=ids[None].repeat(B, 1, 1).to(dev),
               img_mask=torch.ones(B, N, dtype=torch.int32, device=dev), cond=cond.to(dev, torch.bfloat16),
               guidance=torch.full((B,), 30.0, device=dev, dtype=torch.bfloat16))
     return x.to(dev, torch.bfloat16), kw
@@ -437,6 +443,11 @@ def parse_args(argv=None):
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.traffic = committed file)")
     ap.add_argument("--traffic-probe", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--stub-engine", action="store_true", help=argparse.SUPPRESS)   # tests: the driver over gloo without a GPU
+    # tests (tests/test_parallel_gpu.py): the REAL engine in a world of two on ONE GPU - RCCL refuses two ranks on one device,
+    # so the ranks rendezvous over gloo, share --device-index, and run the tiny model (the record is marked, never a measurement)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help=argparse.SUPPRESS)
+    ap.add_argument("--device-index", type=int, default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--test-tiny", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--tile-cfg", type=int, default=None)
     ap.add_argument("--attn-variant", type=int, default=None)
     ap.add_argument("--no-fuse-vt", action="store_true", help="A/B: V^T by the pre-pass kernel instead of the qkv GEMM's epilogue")
@@ -553,14 +564,20 @@ def main(argv=None):
         return
     from visualcloze_amd import hip
     hip.require_gpu()                       # fails loudly: there is no CPU path to fall back to
+    if a.device_index is not None:
+        local = a.device_index              # (tests: every rank on the same GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     from visualcloze_amd import parallel as par
     numa = par.pin_to_gpu_numa(local) if world > 1 else None     # one rank per GPU, each on its GPU's socket
-    par.init_distributed("nccl", dev)
+    par.init_distributed(a.backend, dev)
     assert par.world() == world
     wl = WORKLOADS[a.workload]
-    model, bcast_s = build_model(dev, rank, world)
+    tiny = None
+    if a.test_tiny:
+        tiny = dict(in_channels=384, out_channels=64, vec_in_dim=64, context_in_dim=128, hidden_size=256, mlp_ratio=4.0, num_heads=2,
+                    depth=2, depth_single_blocks=2, axes_dim=[16, 56, 56], theta=10_000, qkv_bias=True, guidance_embed=True)
+    model, bcast_s = build_model(dev, rank, world, lora_rank=8 if tiny else 256, params=tiny)
     weight_bytes = sum(p.numel() * p.element_size() for p in model.parameters())
     eng = model.prepare(free_parameters=True)   # sampling-only process: keep the 23.8 GB of merged weights, drop the rest
     if a.tile_cfg is not None:
@@ -573,7 +590,8 @@ def main(argv=None):
         eng.fuse_knorm = False
     eng.splitk = not a.no_splitk
     PB = a.per_gpu_batch
-    x, kw = make_inputs(dev, wl, seed=par.sample_seed(0, rank * PB), B=PB)   # seed from the global sample index
+    x, kw = make_inputs(dev, wl, seed=par.sample_seed(0, rank * PB), B=PB,   # seed from the global sample index
+                        **(dict(ctx_dim=tiny["context_in_dim"], vec_dim=tiny["vec_in_dim"]) if tiny else {}))
     job = Job(model, x, kw, wl["steps"], t0=wl.get("t0", 0.0), do_shift=wl.get("do_shift", True))
 
     from visualcloze_amd.board import BoardSampler, pci_bus_id_of
@@ -590,7 +608,12 @@ def main(argv=None):
     rec["numa_node"] = numa
     rec["hbm_resident_gb"] = round(torch.cuda.memory_allocated(dev) / 1e9, 1)        # merged weights + workspaces while sampling
     rec["hbm_peak_gb"] = round(torch.cuda.max_memory_allocated(dev) / 1e9, 1)        # during the one-time LoRA merge
-    if rank == 0:
+    if tiny:
+        rec.update(stub=True, metric="stub-driver-test", data="tiny test model (2+2 blocks, hidden 256): driver test, not a measurement",
+                   final_latent_sum=float(final.double().sum()))
+        if rank == 0:
+            print(json.dumps(rec), flush=True)
+    elif rank == 0:
         rec["board"] = board.summary()              # sampled DURING the timed steps: did this box sit at its power cap?
         rec["precompute_ms"] = round(job.precompute_ms(), 3)
         rec["roofline"] = roofline_gemm(job)

@@ -42,6 +42,7 @@
 // Audit after every change (Makefile target `audit64`): no spills, no scratch, no compiler-generated v_accvgpr_*.
 #include <algorithm>
 #include <type_traits>
+#include <vector>
 #include "common.h"
 #include "vcloze_internal.h"
 
@@ -58,6 +59,7 @@ struct Attn64Args {
   int32_t full_rounds, tail_items, tail_units;   // full_rounds >= 0: tail split on (the schedule itself is derived per XCD, see Sched64)
   float* part;
   int32_t* arrived;     // tail split: one arrival counter per (XCD, tail item), zero between launches (see merge_item64)
+  int32_t l2_local;     // blocks b and b + 8k were OBSERVED on one XCD (xcc_probe_kernel): an item's pieces meet in ONE L2
   // optional in-kernel QKNorm + RoPE of the query rows (q_scale != nullptr): as vc_qknorm_rope_vt
   const bf16_t* q_scale; const bf16_t* q_scale2; const float* rope; int64_t rope_bstride; int32_t split;
   int32_t q_pre;        // the q columns hold normalised, rotated queries times 128^-0.5 * log2(e) (VcAttention.q_prescaled)
@@ -744,15 +746,23 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
       // LAST ARRIVER COMBINES: every piece of the item is in L2 once its workgroup's release + arrival count is through; the
       // workgroup that brings the count to the number of pieces merges them (all pieces of an item live in this XCD) and
       // leaves the counter at zero for the next launch.  No workgroup ever waits for another.
+      // Visibility: all pieces of an item are written and read by workgroups of ONE XCD (tail split per XCD), whose CUs share
+      // one L2 and write through their L1s - so a piece is visible to the combiner once its stores are acknowledged
+      // (vmcnt(0)) before the arrival count, and the combiner drops its L1 before it reads.  That holds where blocks b and
+      // b + 8k share an XCD, which the launcher OBSERVES per device (xcc_probe_kernel); elsewhere (l2_local == 0) the same
+      // protocol runs on agent-scope fences - correct on any placement, and 20 % slower per launch (an L2 write-back per piece:
+      // profiles/r05b_ab_cfg2.log).
       const int xcd = blockIdx.x & 7, it_tail = id - id_tail;
       int32_t* cnt = a.arrived + xcd * (G >> 3) + it_tail;
-      __threadfence();
+      if (a.l2_local) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else __threadfence();
       __syncthreads();
-      if (tid == 0) *(volatile int*)smem = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) *(volatile int*)smem = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __syncthreads();
       const int before = __builtin_amdgcn_readfirstlane(*(volatile int*)smem);
       if (before + 1 == merge_item64(a, G, xcd, it_tail, 0, tid, true)) {
-        __threadfence();
+        if (a.l2_local) asm volatile("buffer_inv sc0" ::: "memory");
+        else __threadfence();
 #pragma nounroll
         for (int qbm = 0; qbm < 2; ++qbm) merge_item64(a, G, xcd, it_tail, qbm, tid, false);      // (one copy of the code)
         if (tid == 0) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -788,6 +798,32 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
 
 }  // namespace
 
+// Where do the blocks of a grid run?  out[b] = XCC_ID of block b.  The tail combine may rely on one L2 per (blockIdx & 7) only
+// where that is what the device does (MI300X / MI355X in SPX mode dispatch workgroups round-robin over the 8 XCDs).
+__global__ void xcc_probe_kernel(int32_t* out) {
+  if (threadIdx.x == 0) out[blockIdx.x] = (int32_t)__builtin_amdgcn_s_getreg(20 | (31 << 11));      // HW_REG_XCC_ID
+}
+static int g_l2_local[VC_MAX_DEVICES];      // 0 = not probed yet, 1 = blocks b, b + 8k share an XCD, -1 = they do not
+static int probe_l2_local(int n_cu) {
+  const int d = vc_device_index();
+  if (g_l2_local[d] != 0) return g_l2_local[d];
+  const int nb = 8 * n_cu;
+  int32_t* dev = nullptr;
+  std::vector<int32_t> host(nb, -1);
+  int verdict = -1;
+  if (hipMalloc((void**)&dev, nb * sizeof(int32_t)) == hipSuccess) {
+    hipLaunchKernelGGL(xcc_probe_kernel, dim3(nb), dim3(64), 0, nullptr, dev);
+    if (hipMemcpy(host.data(), dev, nb * sizeof(int32_t), hipMemcpyDeviceToHost) == hipSuccess) {
+      verdict = 1;
+      for (int b = 8; b < nb; ++b)
+        if (host[b] != host[b & 7]) { verdict = -1; break; }
+    }
+    (void)hipFree(dev);
+  }
+  (void)hipGetLastError();
+  return g_l2_local[d] = verdict;
+}
+
 // the arrival counters [8 XCDs][n_cu / 8 tail items] (VC_ATTN_SCRATCH_HEAD bytes: zero before the first launch, left zero by
 // every launch), then the pieces [n_cu][2]
 int64_t vc_attention64_scratch_bytes_impl(int n_cu) { return (int64_t)n_cu * 2 * PART64_BYTES + VC_ATTN_SCRATCH_HEAD; }
@@ -805,6 +841,7 @@ int vc_attention64_launch(const VcAttention& A, bool tail_split, int n_cu, uint6
   a.q_scale = (const bf16_t*)A.q_scale; a.q_scale2 = (const bf16_t*)(A.q_scale2 ? A.q_scale2 : A.q_scale);
   a.rope = A.rope; a.rope_bstride = A.rope_bstride; a.split = A.q_scale2 ? A.split : L;
   a.q_pre = A.q_prescaled != 0;
+  a.l2_local = 0;
   a.qblocks = (L + QB - 1) / QB;
   a.items = a.qblocks * H * B;
   a.full_rounds = -1; a.tail_items = 0; a.tail_units = 0;
@@ -837,6 +874,14 @@ int vc_attention64_launch(const VcAttention& A, bool tail_split, int n_cu, uint6
   if (tail_split && !kv_len && any_tail && scratch && scratch_bytes >= vc_attention64_scratch_bytes_impl(n_cu) && G * 4 <= VC_ATTN_SCRATCH_HEAD &&
       worst_split + 4 < nkt) {
     a.full_rounds = a.items / G; a.tail_items = a.items - a.full_rounds * G; a.tail_units = a.tail_items * nkt;
+    // the placement probe allocates and synchronises: never under stream capture (the step graph's warm-up evaluation runs first,
+    // uncaptured; a capture that comes first runs on the agent-scope fences)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (g_l2_local[vc_device_index()] != 0 || (hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone))
+      a.l2_local = probe_l2_local(n_cu) > 0;
+#ifdef VC_ATTN_AGENT_FENCES      /* A/B builds */
+    a.l2_local = 0;
+#endif
     hipLaunchKernelGGL(kern, dim3(G), dim3(256), LDS64, s, a);      // (the pieces are merged inside: last arriver combines)
   } else {
     hipLaunchKernelGGL(kern, dim3(std::min(a.items, G)), dim3(256), LDS64, s, a);

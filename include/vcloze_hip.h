@@ -106,8 +106,13 @@ typedef struct VcGemmArgs {
   int64_t splitk_ws_bytes;
   int32_t sk_full, sk_rem, sk_S;
   int32_t batch;            /* 0 / 1: one GEMM per problem; Z > 1: see VcGemmProblem.a_zstride (VC_EPI_BIAS, the 128x128 tile) */
+  /* ABI 8, filled by the launcher: > 0 = the STREAM form of the remainder - where it is more than half a round of tiles (no
+   * S >= 2 fits), sk_stream work items (one per CU) share the remainder's K-iterations evenly, tile-major: item p owns
+   * iterations [p I / n, (p + 1) I / n) of I = sk_rem * K / 64, i.e. at most two segments (end of one tile, start of the next)
+   * with one f32 partial tile each (slot 2 p + segment); the reduce launch sums a tile's pieces in K order.  Static: bit-reproducible. */
+  int32_t sk_stream, sk_pad_;
 } VcGemmArgs;
-#define VC_GEMM_SPLITK_WS_BYTES (256LL * 256 * 192 * 4)   /* one 256x192 f32 tile per work item of one round of 256 CUs */
+#define VC_GEMM_SPLITK_WS_BYTES (2LL * 256 * 256 * 192 * 4)   /* two 256x192 f32 partial tiles per work item of one round of 256 CUs */
 
 /* Replaces torch.nn.functional.linear (+ fused neighbours) on the hot path.
  * tile_cfg: 0 = chosen by the launcher's cost model (what the product path passes); a fixed tile for tests and A/B runs:
@@ -124,6 +129,9 @@ typedef struct VcGemmArgs {
 #define VC_GEMM_NO_SPLIT 64
 #define VC_GEMM_SPLITK(S) ((S) << 16)
 #define VC_GEMM_NO_SPLITK (1 << 20)
+#define VC_GEMM_STREAMK (1 << 21)   /* tests / A-B: force the 256x192 loader-wave tile with the remainder tiles in the STREAM form */
+#define VC_GEMM_PREFER_STREAMK (1 << 22)  /* A-B: an auto-tiled call takes the stream form wherever it is eligible, whatever the cost model says */
+#define VC_GEMM_STREAMK_ANY_K (1 << 23)   /* A-B: ... also below the K the launcher offers it from */
 /* VC_GEMM_PERSIST (128) added to tile_cfg: a launch with more tiles than CUs on a loader-wave tile runs as ONE persistent
  * workgroup per CU that walks the tiles of its XCD's strip and fetches the next tile's first operands during the current
  * tile's epilogue (same results bit for bit; not for VC_EPI_GATE_RES).  Opt-in: measured neutral on MI355X (+0.05 % steps/s;
@@ -133,7 +141,8 @@ int vc_gemm(const VcGemmArgs* args, int tile_cfg, void* stream);
 /* The plan vc_gemm would execute for these arguments, without launching anything (works without a GPU): out[0] = first row
  * of the second launch (0 = a single launch), out[1], out[2] = tile number (1..5 as above) and main-loop form (0 plain,
  * 1 ping-pong, 2 loader waves) of the first or only launch, out[3], out[4] = of the second, out[5] = tiles of both,
- * out[6] = split-K factor S of the remainder tiles (0 = none), out[7] = how many tiles are split. */
+ * out[6] = split-K factor S of the remainder tiles (0 = none; -n = the stream form with n work items), out[7] = how many tiles
+ * are split. */
 int vc_gemm_plan(const VcGemmArgs* args, int tile_cfg, int32_t out[8]);
 
 /* LayerNorm(eps=1e-6, no affine) + AdaLN modulate: y = bf16((1+scale)*LN(x) + shift).
@@ -182,10 +191,8 @@ int vc_qknorm_rope_vt(void* qkv, int64_t ld, int64_t bstride, const void* q_scal
  * bit-identical results.  8 = ONE WAVE PER SIMD, 4 waves x 64 queries, software-pipelined inside the wave
  * (attention64.hip), persistent; q * 128^-0.5 log2(e) is rounded to bf16 when the queries are loaded.
  * +4 (7, 12) = TAIL SPLIT: the items beyond the last full round of resident workgroups are cut along the keys into one
- * equal chunk per workgroup; partial (O, m, l) go to `scratch` (>= vc_attention_scratch_bytes(), device memory) and the
- * workgroup that finishes an item's LAST piece combines them in a fixed order (variant 12; variant 7: a second kernel).  The
- * first 4096 bytes of `scratch` are arrival counters: ZERO them once before the first call; every call leaves them zero, the
- * rest undefined.  One scratch serves one stream at a time.  Same softmax, different f32
+ * equal chunk per workgroup; partial (O, m, l) go to `scratch` (>= vc_attention_scratch_bytes(), device memory,
+ * contents undefined afterwards) and a second kernel on the same stream merges them.  One scratch serves one stream at a time.  Same softmax, different f32
  * summation order for those rows.  The launcher drops the split when scratch is NULL / too small, kv_len is given, or
  * it would not shorten the critical path.  12 is the default of the host engine.
  * q_scale != NULL (variants 8, 12 only): the q columns of qkv hold the RAW projection output and QKNorm + RoPE

@@ -629,9 +629,7 @@ def test_race_screen_repeated_launches_are_bit_identical():
             hip.attention(qkv, vt, o1, L2, H, variant=variant)
         torch.cuda.synchronize()
         assert torch.equal(o0, o1), f"attention variant {variant} not deterministic"
-        if variant == 12:      # tail pieces combined by each item's LAST ARRIVER: whoever that is, the same bits - and every launch
-            # leaves the arrival counters (the head of the scratch) at zero for the next one
-            assert int(hip.attention_scratch(DEV)[:4096].to(torch.int32).sum().item()) == 0
+        if variant == 12:      # tail items cut along the keys and merged: the same function as the uncut kernel
             o8 = torch.empty_like(o0)
             hip.attention(qkv, vt, o8, L2, H, variant=8)                # the same kernel, no item cut: f32 summation order only
             torch.cuda.synchronize()

@@ -30,7 +30,7 @@ def test_abi_exports_every_declared_symbol():
 def test_struct_layout_matches_header():
     from visualcloze_amd import hip
     assert ctypes.sizeof(hip.GemmProblem) == 10 * 8 + 12 * 8 + 16 * 4     # 10 pointers (ABI 8: + qn_scale), 12 int64 (incl. the batch strides), 16 int32 (incl. the V^T and QK-norm fields)
-    assert ctypes.sizeof(hip.GemmArgs) == 4 * ctypes.sizeof(hip.GemmProblem) + 8 + 8 + 8 + 8 + 8 + 8 + 4 * 4   # + splitk_ws, its size, sk_*, batch (ABI 7)
+    assert ctypes.sizeof(hip.GemmArgs) == 4 * ctypes.sizeof(hip.GemmProblem) + 8 + 8 + 8 + 8 + 8 + 8 + 6 * 4   # + splitk_ws, its size, sk_*, batch (ABI 7), sk_stream + pad (ABI 8)
     assert ctypes.sizeof(hip.FluxConfig) == 14 * 4
     assert ctypes.sizeof(hip.FluxInputs) == 4 * 4 + 7 * 8 + 2 * 4
     # the library reports the same sizes (and hip.lib() refuses to load one that does not)

@@ -411,6 +411,94 @@ def test_gemm_splitk_taken_by_the_cost_model_at_product_shapes(hip, M, K):
     assert d.max().item() <= 2 ** -5 * outs[2].float().abs().max().item()
 
 
+@pytest.mark.parametrize("epi", [0, 1, 2, 3])
+@pytest.mark.parametrize("shape", [(777, 1024, 2048), (300, 264, 4096), (2100, 3072, 768), (1, 192, 256), (4352, 3136, 1600)])
+def test_gemm_stream_form_of_the_splitk_remainder(hip, epi, shape):
+    """VC_GEMM_STREAMK: the remainder tiles' K-iterations dealt out evenly to work items (two segments where a range crosses a
+    tile edge, partial tiles summed in K order by the reduce launch) - every epilogue, partial tiles in M and N, items of ~12
+    iterations that cross tile edges (3-4 pieces per tile; K = 4096: 6-7, beyond the reducer's four-at-once path), items that are
+    whole tiles (K = 768, 256), more tiles than one round (4352 x 3136: 17 x 17 = 289 tiles = 256 whole + 33 streamed), against
+    torch, twice bit for bit, and within rounding of the one-pass kernel."""
+    M, N, K = shape
+    a = rnd(M, K + 64, seed=1)[:, :K]
+    w, bias = rnd(N, K, scale=K ** -0.5, seed=2), rnd(N, seed=3)
+    gate = rnd(N, seed=5)
+    x0 = rnd(M, N, seed=4)
+    ws = hip.splitk_workspace(DEV)
+    outs = []
+    for cfg in (hip.GEMM_STREAMK, hip.GEMM_STREAMK, 36):
+        out = x0.clone() if epi == 2 else torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        p = hip.make_problem(a, w, bias, out, res=out if epi == 2 else None, gate=gate if epi == 2 else None)
+        hip.gemm(p, epi=epi, tile_cfg=cfg, splitk_ws=ws)
+        torch.cuda.synchronize()
+        outs.append(out)
+    check(outs[0], R.gemm_ref(a, w, bias, epi, x0, gate))
+    assert torch.equal(outs[0], outs[1])                      # static assignment, fixed summation order
+    d = (outs[0].float() - outs[2].float()).abs()
+    assert d.max().item() <= 2 ** -5 * outs[2].float().abs().max().item()     # vs the one-pass kernel: rounding flips only
+    if M * N > 10000:
+        assert (d > 0).float().mean().item() < 0.1
+
+
+def test_gemm_stream_form_grouped_batch_strided_with_step_counter(hip):
+    """The stream form of a GROUPED launch as the DoubleStream blocks issue it (two streams of two samples, batch-strided A rows,
+    per-sample gates picked by a device step counter, residual in place): a work item's two segments may belong to DIFFERENT
+    problems.  And what it refuses: a scratch that is too small, problems of unequal K."""
+    B, Nn, T, D, NO = 2, 520, 136, 768, 192
+    L = Nn + T
+    joint = rnd(B * L, NO + 64, seed=1)[:, :NO]
+    ld = joint.stride(0)
+    w2, b2 = rnd(D, NO, scale=NO ** -0.5, seed=7), rnd(D, seed=8)
+    gates = rnd(3, B, D, seed=9)
+    step = torch.tensor([2], dtype=torch.int32, device=DEV)
+    ws = hip.splitk_workspace(DEV)
+    res = {}
+    for tag, cfg in (("sk", hip.GEMM_STREAMK), ("one", 36)):
+        oi, ot = rnd(B * Nn, D, seed=10), rnd(B * T, D, seed=11)
+        oi0, ot0 = oi.clone(), ot.clone()
+        ps = [hip.make_problem(joint[T:], w2, b2, oi, res=oi, gate=gates[0], rows_per_batch=Nn, gate_bstride=D, M=B * Nn, a_rpb=Nn, a_bstride=L * ld),
+              hip.make_problem(joint[:T], w2, b2, ot, res=ot, gate=gates[0], rows_per_batch=T, gate_bstride=D, M=B * T, a_rpb=T, a_bstride=L * ld)]
+        hip.gemm(ps, epi=hip.EPI_GATE_RES, tile_cfg=cfg, step_ptr=step, gate_step_stride=B * D, splitk_ws=ws)
+        torch.cuda.synchronize()
+        res[tag] = (oi, ot)
+    for b in range(B):
+        check(res["sk"][0][b * Nn:(b + 1) * Nn], R.gemm_ref(joint[b * L + T:(b + 1) * L], w2, b2, 2, oi0[b * Nn:(b + 1) * Nn], gates[2, b]))
+        check(res["sk"][1][b * T:(b + 1) * T], R.gemm_ref(joint[b * L:b * L + T], w2, b2, 2, ot0[b * T:(b + 1) * T], gates[2, b]))
+    for k in range(2):
+        d = (res["sk"][k].float() - res["one"][k].float()).abs().max().item()
+        assert d <= 2 ** -5 * res["one"][k].float().abs().max().item()
+    small = torch.empty(1 << 20, dtype=torch.uint8, device=DEV)
+    with pytest.raises(hip.VclozeHipError, match="splitk_ws"):
+        hip.gemm(hip.make_problem(joint[:T], w2, b2, rnd(T, D)), tile_cfg=hip.GEMM_STREAMK, splitk_ws=small)
+    with pytest.raises(hip.VclozeHipError, match="one K"):
+        hip.gemm([hip.make_problem(rnd(300, 128), rnd(192, 128), None, rnd(300, 192)), hip.make_problem(rnd(300, 256), rnd(192, 256), None, rnd(300, 192))],
+                 tile_cfg=hip.GEMM_STREAMK, splitk_ws=ws)
+
+
+@pytest.mark.parametrize("M,K", [(6656, 15360), (7424, 12288), (6656, 3072)])
+def test_gemm_stream_form_at_product_shapes(hip, M, K):
+    """cfg 3 / cfg 5's N = 3072 launches (416 = 256 + 160 tiles, 464 = 256 + 208): the remainder as 256 stream items of 0.625 /
+    0.8125 tile each (VC_GEMM_PREFER_STREAMK: the auto plan with the stream form wherever it is eligible; at K = 3072 only with
+    VC_GEMM_STREAMK_ANY_K), gate + residual in place: against torch, twice bit for bit, within rounding of the launcher's own plan."""
+    N = 3072
+    a, w, bias = rnd(M, K, seed=1), rnd(N, K, scale=K ** -0.5, seed=2), rnd(N, seed=3)
+    gate, x0 = rnd(N, seed=5), rnd(M, N, seed=4)
+    ws = hip.splitk_workspace(DEV)
+    flag = hip.GEMM_PREFER_STREAMK | (hip.GEMM_STREAMK_ANY_K if K < 6144 else 0)
+    args = hip.GemmArgs()
+    outs = []
+    for cfg in (flag, flag, hip.GEMM_NO_SPLITK):
+        out = x0.clone()
+        hip.gemm(hip.make_problem(a, w, bias, out, res=out, gate=gate), epi=2, tile_cfg=cfg, splitk_ws=ws)
+        torch.cuda.synchronize()
+        outs.append(out)
+    check(outs[0], R.gemm_ref(a, w, bias, 2, x0, gate))
+    assert torch.equal(outs[0], outs[1])
+    assert not torch.equal(outs[0], outs[2])              # the stream form WAS taken (other summation order -> a few 1-ulp flips)
+    d = (outs[0].float() - outs[2].float()).abs()
+    assert d.max().item() <= 2 ** -5 * outs[2].float().abs().max().item()
+
+
 @pytest.mark.parametrize("L,H,dh", [(512, 64, 64), (128, 12, 64), (77 + 51, 3, 128), (40, 2, 64)])
 def test_gemm_batched_instances_per_head_products(hip, L, H, dh):
     """VcGemmArgs.batch = H: the per-head S_h = Q_h K_h^T and O_h = S_h V_h products of the T5 / CLIP attention (head_dim 64:

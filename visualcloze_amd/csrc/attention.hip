@@ -387,7 +387,7 @@ extern "C" void vc_debug_set_attn_ts(void* p) { g_attn_debug_ts = (uint64_t*)p; 
 static int attn_cu_count() { return vc_cu_count(); }
 
 int64_t vc_attention_scratch_bytes_impl() {
-  return std::max((int64_t)2 * attn_cu_count() * 2 * PART_FLOATS * (int64_t)sizeof(float) + VC_ATTN_SCRATCH_HEAD, vc_attention64_scratch_bytes_impl(attn_cu_count()));
+  return std::max((int64_t)2 * attn_cu_count() * 2 * PART_FLOATS * (int64_t)sizeof(float), vc_attention64_scratch_bytes_impl(attn_cu_count()));
 }
 
 int vc_attention_launch(const VcAttention& A, hipStream_t s, char* err, int errlen) {
@@ -414,8 +414,7 @@ int vc_attention_launch(const VcAttention& A, hipStream_t s, char* err, int errl
   if (variant & 8)    // one wave per SIMD, 64 queries per wave (attention64.hip); +4 = tail split
     return vc_attention64_launch(A, (variant & 4) != 0, attn_cu_count(), g_attn_debug_ts, s, err, errlen);
   a.debug_ts = g_attn_debug_ts;
-  a.full_rounds = -1; a.tail_items = 0; a.tail_units = 0;
-  a.part = scratch ? (float*)((char*)scratch + VC_ATTN_SCRATCH_HEAD) : nullptr;      // (the head belongs to variant 12's arrival counters)
+  a.full_rounds = -1; a.tail_items = 0; a.tail_units = 0; a.part = (float*)scratch;
   const int lds = 2 * STAGE;
   hipError_t e;
   const bool persist = (variant & 2) != 0;   // +2: persistent grid with static item assignment (variants 2, 3)

@@ -42,7 +42,6 @@
 // Audit after every change (Makefile target `audit64`): no spills, no scratch, no compiler-generated v_accvgpr_*.
 #include <algorithm>
 #include <type_traits>
-#include <vector>
 #include "common.h"
 #include "vcloze_internal.h"
 
@@ -58,8 +57,6 @@ struct Attn64Args {
   int32_t B, L, Lpad, H, qblocks, items;
   int32_t full_rounds, tail_items, tail_units;   // full_rounds >= 0: tail split on (the schedule itself is derived per XCD, see Sched64)
   float* part;
-  int32_t* arrived;     // tail split: one arrival counter per (XCD, tail item), zero between launches (see merge_item64)
-  int32_t l2_local;     // blocks b and b + 8k were OBSERVED on one XCD (xcc_probe_kernel): an item's pieces meet in ONE L2
   // optional in-kernel QKNorm + RoPE of the query rows (q_scale != nullptr): as vc_qknorm_rope_vt
   const bf16_t* q_scale; const bf16_t* q_scale2; const float* rope; int64_t rope_bstride; int32_t split;
   int32_t q_pre;        // the q columns hold normalised, rotated queries times 128^-0.5 * log2(e) (VcAttention.q_prescaled)
@@ -89,7 +86,7 @@ constexpr int A_O = 0, A_Q = 128, A_K = 192;        // AGPR map
 constexpr int PART64_O_BYTES = 4 * 2 * 16 * 64 * 8;
 constexpr int PART64_BYTES = PART64_O_BYTES + 4 * 2 * 64 * 8;
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-VC_DEV int chunk_begin64(int c, int units, int chunks) { return (int)(((uint32_t)c * (uint32_t)units) / (uint32_t)chunks); }   // (c <= chunks <= 128, units < 2^24)
+VC_DEV int chunk_begin64(int c, int units, int chunks) { return (int)(((long)c * units) / chunks); }
 
 // Work schedule of the persistent grid, PER XCD (grid % 8 == 0; block b runs on XCD b % 8 - observed placement, used for
 // speed only).  XCD x owns the contiguous logical items [start, start + n) that xcd_remap gives it: all query blocks of a
@@ -191,94 +188,6 @@ VC_DEV float xsum32(float x) {
   float lo, hi;
   half_swap(x, lo, hi);
   return lo + hi;
-}
-
-// Combines the pieces of ONE tail item: out = sum_p w_p (O_p / l_p) / sum_p w_p, w_p = l_p 2^(m_p - max m), for the query
-// block qb of every wave - run by the workgroup that finished the item's LAST piece (attn64_kernel), whose thread layout is the
-// writers'.  ONE pass over the pieces in chunk order (a fixed summation order: whoever arrives last, the bits are the same)
-// with a running maximum (the accumulator is rescaled when a piece raises it) and the next piece's loads issued before the
-// current one is folded in: a chain of L2 round trips, not bandwidth.  Returns the number of pieces through *n_pieces when
-// count_only (nothing is read or written then).
-VC_DEV int merge_item64(const Attn64Args& a, int G, int xcd, int it, int qb, int tid, bool count_only) {
-  const int nkt = (a.L + KVB - 1) / KVB;
-  const Sched64 sc = sched64(xcd, G, a.items, nkt);
-  const int u0 = it * nkt, u1 = u0 + nkt;
-  int c = (int)(((uint32_t)u0 * (uint32_t)sc.W) / (uint32_t)sc.units);
-  while (c > 0 && chunk_begin64(c, sc.units, sc.W) > u0) --c;
-  while (c + 1 < sc.W && chunk_begin64(c + 1, sc.units, sc.W) <= u0) ++c;
-  // chunk cc holds units of this item iff it is not empty (fewer units than blocks) and begins before u1
-  auto next_chunk = [&](int cc) {
-    while (cc < sc.W && chunk_begin64(cc, sc.units, sc.W) < u1 && chunk_begin64(cc + 1, sc.units, sc.W) == chunk_begin64(cc, sc.units, sc.W)) ++cc;
-    return (cc < sc.W && chunk_begin64(cc, sc.units, sc.W) < u1) ? cc : -1;
-  };
-  if (count_only) {
-    int n = 0;
-    for (int cc = next_chunk(c); cc >= 0; cc = next_chunk(cc + 1)) ++n;
-    return n;
-  }
-  const int lane = tid & 63, wave = tid >> 6;
-  const int lq = lane & 31, hh = lane >> 5;
-  const char* base = (const char*)a.part;
-  const long ml_off = PART64_O_BYTES + ((wave * 2 + qb) * 64 + lane) * 8;
-  const long o_off = ((long)(wave * 2 + qb) * 16 * 64 + lane) * 8;
-  auto piece_ptr = [&](int cc) {
-    const int piece = (cc * 8 + xcd) * 2 + (it - chunk_begin64(cc, sc.units, sc.W) / nkt);
-    return base + (long)piece * PART64_BYTES;
-  };
-  f16x4 v[16], vn[16];
-  f32x2 ml, mln = {0.f, 0.f};
-  int cc = next_chunk(c);
-  {
-    const char* pp = piece_ptr(cc);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = *(const f16x4*)(pp + o_off + i * 512);
-    ml = *(const f32x2*)(pp + ml_off);
-  }
-  float acc[16][4];
-#pragma unroll
-  for (int i = 0; i < 16; ++i)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) acc[i][e] = 0.f;
-  float wsum = 0.f, m = -INFINITY;
-  for (;;) {
-    const int nx = next_chunk(cc + 1);
-    if (nx >= 0) {
-      const char* pp = piece_ptr(nx);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) vn[i] = *(const f16x4*)(pp + o_off + i * 512);
-      mln = *(const f32x2*)(pp + ml_off);
-    }
-    const float m_new = fmaxf(m, ml[0]);
-    const float keep = __builtin_amdgcn_exp2f(m - m_new);          // 0 on the first piece (m = -inf), 1 while the maximum stands
-    const float w = ml[1] * __builtin_amdgcn_exp2f(ml[0] - m_new);
-    m = m_new;
-    wsum = wsum * keep + w;
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc[i][e] = acc[i][e] * keep + w * (float)v[i][e];
-    if (nx < 0) break;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = vn[i];
-    ml = mln;
-    cc = nx;
-  }
-  const int id = sc.start + sc.rounds * sc.W + it;
-  const int qb_i = id % a.qblocks, bh = id / a.qblocks;
-  const int h = bh % a.H, b = bh / a.H;
-  const int q = qb_i * QB + wave * QW + qb * 32 + lq;
-  if (q < a.L) {
-    const float inv = 1.0f / wsum;
-    bf16_t* orow = a.out + (long)b * a.out_bstride + (long)q * a.ldo + h * 128;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      u32x2 w;
-      w[0] = pack2bf(acc[i][0] * inv, acc[i][1] * inv);
-      w[1] = pack2bf(acc[i][2] * inv, acc[i][3] * inv);
-      *(u32x2*)(orow + (i >> 2) * 32 + (i & 3) * 8 + hh * 4) = w;
-    }
-  }
-  return 0;
 }
 
 template <bool BOUNDED>
@@ -728,7 +637,7 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
 
     // ---- epilogue ----
     asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");     // ring quiet, last P.V MFMAs retired
-    if (piece >= 0) {          // part of an item's keys only: (O / l, m, l) of this key range, merged by the item's last arriver
+    if (piece >= 0) {          // part of an item's keys only: (O / l, m, l) of this key range, merged by attn64_merge_kernel
       char* pp = (char*)a.part + (long)piece * PART64_BYTES;
       sfor<0, 2>([&](auto QBc) {
         constexpr int qb = decltype(QBc)::value;
@@ -743,31 +652,6 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
         const f32x2 ml = {m_run[qb], l_tot};
         *(f32x2*)(pp + PART64_O_BYTES + ((wave * 2 + qb) * 64 + lane) * 8) = ml;
       });
-      // LAST ARRIVER COMBINES: every piece of the item is in L2 once its workgroup's release + arrival count is through; the
-      // workgroup that brings the count to the number of pieces merges them (all pieces of an item live in this XCD) and
-      // leaves the counter at zero for the next launch.  No workgroup ever waits for another.
-      // Visibility: all pieces of an item are written and read by workgroups of ONE XCD (tail split per XCD), whose CUs share
-      // one L2 and write through their L1s - so a piece is visible to the combiner once its stores are acknowledged
-      // (vmcnt(0)) before the arrival count, and the combiner drops its L1 before it reads.  That holds where blocks b and
-      // b + 8k share an XCD, which the launcher OBSERVES per device (xcc_probe_kernel); elsewhere (l2_local == 0) the same
-      // protocol runs on agent-scope fences - correct on any placement, and 20 % slower per launch (an L2 write-back per piece:
-      // profiles/r05b_ab_cfg2.log).
-      const int xcd = blockIdx.x & 7, it_tail = id - id_tail;
-      int32_t* cnt = a.arrived + xcd * (G >> 3) + it_tail;
-      if (a.l2_local) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else __threadfence();
-      __syncthreads();
-      if (tid == 0) *(volatile int*)smem = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __syncthreads();
-      const int before = __builtin_amdgcn_readfirstlane(*(volatile int*)smem);
-      if (before + 1 == merge_item64(a, G, xcd, it_tail, 0, tid, true)) {
-        if (a.l2_local) asm volatile("buffer_inv sc0" ::: "memory");
-        else __threadfence();
-#pragma nounroll
-        for (int qbm = 0; qbm < 2; ++qbm) merge_item64(a, G, xcd, it_tail, qbm, tid, false);      // (one copy of the code)
-        if (tid == 0) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      __syncthreads();       // smem[0] is ring memory again from the next item's prologue on
     } else {
       sfor<0, 2>([&](auto QBc) {
         constexpr int qb = decltype(QBc)::value;
@@ -796,37 +680,93 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
 #endif
 }
 
+// Combines the pieces of the tail items: out = sum_p w_p (O_p / l_p) / sum_p w_p, w_p = l_p 2^(m_p - max m).  One
+// workgroup per (XCD, tail item of that XCD, query block of the wave) on the XCD that wrote the pieces (block b -> XCD
+// b % 8); thread layout = the writer's.  ONE pass over the pieces with a running maximum (the accumulator is rescaled when
+// a piece raises it) and the next piece's loads issued before the current one is folded in: the kernel is a chain of
+// L2 round trips, not bandwidth, and this keeps the chain at ~one trip (+ the store) whatever the number of pieces.
+__global__ __launch_bounds__(256) void attn64_merge_kernel(const Attn64Args a, int G) {
+  const int xcd = blockIdx.x & 7, it = blockIdx.x >> 4, qb = (blockIdx.x >> 3) & 1;
+  const int nkt = (a.L + KVB - 1) / KVB;
+  const Sched64 sc = sched64(xcd, G, a.items, nkt);
+  if (it >= sc.tail) return;
+  const int u0 = it * nkt, u1 = u0 + nkt;
+  int c = (int)(((long)u0 * sc.W) / sc.units);
+  while (c > 0 && chunk_begin64(c, sc.units, sc.W) > u0) --c;
+  while (c + 1 < sc.W && chunk_begin64(c + 1, sc.units, sc.W) <= u0) ++c;
+  if (chunk_begin64(c + 1, sc.units, sc.W) >= u1) return;        // the whole item ran inside one chunk: already written
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane & 31, hh = lane >> 5;
+  const char* base = (const char*)a.part;
+  const long ml_off = PART64_O_BYTES + ((wave * 2 + qb) * 64 + lane) * 8;
+  const long o_off = ((long)(wave * 2 + qb) * 16 * 64 + lane) * 8;
+  // chunk cc holds units of this item iff it is not empty (fewer units than blocks) and begins before u1
+  auto next_chunk = [&](int cc) {
+    while (cc < sc.W && chunk_begin64(cc, sc.units, sc.W) < u1 && chunk_begin64(cc + 1, sc.units, sc.W) == chunk_begin64(cc, sc.units, sc.W)) ++cc;
+    return (cc < sc.W && chunk_begin64(cc, sc.units, sc.W) < u1) ? cc : -1;
+  };
+  auto piece_ptr = [&](int cc) {
+    const int piece = (cc * 8 + xcd) * 2 + (it - chunk_begin64(cc, sc.units, sc.W) / nkt);
+    return base + (long)piece * PART64_BYTES;
+  };
+  f16x4 v[16], vn[16];
+  f32x2 ml, mln = {0.f, 0.f};
+  int cc = next_chunk(c);
+  {
+    const char* pp = piece_ptr(cc);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = *(const f16x4*)(pp + o_off + i * 512);
+    ml = *(const f32x2*)(pp + ml_off);
+  }
+  float acc[16][4];
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[i][e] = 0.f;
+  float wsum = 0.f, m = -INFINITY;
+  for (;;) {
+    const int nx = next_chunk(cc + 1);
+    if (nx >= 0) {
+      const char* pp = piece_ptr(nx);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) vn[i] = *(const f16x4*)(pp + o_off + i * 512);
+      mln = *(const f32x2*)(pp + ml_off);
+    }
+    const float m_new = fmaxf(m, ml[0]);
+    const float keep = __builtin_amdgcn_exp2f(m - m_new);          // 0 on the first piece (m = -inf), 1 while the maximum stands
+    const float w = ml[1] * __builtin_amdgcn_exp2f(ml[0] - m_new);
+    m = m_new;
+    wsum = wsum * keep + w;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][e] = acc[i][e] * keep + w * (float)v[i][e];
+    if (nx < 0) break;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = vn[i];
+    ml = mln;
+    cc = nx;
+  }
+  const int id = sc.start + sc.rounds * sc.W + it;
+  const int qb_i = id % a.qblocks, bh = id / a.qblocks;
+  const int h = bh % a.H, b = bh / a.H;
+  const int q = qb_i * QB + wave * QW + qb * 32 + lq;
+  if (q < a.L) {
+    const float inv = 1.0f / wsum;
+    bf16_t* orow = a.out + (long)b * a.out_bstride + (long)q * a.ldo + h * 128;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      u32x2 w;
+      w[0] = pack2bf(acc[i][0] * inv, acc[i][1] * inv);
+      w[1] = pack2bf(acc[i][2] * inv, acc[i][3] * inv);
+      *(u32x2*)(orow + (i >> 2) * 32 + (i & 3) * 8 + hh * 4) = w;
+    }
+  }
+}
+
 }  // namespace
 
-// Where do the blocks of a grid run?  out[b] = XCC_ID of block b.  The tail combine may rely on one L2 per (blockIdx & 7) only
-// where that is what the device does (MI300X / MI355X in SPX mode dispatch workgroups round-robin over the 8 XCDs).
-__global__ void xcc_probe_kernel(int32_t* out) {
-  if (threadIdx.x == 0) out[blockIdx.x] = (int32_t)__builtin_amdgcn_s_getreg(20 | (31 << 11));      // HW_REG_XCC_ID
-}
-static int g_l2_local[VC_MAX_DEVICES];      // 0 = not probed yet, 1 = blocks b, b + 8k share an XCD, -1 = they do not
-static int probe_l2_local(int n_cu) {
-  const int d = vc_device_index();
-  if (g_l2_local[d] != 0) return g_l2_local[d];
-  const int nb = 8 * n_cu;
-  int32_t* dev = nullptr;
-  std::vector<int32_t> host(nb, -1);
-  int verdict = -1;
-  if (hipMalloc((void**)&dev, nb * sizeof(int32_t)) == hipSuccess) {
-    hipLaunchKernelGGL(xcc_probe_kernel, dim3(nb), dim3(64), 0, nullptr, dev);
-    if (hipMemcpy(host.data(), dev, nb * sizeof(int32_t), hipMemcpyDeviceToHost) == hipSuccess) {
-      verdict = 1;
-      for (int b = 8; b < nb; ++b)
-        if (host[b] != host[b & 7]) { verdict = -1; break; }
-    }
-    (void)hipFree(dev);
-  }
-  (void)hipGetLastError();
-  return g_l2_local[d] = verdict;
-}
-
-// the arrival counters [8 XCDs][n_cu / 8 tail items] (VC_ATTN_SCRATCH_HEAD bytes: zero before the first launch, left zero by
-// every launch), then the pieces [n_cu][2]
-int64_t vc_attention64_scratch_bytes_impl(int n_cu) { return (int64_t)n_cu * 2 * PART64_BYTES + VC_ATTN_SCRATCH_HEAD; }
+int64_t vc_attention64_scratch_bytes_impl(int n_cu) { return (int64_t)n_cu * 2 * PART64_BYTES; }
 
 int vc_attention64_launch(const VcAttention& A, bool tail_split, int n_cu, uint64_t* debug_ts, hipStream_t s, char* err, int errlen) {
   Attn64Args a;
@@ -841,12 +781,9 @@ int vc_attention64_launch(const VcAttention& A, bool tail_split, int n_cu, uint6
   a.q_scale = (const bf16_t*)A.q_scale; a.q_scale2 = (const bf16_t*)(A.q_scale2 ? A.q_scale2 : A.q_scale);
   a.rope = A.rope; a.rope_bstride = A.rope_bstride; a.split = A.q_scale2 ? A.split : L;
   a.q_pre = A.q_prescaled != 0;
-  a.l2_local = 0;
   a.qblocks = (L + QB - 1) / QB;
   a.items = a.qblocks * H * B;
-  a.full_rounds = -1; a.tail_items = 0; a.tail_units = 0;
-  a.arrived = (int32_t*)scratch;
-  a.part = scratch ? (float*)((char*)scratch + VC_ATTN_SCRATCH_HEAD) : nullptr;
+  a.full_rounds = -1; a.tail_items = 0; a.tail_units = 0; a.part = (float*)scratch;
   static VcOncePerDevice done;
   hipError_t e;
   if (done.need()) {
@@ -871,18 +808,13 @@ int vc_attention64_launch(const VcAttention& A, bool tail_split, int n_cu, uint6
       any_tail |= tail;
       worst_split = std::max(worst_split, (int)(((long)tail * nkt + W - 1) / W));
     }
-  if (tail_split && !kv_len && any_tail && scratch && scratch_bytes >= vc_attention64_scratch_bytes_impl(n_cu) && G * 4 <= VC_ATTN_SCRATCH_HEAD &&
-      worst_split + 4 < nkt) {
+  if (tail_split && !kv_len && any_tail && scratch && scratch_bytes >= vc_attention64_scratch_bytes_impl(n_cu) && worst_split + 4 < nkt) {
     a.full_rounds = a.items / G; a.tail_items = a.items - a.full_rounds * G; a.tail_units = a.tail_items * nkt;
-    // the placement probe allocates and synchronises: never under stream capture (the step graph's warm-up evaluation runs first,
-    // uncaptured; a capture that comes first runs on the agent-scope fences)
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (g_l2_local[vc_device_index()] != 0 || (hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone))
-      a.l2_local = probe_l2_local(n_cu) > 0;
-#ifdef VC_ATTN_AGENT_FENCES      /* A/B builds */
-    a.l2_local = 0;
-#endif
-    hipLaunchKernelGGL(kern, dim3(G), dim3(256), LDS64, s, a);      // (the pieces are merged inside: last arriver combines)
+    hipLaunchKernelGGL(kern, dim3(G), dim3(256), LDS64, s, a);
+    // XCD x has (items / 8 [+ 1]) % (G / 8) tail items: 16 blocks (8 XCDs x 2 query blocks) per tail slot that any XCD fills
+    const int W = G >> 3, qn = a.items >> 3, rn = a.items & 7;
+    const int tail_slots = std::max(rn ? (qn + 1) % W : 0, qn % W);
+    hipLaunchKernelGGL(attn64_merge_kernel, dim3(16 * tail_slots), dim3(256), 0, s, a, G);
   } else {
     hipLaunchKernelGGL(kern, dim3(std::min(a.items, G)), dim3(256), LDS64, s, a);
   }

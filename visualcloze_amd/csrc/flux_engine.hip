@@ -663,7 +663,6 @@ int vc_flux_prepare_impl(void* handle, const VcFluxInputs* in, void* workspace, 
   TRY(stage_send(f, f.G32, g32, B * sizeof(float), s, e));
   TRY(stage_end(f, s, e));
   HIP(hipMemsetAsync(f.VT, 0, (size_t)B * f.H * 128 * f.Lp * 2, s), "hipMemsetAsync");
-  HIP(hipMemsetAsync(f.ATT_SCRATCH, 0, VC_ATTN_SCRATCH_HEAD, s), "hipMemsetAsync");      // the tail split's arrival counters (VcAttention.scratch)
   // step-invariant projections
   TRY(lin(f, f.txt_in, in->txt, f.cfg.context_in_dim, f.TXT0, D, B * T, VC_EPI_BIAS, s, e));
   if (f.cfg.guidance_embed) {

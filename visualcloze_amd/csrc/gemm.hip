@@ -27,6 +27,9 @@ constexpr int BK = 64;
 #ifndef VC_GEMM_GROUP_M
 #define VC_GEMM_GROUP_M 8
 #endif
+#ifndef VC_GEMM_STREAMK_MIN_K
+#define VC_GEMM_STREAMK_MIN_K 6144      /* the stream remainder is not offered below this K (the partial traffic outweighs the short tiles) */
+#endif
 
 // CONV (loader-wave schedule only): the A operand is the im2col matrix of a 3x3 convolution over an NHWC map, gathered
 // on the fly by the loader waves - K-tile kt lies inside tap kt*64 / C, row m is output pixel (m / W, m % W), out-of-
@@ -79,12 +82,26 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
   // p / sk_rem of tile sk_full + p % sk_rem (the items of one slice are neighbours: those that share an m-tile share their A
   // slab in one XCD's L2).  An item leaves its f32 accumulators in args.splitk_ws [tile][slice][BM][BN] instead of running an
   // epilogue; splitk_reduce_kernel finishes the tile.  Every other instantiation compiles exactly as without this.
+  // STREAM form (args.sk_stream = n work items, for remainders of MORE than half a round, where no uniform S >= 2 fits): the
+  // K-iterations of the sk_rem tiles, flattened tile-major, are dealt out evenly - item p owns iterations [p I / n, (p + 1) I / n)
+  // of I = sk_rem * (K / 64), at most two segments (the end of one tile, the start of the next; n >= sk_rem), each a pass of this
+  // loop with its own prologue, accumulators and partial tile (slot 2 p + segment).  Static assignment: bit-reproducible.
   int sk_slice = 0, sk_slot = -1;
+  int sk_it = 0, sk_it_end = 0, sk_seg = 0;          // stream form: next iteration / end of this item's range, segment index
+  bool sk_bias = true;                               // this pass starts its tile's K range: its accumulators start at the bias
   if constexpr (SPLITK) {
-    sk_slice = blockIdx.x / args.sk_rem;
-    const int r = blockIdx.x - sk_slice * args.sk_rem;
-    id_cur = args.sk_full + r;
-    sk_slot = r * args.sk_S + sk_slice;
+    if (args.sk_stream > 0) {
+      const uint32_t I = (uint32_t)args.sk_rem * (uint32_t)(args.p[0].K / BK), n = (uint32_t)args.sk_stream;
+      sk_it = (int)((uint64_t)blockIdx.x * I / n);
+      sk_it_end = (int)((uint64_t)(blockIdx.x + 1) * I / n);
+      if (sk_it >= sk_it_end) return;                // (more items than iterations: nothing to do, before any barrier)
+    } else {
+      sk_slice = blockIdx.x / args.sk_rem;
+      const int r = blockIdx.x - sk_slice * args.sk_rem;
+      id_cur = args.sk_full + r;
+      sk_slot = r * args.sk_S + sk_slice;
+      sk_bias = sk_slice == 0;
+    }
   }
   if constexpr (PERSIST) {
     const int total = args.p[args.nprob - 1].tile_start + args.p[args.nprob - 1].tiles_m * args.p[args.nprob - 1].tiles_n;
@@ -157,7 +174,18 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
     }
   };
 
-  for (bool first_tile = true;; first_tile = false) {      // (one pass unless PERSIST)
+  for (bool first_tile = true;; first_tile = false) {      // (one pass unless PERSIST, or a stream item with two segments)
+  int sk_k0 = 0, sk_k1 = 0;
+  if constexpr (SPLITK) {
+    if (args.sk_stream > 0) {
+      const int nk0 = args.p[0].K / BK, t = sk_it / nk0;
+      sk_k0 = sk_it - t * nk0;
+      sk_k1 = min(nk0, sk_it_end - t * nk0);
+      id_cur = args.sk_full + t;
+      sk_slot = blockIdx.x * 2 + sk_seg;
+      sk_bias = sk_k0 == 0;
+    }
+  }
   const Tile tile_cur = decode(id_cur);
   const VcGemmProblem& P = tile_cur.P;
   const int m0 = tile_cur.m0, n0 = tile_cur.n0;
@@ -167,8 +195,13 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
   // K-tiles [kt_lo, kt_lo + nk) of this work item (the whole K unless it is a split-K slice)
   int kt_lo = 0, nk = K / BK;
   if constexpr (SPLITK) {
-    kt_lo = (int)((long)nk * sk_slice / args.sk_S);
-    nk = (int)((long)nk * (sk_slice + 1) / args.sk_S) - kt_lo;
+    if (args.sk_stream > 0) {
+      kt_lo = sk_k0;
+      nk = sk_k1 - sk_k0;
+    } else {
+      kt_lo = (int)((long)nk * sk_slice / args.sk_S);
+      nk = (int)((long)nk * (sk_slice + 1) / args.sk_S) - kt_lo;
+    }
   }
   const bf16_t* __restrict__ Ab = (const bf16_t*)P.A + (long)kt_lo * BK;
   const bf16_t* __restrict__ Wb = (const bf16_t*)P.W + (long)kt_lo * BK;
@@ -372,7 +405,7 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
       if (grp == 1) __builtin_amdgcn_s_setprio(1);
       // the accumulators start at the bias (6 8-B loads per lane, hidden under the wait for the first K-tile): epilogue
       // pass 1 is then convert + LDS write only (it was VALU-bound on the bias unpack/add: 6.9 k cycles per block)
-      if (P.bias && (!SPLITK || sk_slice == 0)) {       // (a split-K tile: slice 0 carries the bias)
+      if (P.bias && (!SPLITK || sk_bias)) {             // (a split-K tile: the piece that starts its K range carries the bias)
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
           const int col = n0 + wn * TN + j * 16 + fq * 4;
@@ -864,6 +897,11 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
 #pragma unroll
           for (int j = 0; j < NI; ++j) *(f32x4*)(wsp + i * 16 * BN + j * 16) = acc[i][j];
       }
+      if (args.sk_stream > 0) {          // a second segment: the start of the next tile (every wave decides alike)
+        sk_it += nk;
+        ++sk_seg;
+        if (sk_it < sk_it_end) continue;
+      }
       break;
     }
   } else {
@@ -925,6 +963,41 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const VcGemmArgs arg
   if (m >= P.M || n >= P.N) return;
   const float* __restrict__ src = (const float*)args.splitk_ws + (long)r * args.sk_S * (BM * BN) + row * BN + ch * 8;
   f32x4 a0, a1;
+  if (args.sk_stream > 0) {
+    // stream form: the pieces of tile r are the segments of the work items whose iteration ranges meet [r nk, (r + 1) nk), summed
+    // in K order = ascending item (the first starts at K = 0 and carries the bias).  The piece list is scalar work; the first
+    // four pieces' loads are in flight together (a remainder of more than half a round has at most three per tile).
+    const uint32_t nk0 = (uint32_t)(args.p[0].K / BK), I = (uint32_t)args.sk_rem * nk0, n = (uint32_t)args.sk_stream;
+    const uint32_t u0 = (uint32_t)r * nk0, u1 = u0 + nk0;
+    auto it0 = [&](uint32_t q) { return (uint32_t)((uint64_t)q * I / n); };
+    uint32_t q = (uint32_t)((uint64_t)u0 * n / I);
+    while (q > 0 && it0(q) > u0) --q;
+    while (q + 1 < n && it0(q + 1) <= u0) ++q;
+    const float* __restrict__ base = (const float*)args.splitk_ws + row * BN + ch * 8;
+    const float* pc[4] = {nullptr, nullptr, nullptr, nullptr};
+    int np = 0;
+    uint32_t q_more = n;                // first item beyond the fourth piece (n = none)
+    for (; q < n && it0(q) < u1; ++q) {
+      const uint32_t b = it0(q);
+      if (b == it0(q + 1)) continue;
+      if (np == 4) { q_more = q; break; }
+      pc[np++] = base + (long)(q * 2 + (b / nk0 == (uint32_t)r ? 0 : 1)) * (BM * BN);
+    }
+    f32x4 lo[4], hi[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i < np) { lo[i] = *(const f32x4*)pc[i]; hi[i] = *(const f32x4*)(pc[i] + 4); }
+    a0 = lo[0]; a1 = hi[0];
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+      if (i < np) { a0 += lo[i]; a1 += hi[i]; }
+    for (q = q_more; q < n && it0(q) < u1; ++q) {       // (forced test geometries: many short items per tile)
+      const uint32_t b = it0(q);
+      if (b == it0(q + 1)) continue;
+      const float* pq = base + (long)(q * 2 + (b / nk0 == (uint32_t)r ? 0 : 1)) * (BM * BN);
+      a0 += *(const f32x4*)pq; a1 += *(const f32x4*)(pq + 4);
+    }
+  } else
   switch (args.sk_S) {        // (wave-uniform; each case is fully unrolled: all 2 S loads of a thread are in flight together)
     case 2: sum_slices<2, BM * BN>(src, a0, a1); break;
     case 3: sum_slices<3, BM * BN>(src, a0, a1); break;
@@ -991,7 +1064,7 @@ hipError_t launch_splitk_slices(const VcGemmArgs& a, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_done.mark();
   }
-  hipLaunchKernelGGL(fn, dim3(a.sk_rem * a.sk_S), dim3(NT), LDS, s, a);
+  hipLaunchKernelGGL(fn, dim3(a.sk_stream > 0 ? a.sk_stream : a.sk_rem * a.sk_S), dim3(NT), LDS, s, a);
   return hipGetLastError();
 }
 
@@ -1128,7 +1201,7 @@ TilePlan best_tile(const VcGemmArgs& a) {
   return best;
 }
 
-int launch_tiles(VcGemmArgs a, int tile_cfg, int pp, bool want_persist, hipStream_t s, char* err, int errlen, int splitk_S = 0) {
+int launch_tiles(VcGemmArgs a, int tile_cfg, int pp, bool want_persist, hipStream_t s, char* err, int errlen, int splitk_S = 0, int stream_items = 0) {
   if (tile_cfg < 1 || tile_cfg > 5 || pp > 2 || (pp == 1 && tile_cfg < 3) || (pp == 2 && tile_cfg != 4 && tile_cfg != 2)) { snprintf(err, errlen, "gemm: bad tile_cfg %d", tile_cfg); return VC_ERR_ARG; }
   const int bm = cfg_bm[tile_cfg], bn = cfg_bn[tile_cfg];
   int total = 0, np = 0;
@@ -1143,7 +1216,7 @@ int launch_tiles(VcGemmArgs a, int tile_cfg, int pp, bool want_persist, hipStrea
   }
   if (np == 0) return VC_OK;
   a.nprob = np;
-  a.sk_full = total; a.sk_rem = 0; a.sk_S = 1;
+  a.sk_full = total; a.sk_rem = 0; a.sk_S = 1; a.sk_stream = 0;
   if (a.batch > 1) {
     if (tile_cfg != 1 || pp != 0 || a.epi != VC_EPI_BIAS) { snprintf(err, errlen, "gemm: batch > 1 runs on the 128x128 tile with VC_EPI_BIAS"); return VC_ERR_ARG; }
     const hipError_t ez = launch_zbatch(a, total, s);
@@ -1161,6 +1234,20 @@ int launch_tiles(VcGemmArgs a, int tile_cfg, int pp, bool want_persist, hipStrea
       for (int i = 0; i < np; ++i)
         if (a.p[i].K / BK < splitk_S) { snprintf(err, errlen, "gemm: K=%d is too short for %d slices", a.p[i].K, splitk_S); return VC_ERR_ARG; }
       a.sk_full = full; a.sk_rem = rem; a.sk_S = splitk_S;
+    }
+  } else if (stream_items > 0) {      // ... or as stream_items work items over their flattened K-iterations (stream form)
+    const int n_cu = vc_cu_count();
+    const int full = total / n_cu * n_cu, rem = total - full;
+    if (tile_cfg != 4 || pp != 2 || a.epi == VC_EPI_QKV) { snprintf(err, errlen, "gemm: split-K runs on the 256x192 loader-wave tile, not with VC_EPI_QKV"); return VC_ERR_ARG; }
+    if (rem > 0) {
+      if (stream_items < rem || stream_items > 4096) { snprintf(err, errlen, "gemm: %d stream items for %d remainder tiles", stream_items, rem); return VC_ERR_ARG; }
+      if (!a.splitk_ws || a.splitk_ws_bytes < (int64_t)stream_items * 2 * bm * bn * 4) {
+        snprintf(err, errlen, "gemm: stream split-K with %d work items needs %lld bytes of splitk_ws (have %lld)", stream_items,
+                 (long long)stream_items * 2 * bm * bn * 4, (long long)(a.splitk_ws ? a.splitk_ws_bytes : 0)); return VC_ERR_ARG; }
+      for (int i = 1; i < np; ++i)
+        if (a.p[i].K != a.p[0].K) { snprintf(err, errlen, "gemm: stream split-K needs one K for all problems"); return VC_ERR_ARG; }
+      a.sk_full = full; a.sk_rem = rem; a.sk_stream = stream_items;
+      a.sk_S = 2;                     // (marks "remainder split" for the code below; the stream form reads sk_stream, not sk_S)
     }
   }
   // VC_GEMM_PERSIST + more tiles than CUs on the loader-wave schedule: one persistent workgroup per CU walks them
@@ -1241,11 +1328,12 @@ static int validate_gemm(VcGemmArgs& a, char* err, int errlen) {
 }
 
 // The launch plan of one vc_gemm call: cut = first row of the second launch (0 = one launch); tile / pp of the two launches.
-struct GemmPlan { int cut, tile1, pp1, tile2, pp2, sk_S = 0, sk_tiles = 0; };
+struct GemmPlan { int cut, tile1, pp1, tile2, pp2, sk_S = 0, sk_tiles = 0, sk_stream = 0; };
 static GemmPlan plan_gemm(const VcGemmArgs& a, int tile_cfg) {
   const int force_cut = (tile_cfg >> 8) & 255;         // tests: cut problem 0 at row force_cut * 256
   const int force_sk = (tile_cfg >> 16) & 15;          // tests / A-B: VC_GEMM_SPLITK(S)
   const bool no_split = (tile_cfg & VC_GEMM_NO_SPLIT) != 0, no_splitk = (tile_cfg & VC_GEMM_NO_SPLITK) != 0;
+  const int tile_cfg_flags = tile_cfg;
   tile_cfg &= 63;
   if (a.batch > 1) return GemmPlan{0, 1, 0, 0, 0};          // Z instances per problem: the 128x128 tile (grid (tiles, Z))
   const long n_cus = vc_cu_count();
@@ -1255,6 +1343,18 @@ static GemmPlan plan_gemm(const VcGemmArgs& a, int tile_cfg) {
     if (rem > 0) { pl.sk_S = S; pl.sk_tiles = (int)rem; }
     return pl;
   };
+  // stream form: n work items share the remainder's K-iterations evenly (each >= ~12 iterations, at most one per CU)
+  auto stream_plan = [&]() {
+    const long total = tiles_of(a, 4), rem = total % n_cus;
+    GemmPlan pl{0, 4, 2, 0, 0};
+    if (rem > 0) {
+      long n = rem * (a.p[0].K / BK) / 12;
+      n = n < rem ? rem : n > n_cus ? n_cus : n;
+      pl.sk_stream = (int)n; pl.sk_tiles = (int)rem;
+    }
+    return pl;
+  };
+  if (tile_cfg_flags & VC_GEMM_STREAMK) return stream_plan();
   if (force_sk >= 2) return sk_plan(force_sk > 8 ? 8 : force_sk);
   for (int i = 0; i < a.nprob; ++i)      // heads are normalised inside the epilogue: every head must lie in one 192-wide tile
     if (a.epi == VC_EPI_QKV && (a.p[i].kn_scale || a.p[i].qn_scale)) return GemmPlan{0, 4, tile_cfg != 0 && ((tile_cfg >> 4) & 3) != 2 ? (tile_cfg >> 4) & 3 : 2, 0, 0};
@@ -1282,6 +1382,23 @@ static GemmPlan plan_gemm(const VcGemmArgs& a, int tile_cfg) {
       const double area = (double)cfg_bm[4] * cfg_bn[4] / cand_eff[1];
       const double cost = R * area * (a.p[0].K + cand_ovh[1]) + area * ((double)a.p[0].K / S + cand_ovh[1] + 150.0) + (2.0 * bytes / 4e6 + 3.0) * 3.2e6;
       if (cost < 0.93 * whole.cost) { sk = sk_plan(S); sk_cost = cost; }
+    }
+  }
+  // STREAM REMAINDER: more than half a round of tiles beyond the whole rounds (no uniform S >= 2 fits one round): every CU takes
+  // rem / CUs of a tile's K-iterations, at most two segments, <= 3 partial tiles per remainder tile (cfg 3's N = 3072 launches:
+  // 416 tiles = 256 + 160 -> 0.625 tile per CU instead of a second round of 240 narrower tiles; cfg 5: 464 = 256 + 208).
+  // Priced like the uniform form: two prologues per item, (CUs + rem) partial tiles written and read once, one more launch boundary.
+  if (!no_splitk && sk.sk_S == 0 && a.splitk_ws && a.epi != VC_EPI_QKV) {
+    const long total = tiles_of(a, 4), R = total / n_cus, rem = total % n_cus;
+    bool same_k = true;
+    for (int i = 1; i < a.nprob; ++i) same_k = same_k && a.p[i].K == a.p[0].K;
+    const double bytes = (double)(n_cus + rem) * cfg_bm[4] * cfg_bn[4] * 4;
+    const bool prefer = (tile_cfg_flags & VC_GEMM_PREFER_STREAMK) != 0, any_k = (tile_cfg_flags & VC_GEMM_STREAMK_ANY_K) != 0;
+    if (R >= 1 && 2 * rem > n_cus && same_k && (a.p[0].K >= VC_GEMM_STREAMK_MIN_K || any_k) && (double)n_cus * 2 * cfg_bm[4] * cfg_bn[4] * 4 <= (double)a.splitk_ws_bytes) {
+      const double area = (double)cfg_bm[4] * cfg_bn[4] / cand_eff[1];
+      const double cost = R * area * (a.p[0].K + cand_ovh[1]) + area * ((double)rem / n_cus * a.p[0].K + 2 * (cand_ovh[1] + 150.0)) + (2.0 * bytes / 4e6 + 3.0) * 3.2e6;
+      if (prefer || any_k) return stream_plan();
+      if (cost < 0.93 * whole.cost) { sk = stream_plan(); sk_cost = cost; }
     }
   }
   // Block-round quantisation: cut problem 0's rows where the 256x192 tiles above the cut are (nearly) whole rounds of the 256
@@ -1317,7 +1434,7 @@ static GemmPlan plan_gemm(const VcGemmArgs& a, int tile_cfg) {
       if (t1 + rp.cost < best) { best = t1 + rp.cost; cut = rows; rest_plan = rp; best_cut = best; }
     }
   }
-  if (sk.sk_S > 1 && (cut == 0 || sk_cost <= best_cut)) return sk;
+  if ((sk.sk_S > 1 || sk.sk_stream > 0) && (cut == 0 || sk_cost <= best_cut)) return sk;
   if (cut == 0) return GemmPlan{0, whole.tile_cfg, whole.pp, 0, 0};
   return GemmPlan{cut, 4, 2, rest_plan.tile_cfg, rest_plan.pp};
 }
@@ -1329,7 +1446,7 @@ int vc_gemm_launch(VcGemmArgs a, int tile_cfg, hipStream_t s, char* err, int err
   if (rc != VC_OK) return rc;
   const GemmPlan pl = plan_gemm(a, tile_cfg);
   const bool want_persist = (tile_cfg & VC_GEMM_PERSIST) != 0;
-  if (pl.cut == 0) return launch_tiles(a, pl.tile1, pl.pp1, want_persist, s, err, errlen, pl.sk_S);
+  if (pl.cut == 0) return launch_tiles(a, pl.tile1, pl.pp1, want_persist, s, err, errlen, pl.sk_S, pl.sk_stream);
   VcGemmArgs first = a;
   first.nprob = 1;
   first.p[0].M = pl.cut;                                       // rows [0, cut) of problem 0 on the 256x192 loader-wave tile
@@ -1349,6 +1466,6 @@ int vc_gemm_plan_impl(VcGemmArgs a, int tile_cfg, int32_t out[8], char* err, int
   VcGemmArgs first = a, rest = a;
   if (pl.cut) { first.nprob = 1; first.p[0].M = pl.cut; rest.p[0].m_begin = pl.cut; }
   out[5] = (int32_t)(tiles_of(first, pl.tile1) + (pl.cut ? tiles_of(rest, pl.tile2) : 0));
-  out[6] = pl.sk_S; out[7] = pl.sk_tiles;
+  out[6] = pl.sk_stream > 0 ? -pl.sk_stream : pl.sk_S; out[7] = pl.sk_tiles;
   return VC_OK;
 }

@@ -32,7 +32,6 @@ int vc_attention_launch(const VcAttention& a, hipStream_t s, char* err, int errl
 int64_t vc_attention_scratch_bytes_impl();
 int vc_attention64_launch(const VcAttention& a, bool tail_split, int n_cu, uint64_t* debug_ts, hipStream_t s, char* err, int errlen);
 int64_t vc_attention64_scratch_bytes_impl(int n_cu);
-constexpr int VC_ATTN_SCRATCH_HEAD = 4096;   // first bytes of VcAttention.scratch: arrival counters of the tail split (see vcloze_hip.h)
 int vc_ln_modulate2_launch(const VcLnStream* a, const VcLnStream* b, int64_t mod_bstride, int32_t D, const int32_t* step_ptr,
                            int64_t mod_step_stride, hipStream_t s, char* err, int errlen);
 int vc_ln_modulate_launch(const void* x, int64_t ldx, void* y, int64_t ldy, const void* shift, const void* scale,

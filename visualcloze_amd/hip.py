@@ -22,7 +22,10 @@ EPI_BIAS, EPI_GELU, EPI_GATE_RES, EPI_SILU, EPI_QKV = 0, 1, 2, 3, 4
 GEMM_NO_SPLIT = 64             # VC_GEMM_NO_SPLIT: tile_cfg value that keeps an auto-tiled vc_gemm one launch
 GEMM_PERSIST = 128             # VC_GEMM_PERSIST: opt into the persistent tile loop of the loader-wave GEMM (multi-round launches)
 GEMM_NO_SPLITK = 1 << 20       # VC_GEMM_NO_SPLITK: an auto-tiled call keeps its remainder tiles whole even with a splitk_ws
-GEMM_SPLITK_WS_BYTES = 256 * 256 * 192 * 4     # VC_GEMM_SPLITK_WS_BYTES
+GEMM_STREAMK = 1 << 21         # VC_GEMM_STREAMK: force the stream form of the split-K remainder (tests, A/B runs)
+GEMM_PREFER_STREAMK = 1 << 22  # VC_GEMM_PREFER_STREAMK: auto-tiled calls take the stream form wherever eligible (A/B runs)
+GEMM_STREAMK_ANY_K = 1 << 23   # VC_GEMM_STREAMK_ANY_K: ... at any K
+GEMM_SPLITK_WS_BYTES = 2 * 256 * 256 * 192 * 4     # VC_GEMM_SPLITK_WS_BYTES
 
 
 def GEMM_SPLITK(S: int) -> int:
@@ -57,6 +60,7 @@ class GemmArgs(C.Structure):
         ("step_ptr", C.c_void_p), ("gate_step_stride", C.c_int64), ("debug_ts", C.c_void_p),
         ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64),
         ("sk_full", C.c_int32), ("sk_rem", C.c_int32), ("sk_S", C.c_int32), ("batch", C.c_int32),
+        ("sk_stream", C.c_int32), ("sk_pad_", C.c_int32),
     ]
 
 
@@ -298,7 +302,7 @@ def make_problem(a, w, bias, out, res=None, gate=None, rows_per_batch=None, gate
 
 
 def splitk_workspace(device) -> torch.Tensor:
-    """f32 scratch for the split-K remainder of vc_gemm (VcGemmArgs.splitk_ws): one 256x192 tile per CU of one round"""
+    """f32 scratch for the split-K remainder of vc_gemm (VcGemmArgs.splitk_ws): two 256x192 partial tiles per CU of one round"""
     return torch.empty(GEMM_SPLITK_WS_BYTES, dtype=torch.uint8, device=device)
 
 
@@ -382,8 +386,7 @@ def attention_scratch(device) -> torch.Tensor:
     serialise their use of it."""
     key = str(device)
     if key not in _attn_scratch:
-        # zeroed: the first 4096 bytes are the tail split's arrival counters, which every launch leaves at zero again
-        _attn_scratch[key] = torch.zeros(lib().vc_attention_scratch_bytes(), dtype=torch.uint8, device=device)
+        _attn_scratch[key] = torch.empty(lib().vc_attention_scratch_bytes(), dtype=torch.uint8, device=device)
     return _attn_scratch[key]
 
 

@@ -445,6 +445,42 @@ def test_full_width_trajectory_vs_oracle(procedural_small_model, case):
         assert e16 < 1.0 * floor and e32 < 1.5 * floor, (k, e16, e32, floor)
 
 
+def test_full_width_blocks_vs_the_reference_itself(procedural_small_model):
+    """The HIP blocks against the REFERENCE'S OWN outputs at FLUX width (tests/golden/fullwidth_reference.npz: the reference's
+    FluxLoraWrapper, 1 DoubleStreamBlock + 1 SingleStreamBlock at hidden 3072 / 24 heads / L = 3968, fp32 on the CPU - not the
+    oracle): `Flux.forward` whole, and the block outputs where the fixture samples them (engine taps).  Bounds as for the fp32
+    oracle: <= max(3e-2, 4 x the bf16 floor); measured ~9e-3 = the floor itself."""
+    import numpy as np
+    from tests.helpers import parity_log
+    FT = _traj_module()
+    fx = np.load(os.path.join(os.path.dirname(TRAJ_FIXTURE), "fullwidth_reference.npz"))
+    inp = FT.inputs("cfg2")
+    assert float(fx["x_sum"]) == inp["x"].double().sum().item()
+    m = procedural_small_model
+    t = torch.tensor(fx["t"])
+    got = _call(m, inp, t)
+    e = rel_l2(got, torch.tensor(fx["flux"]))
+    # the block outputs: the same evaluation through the Python-ordered plan with taps (bit-identical to the handle's)
+    eng = m.engine()
+    N = inp["x"].shape[1]
+    ws = eng.workspace(T, N, 1, 1)
+    kw = _kw(inp)
+    eng.prepare_sample(ws, kw["txt"], kw["y"], inp["guidance"].to(DEV), False, kw["img_ids"], kw["txt_ids"],
+                       t.to(DEV).float().reshape(1, 1), [ws.L])                      # (as model.forward's Python-ordered route)
+    ws.XIN.copy_(torch.cat((inp["x"], inp["cond"]), -1).to(DEV, torch.bfloat16).reshape(N, -1))
+    taps = {}
+    eng.eval_once(ws, None, euler=False, taps=taps, concat=False)
+    torch.cuda.synchronize()
+    assert torch.equal(ws.V.reshape(got.shape), got)
+    rs, cs = int(fx["row_stride"]), int(fx["col_stride"])
+    errs = {"double_img": rel_l2(taps["double.0.img"][::rs, ::cs], torch.tensor(fx["double_img"])),
+            "double_txt": rel_l2(taps["double.0.txt"][::rs, ::cs], torch.tensor(fx["double_txt"])),
+            "single": rel_l2(taps["single.0"][::rs, ::cs], torch.tensor(fx["single"]))}
+    parity_log(f"[1+1 blocks at full width, cfg2] HIP vs the REFERENCE's own fp32 run: Flux.forward {e:.3e}, DoubleStreamBlock img "
+               f"{errs['double_img']:.3e} / txt {errs['double_txt']:.3e}, SingleStreamBlock {errs['single']:.3e}")
+    assert e < 3e-2 and all(v < 3e-2 for v in errs.values()), (e, errs)
+
+
 TIMES_FIXTURE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fulldepth_times_oracle.npz")
 
 

@@ -235,6 +235,18 @@ def test_gemm_launch_plans_for_the_flux_shapes():
     assert plan([4608], 3072, 15360, 2, hip.GEMM_NO_SPLITK, sk=True, n=8)[:3] + plan([4608], 3072, 15360, 2, hip.GEMM_NO_SPLITK, sk=True, n=8)[6:] == [0, 2, 2, 0, 0]
     assert plan([4608], 3072, 15360, 2, n=8)[6:] == [0, 0]                                   # no scratch, no split
     assert plan([777], 1024, 512, 1, hip.GEMM_SPLITK(3), sk=True, n=8) == [0, 4, 2, 0, 0, 24, 3, 24]     # forced (tests)
+    # STREAM form of the remainder (more than half a round, where no uniform S fits): cfg 3's deep-K N = 3072 launches, 416 tiles =
+    # 256 + 160 whose K-iterations are dealt out to 256 work items (0.625 tile each) instead of the row cut; NOT cfg 5's (464 =
+    # 256 + 208: a second round at 81 % fill measures faster), not at K = 3072, not without a scratch; the 5x5 grid's (944 = 3 x 256
+    # + 176) takes it too
+    assert plan([6144, T], 3072, 12288, 2, sk=True, n=8) == [0, 4, 2, 0, 0, 416, -256, 160]
+    assert plan([6656], 3072, 15360, 2, sk=True, n=8) == [0, 4, 2, 0, 0, 416, -256, 160]
+    assert plan([6144, T], 3072, 3072, 2, sk=True, n=8) == [4096, 4, 2, 2, 2, 496, 0, 0]
+    assert plan([7424], 3072, 15360, 2, sk=True, n=8) == [0, 4, 2, 0, 0, 464, 0, 0]
+    assert plan([7424], 3072, 15360, 2, hip.GEMM_PREFER_STREAMK, sk=True, n=8) == [0, 4, 2, 0, 0, 464, -256, 208]
+    assert plan([14912], 3072, 15360, 2, sk=True, n=8) == [0, 4, 2, 0, 0, 944, -256, 176]
+    assert plan([6656], 3072, 15360, 2, hip.GEMM_NO_SPLITK, sk=True, n=8) == [4096, 4, 2, 2, 2, 496, 0, 0]
+    assert plan([300], 264, 4096, 1, hip.GEMM_STREAMK, sk=True, n=8) == [0, 4, 2, 0, 0, 4, -21, 4]       # forced (tests): ~12 iterations per item
     # argument errors come back as codes, with a message
     a = hip.GemmArgs(); a.nprob = 1; a.p[0].M, a.p[0].N, a.p[0].K = 8, 8, 60
     assert L.vc_gemm_plan(C.byref(a), 0, (C.c_int32 * 8)()) == -1 and b"multiple of 64" in L.vc_last_error()

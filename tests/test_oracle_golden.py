@@ -200,3 +200,40 @@ def test_f32_state_sampler_keeps_the_state_in_f32(golden, tiny_sd):
     assert not torch.equal(P.r(states[-1]), states[-1])                    # the state really is finer than bf16
     for i in range(1, 5):
         assert ((states[i] - ref[i]).norm() / ref[i].norm()).item() < 5e-2
+
+
+def test_oracle_at_full_width_against_the_reference_itself():
+    """The oracle held to the REFERENCE at FLUX width once: `tests/golden/fullwidth_reference.npz` is the reference's own
+    FluxLoraWrapper (1 DoubleStreamBlock + 1 SingleStreamBlock, hidden 3072, 24 heads, LoRA r256) run in fp32 on cfg 2's
+    geometry (L = 512 + 3456) by tests/golden/make_fullwidth_reference.py; procedural weights and inputs, outputs only.  The
+    fp32 / un-merged oracle must reproduce `Flux.forward` and the sampled block outputs to fp32 summation noise (K up to 15360
+    per dot product: measured 2e-6 of the output's scale; bound 2e-5 as at the tiny geometry)."""
+    import importlib.util
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    fx = np.load(os.path.join(here, "fullwidth_reference.npz"))
+    spec = importlib.util.spec_from_file_location("make_fullwidth_traj", os.path.join(here, "make_fullwidth_traj.py"))
+    FT = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(FT)
+    inp = FT.inputs("cfg2")
+    assert float(fx["x_sum"]) == inp["x"].double().sum().item()
+    sd = {k: procedural_param(k, s, device="cpu").to(torch.bfloat16).float() for k, s in FT.key_shapes()}
+    Gw = O.FluxGeometry(depth=1, depth_single_blocks=1)
+    taps = {}
+    orig = O.compute_vec
+    O.compute_vec = lambda *a, **k: orig(*a, **{**k, "guidance_is_bf16": False})
+    try:
+        with torch.no_grad():
+            y = O.flux_forward(sd, Gw, torch.cat((inp["x"], inp["cond"]), -1), inp["img_ids"], inp["txt"], inp["txt_ids"],
+                               torch.tensor(fx["t"]), inp["y"], inp["txt_mask"], inp["img_mask"], inp["guidance"],
+                               P=O.Prec("fp32", "ref"), taps=taps)
+    finally:
+        O.compute_vec = orig
+    rs, cs_ = int(fx["row_stride"]), int(fx["col_stride"])
+    close(y, fx["flux"])
+    close(taps["double.0.img"][0, ::rs, ::cs_], fx["double_img"])
+    close(taps["double.0.txt"][0, ::rs, ::cs_], fx["double_txt"])
+    close(taps["single.0"][0, ::rs, ::cs_], fx["single"])
+    err = ((y - torch.tensor(fx["flux"])).norm() / torch.tensor(fx["flux"]).norm()).item()
+    print(f"oracle fp32 vs the reference at full width (1+1 blocks, L = 3968): rel-L2 {err:.2e}")
+    assert err < 1e-5

@@ -1385,20 +1385,19 @@ static GemmPlan plan_gemm(const VcGemmArgs& a, int tile_cfg) {
     }
   }
   // STREAM REMAINDER: more than half a round of tiles beyond the whole rounds (no uniform S >= 2 fits one round): every CU takes
-  // rem / CUs of a tile's K-iterations, at most two segments, <= 3 partial tiles per remainder tile (cfg 3's N = 3072 launches:
-  // 416 tiles = 256 + 160 -> 0.625 tile per CU instead of a second round of 240 narrower tiles; cfg 5: 464 = 256 + 208).
-  // Priced like the uniform form: two prologues per item, (CUs + rem) partial tiles written and read once, one more launch boundary.
+  // f = rem / CUs of a tile's K-iterations, at most two segments, <= 3 partial tiles per remainder tile.  Decided by measurement,
+  // not by the model (which prices a partly filled round at its full length; under the power cap it costs ~0.85 of one at 81 %
+  // fill): interleaved whole steps, profiles/r05d_ab_*.log - cfg 3's N = 3072 launches (416 tiles = 256 + 160, f = 0.625: instead
+  // of the row cut into 256 + 240 narrower tiles) +1.7 % per step, all of it from K >= 12288 (K = 3072 included: +0.0 %);
+  // cfg 5's (464 = 256 + 208, f = 0.81: instead of a second round at 81 % fill) -1.2 %, with K = 3072 -2.1 %.  Taken for
+  // 0.5 < f <= 0.7 and K >= VC_GEMM_STREAMK_MIN_K.
   if (!no_splitk && sk.sk_S == 0 && a.splitk_ws && a.epi != VC_EPI_QKV) {
     const long total = tiles_of(a, 4), R = total / n_cus, rem = total % n_cus;
     bool same_k = true;
     for (int i = 1; i < a.nprob; ++i) same_k = same_k && a.p[i].K == a.p[0].K;
-    const double bytes = (double)(n_cus + rem) * cfg_bm[4] * cfg_bn[4] * 4;
     const bool prefer = (tile_cfg_flags & VC_GEMM_PREFER_STREAMK) != 0, any_k = (tile_cfg_flags & VC_GEMM_STREAMK_ANY_K) != 0;
     if (R >= 1 && 2 * rem > n_cus && same_k && (a.p[0].K >= VC_GEMM_STREAMK_MIN_K || any_k) && (double)n_cus * 2 * cfg_bm[4] * cfg_bn[4] * 4 <= (double)a.splitk_ws_bytes) {
-      const double area = (double)cfg_bm[4] * cfg_bn[4] / cand_eff[1];
-      const double cost = R * area * (a.p[0].K + cand_ovh[1]) + area * ((double)rem / n_cus * a.p[0].K + 2 * (cand_ovh[1] + 150.0)) + (2.0 * bytes / 4e6 + 3.0) * 3.2e6;
-      if (prefer || any_k) return stream_plan();
-      if (cost < 0.93 * whole.cost) { sk = stream_plan(); sk_cost = cost; }
+      if (prefer || any_k || 10 * rem <= 7 * n_cus) return stream_plan();
     }
   }
   // Block-round quantisation: cut problem 0's rows where the 256x192 tiles above the cut are (nearly) whole rounds of the 256

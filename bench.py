@@ -33,6 +33,8 @@ WORKLOADS = {
     "512-grid-2x3": dict(rows=2, row_latent=(64, 192), steps=30),
     "384-grid-1x2": dict(rows=1, row_latent=(48, 96), steps=4),
     "384-grid-3x4": dict(rows=3, row_latent=(48, 192), steps=50),
+    # the largest grid the reference's own UI offers (app.py:10-11: up to 5 in-context rows x 5 columns): L = 512 + 25 * 576 = 14912
+    "384-grid-5x5": dict(rows=5, row_latent=(48, 240), steps=30),
     # cfg 5's SDEdit upsample stage of one 1024x1024 target (visualcloze.py:184-234): 10 points from strength 0.4, no shift
     "1024-sdedit-upsample": dict(rows=1, row_latent=(128, 128), steps=10, t0=0.4, do_shift=False),
     # shapes the pipeline really produces from non-square photographs (resize_with_aspect_ratio, visualcloze.py:28-60: area

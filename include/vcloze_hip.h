@@ -101,7 +101,9 @@ typedef struct VcGemmArgs {
    * plus a remainder of r tiles may run the remainder as r * S work items of K / S each (S <= 8, r * S <= CUs), which leave
    * f32 partial tiles in the scratch; a second, HBM-bound launch sums the S partials of each tile in a fixed order and applies
    * the epilogue (bias, GELU / SiLU / gate + residual) - bit-reproducible (static assignment), equal to the one-pass kernel up
-   * to f32 summation order.  Not for VC_EPI_QKV.  sk_*: filled by the launcher. */
+   * to f32 summation order.  Not for VC_EPI_QKV.  The scratch belongs to ONE stream at a time: launches that share it must be
+   * ordered (one stream, one linear graph) - a reduce launch of one call and the slices of the next would race otherwise.
+   * sk_*: filled by the launcher. */
   void* splitk_ws;
   int64_t splitk_ws_bytes;
   int32_t sk_full, sk_rem, sk_S;

@@ -6,6 +6,7 @@ SURVEY.md §8's table:
     cfg 3   512-grid 2x3           N = 6144   L = 6656
     cfg 5   384-grid 3x4           N = 6912   L = 7424
     sdedit  cfg 5's upsample stage N = 4096   L = 4608      (one 1024x1024 target, unshifted strength-0.4 grid)
+    g5x5    384-grid 5x5           N = 14400  L = 14912     (beyond BASELINE: the largest grid of the reference's UI, app.py:10-11)
 and for two shapes the pipeline REALLY produces from non-square photographs (visualcloze.py:28-60,312-323: area ~ 384^2, sides
 floored to multiples of 16, every row at the aspect of its first image) - off every 64 / 128 / 256 tile edge:
     p34     384-grid 2x3 of 3:4 portraits (320x432 px, 540 tokens each)                N = 3240   L = 3752
@@ -40,6 +41,7 @@ GEOMS = {                         # rows of the grid, latent (h, w) of one conca
     "cfg3": (2, (64, 192)),
     "cfg5": (3, (48, 192)),
     "sdedit": (1, (128, 128)),
+    "g5x5": (5, (48, 240)),                  # the largest grid the reference's UI offers (app.py:10-11): N = 14400, L = 14912
     "p34": [(54, 120), (54, 120)],           # per-row latent sizes
     "mixed": [(54, 120), (40, 162)],
 }

@@ -231,3 +231,31 @@ def test_step_graph_cache_eviction_and_recapture(model):
     for a, b, c in zip(first, second, third):
         assert torch.isfinite(a.float()).all() and torch.equal(a, b) and torch.equal(a, c)
     assert len({tuple(a.shape) for a in first}) >= 4
+
+
+def test_host_copy_cache_hits_through_the_product_sampler(model):
+    """handle._HostCopies (advisor r04): vc_flux_prepare takes the position ids and the guidance as HOST arrays; the D2H copies
+    that would drain the stream once per sample are remembered while the caller hands over the same memory at the same version.
+    The product path slices its arguments per chunk - a new view OBJECT of the same storage per call - so the key must be the
+    memory: the second sample through `Sampler.sample_ode` must hit for all three arguments, an in-place edit of the ids must
+    miss (and change the result), and a different tensor of equal contents must give equal bits."""
+    from tests.procedural import tiny_inputs
+    from visualcloze_amd.transport import Sampler, create_transport
+    m, _ = model
+    fn = Sampler(create_transport()).sample_ode(sampling_method="euler", num_steps=4, do_shift=True, time_shifting_factor=1)
+    inp = tiny_inputs(B=1)
+    kw, x = _kw(inp), inp["x"].to(DEV, torch.bfloat16)
+    a = fn(x, m.forward, kw)
+    hc = m.handle()._host
+    h0, m0 = hc.hits, hc.misses
+    b = fn(x, m.forward, kw)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    assert hc.hits - h0 == 3 and hc.misses == m0, (hc.hits - h0, hc.misses - m0)       # guidance, img_ids, txt_ids: no D2H copy
+    kw2 = dict(kw, img_ids=kw["img_ids"].clone(), txt_ids=kw["txt_ids"].clone(), guidance=kw["guidance"].clone())
+    c = fn(x, m.forward, kw2)                                                          # other memory, equal contents
+    assert torch.equal(a, c) and hc.misses - m0 == 3
+    kw2["img_ids"][0, :, 1] += 3.0                                                     # same memory, new version: positions moved
+    d = fn(x, m.forward, kw2)
+    torch.cuda.synchronize()
+    assert not torch.equal(a, d)

@@ -1296,9 +1296,12 @@ static int validate_gemm(VcGemmArgs& a, char* err, int errlen) {
         (uint64_t)(p.a_rpb > 0 ? p.a_rpb : p.M) * (uint64_t)p.lda >= (1ull << 32) || (uint64_t)p.N * (uint64_t)p.ldw >= (1ull << 32) || (p.ldw != 0 && p.ldw < p.K) || p.ldw % 8) {
       snprintf(err, errlen, "gemm: operand exceeds 32-bit element offsets"); return VC_ERR_ARG; }
     // the loader-wave kernels address A with 32-bit BYTE offsets against the operand, W with byte offsets against its n-tile
-    if ((p.a_rpb > 0 ? (uint64_t)((p.M + p.a_rpb - 1) / p.a_rpb) * (uint64_t)p.a_bstride : (uint64_t)p.M * (uint64_t)p.lda) >= (1ull << 31) ||
-        (uint64_t)288 * (uint64_t)p.ldw >= (1ull << 31)) {
-      snprintf(err, errlen, "gemm: A operand of 4 GB or more (or a W row stride beyond 7 M elements) is not supported"); return VC_ERR_ARG; }
+    // (the largest element offset of A the kernel forms, + one K-tile: batch-strided rows may overlap or leave gaps, so both
+    // terms count - advisor r04)
+    const uint64_t a_last = p.a_rpb > 0 ? (uint64_t)((p.M - 1) / p.a_rpb) * (uint64_t)p.a_bstride + (uint64_t)(p.a_rpb - 1) * (uint64_t)p.lda
+                                        : (uint64_t)(p.M - 1) * (uint64_t)p.lda;
+    if (a_last + (uint64_t)p.K + 64 >= (1ull << 31) || (uint64_t)288 * (uint64_t)p.ldw >= (1ull << 31)) {
+      snprintf(err, errlen, "gemm: A operand spanning 4 GB or more (2^31 bf16 elements; or a W row stride beyond 7 M elements) is not supported"); return VC_ERR_ARG; }
     if (a.epi == VC_EPI_GATE_RES && (!p.res || !p.gate || p.rows_per_batch <= 0 || p.ldres % 8 || p.gate_bstride % 8 || a.gate_step_stride % 8)) {
       snprintf(err, errlen, "gemm: gate/residual epilogue needs res, gate, rows_per_batch"); return VC_ERR_ARG; }
     if (a.epi == VC_EPI_QKV && p.kn_heads != 0 && (p.kn_heads < 0 || p.N != 384 * p.kn_heads || (p.vt && p.vt_col0 != 256 * p.kn_heads) || p.vt_rpb <= 0 ||

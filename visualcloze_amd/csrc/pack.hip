@@ -101,6 +101,8 @@ int vc_pack_latent_launch(const void* in, void* out, int C, int h, int w, int64_
 int vc_pack_mask_launch(const void* in, void* out, int H, int W, int64_t ld, int col0, hipStream_t s, char* err, int errlen) {
   if (!in || !out || H <= 0 || W <= 0 || H % 16 || W % 16 || ld % 8 || col0 % 8) {
     snprintf(err, errlen, "pack_mask: H, W must be positive multiples of 16 (H=%d W=%d)", H, W); return VC_ERR_ARG; }
+  if (((uintptr_t)in | (uintptr_t)out) & 15) {     // the kernel reads the mask and writes the tokens in 16-B vectors (advisor r04)
+    snprintf(err, errlen, "pack_mask: the mask and the token rows must be 16-byte aligned"); return VC_ERR_ARG; }
   PK_LAUNCH("pack_mask", pack_mask_kernel, dim3((W / 16 + TWM - 1) / TWM, H / 16), 0, (const bf16_t*)in, (bf16_t*)out, H, W, (long)ld, col0)
 }
 int vc_unpack_latent_launch(const void* in, int64_t ld, int col0, void* out, int C, int h, int w, hipStream_t s, char* err, int errlen) {

@@ -504,6 +504,8 @@ def pack_latent(latent, tokens, col0=0, stream=None):
     Cc, h, w = latent.shape[-3:]
     if not latent.is_contiguous() or tokens.shape[0] != (h // 2) * (w // 2):
         raise VclozeHipError("pack_latent: contiguous [C,h,w] latent and (h/2)(w/2) token rows expected")
+    if Cc > 64:
+        raise VclozeHipError(f"pack_latent: C={Cc} > 64 channels (the tile staged through LDS holds 64)")
     _check(lib().vc_pack_latent(latent.data_ptr(), tokens.data_ptr(), Cc, h, w, tokens.stride(0), col0,
                                 stream if stream is not None else cur_stream()), "vc_pack_latent")
 
@@ -514,6 +516,8 @@ def pack_mask(mask, tokens, col0=0, stream=None):
     H, W = mask.shape[-2:]
     if not mask.is_contiguous() or tokens.shape[0] != (H // 16) * (W // 16):
         raise VclozeHipError("pack_mask: contiguous [H,W] mask and (H/16)(W/16) token rows expected")
+    if mask.data_ptr() % 16 or tokens.data_ptr() % 16:
+        raise VclozeHipError("pack_mask: the mask and the token rows must be 16-byte aligned (a view at an odd storage offset is not)")
     _check(lib().vc_pack_mask(mask.data_ptr(), tokens.data_ptr(), H, W, tokens.stride(0), col0,
                               stream if stream is not None else cur_stream()), "vc_pack_mask")
 
@@ -523,6 +527,8 @@ def unpack_latent(tokens, latent, col0=0, stream=None):
     Cc, h, w = latent.shape[-3:]
     if not latent.is_contiguous() or tokens.shape[0] != (h // 2) * (w // 2):
         raise VclozeHipError("unpack_latent: contiguous [C,h,w] latent and (h/2)(w/2) token rows expected")
+    if Cc > 64:
+        raise VclozeHipError(f"unpack_latent: C={Cc} > 64 channels (the tile staged through LDS holds 64)")
     _check(lib().vc_unpack_latent(tokens.data_ptr(), tokens.stride(0), col0, latent.data_ptr(), Cc, h, w,
                                   stream if stream is not None else cur_stream()), "vc_unpack_latent")
 

@@ -129,6 +129,17 @@ def test_full_width_one_plus_one_blocks_vs_oracle(small_model, geom):
     inp = _inputs(geom)
     t = torch.tensor([0.62])
     got = _call(m, inp, t)
+    if geom == "g5x5":      # L = 14912: the oracle's L x L attention dominates (2 x 70 s on the box's host cores) - the fp32 /
+        # reference-semantics leg only (with both: bf16 5.4e-3, fp32 9.07e-3, floor 9.07e-3, profiles/r05e_parity.log)
+        with torch.no_grad():
+            want_fp32 = O.flux_forward(sd, O.FluxGeometry(depth=1, depth_single_blocks=1), torch.cat((inp["x"], inp["cond"]), -1).bfloat16().float(),
+                                       inp["img_ids"], inp["txt"].bfloat16().float(), inp["txt_ids"], t, inp["y"].bfloat16().float(),
+                                       inp["txt_mask"], inp["img_mask"], inp["guidance"], P=O.Prec("fp32", "ref"))
+        e32 = rel_l2(got, want_fp32)
+        from tests.helpers import parity_log
+        parity_log(f"[1+1 blocks, {geom}] L={T + inp['x'].shape[1]}: HIP vs fp32 oracle {e32:.3e}")
+        assert e32 < 3e-2
+        return
     want_bf16, want_fp32 = _oracle_pair(sd, O.FluxGeometry(depth=1, depth_single_blocks=1), inp, t)
     floor = rel_l2(want_bf16, want_fp32)          # what bf16 execution costs the oracle itself at this size
     e16, e32 = rel_l2(got, want_bf16), rel_l2(got, want_fp32)

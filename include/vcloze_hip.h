@@ -339,14 +339,17 @@ int vc_flux_destroy(void* handle);
  * which is within 1 ulp of torch's f32 exp).  Pointers must stay valid while bound. */
 int vc_flux_bind_weight(void* handle, const char* name, const void* w, const void* bias, int32_t rows, int32_t cols, int64_t ldw);
 int64_t vc_flux_mod_offset(void* handle, const char* module_name);
-/* knobs for tests and A/B runs: "attn_variant" (-1 = by size, the default), "tile_cfg" (0), "fuse_qnorm" (1: query
- * QKNorm + RoPE inside the attention kernel), "fuse_vt" (1: V^T from the qkv GEMM's epilogue, VC_EPI_QKV);
+/* knobs for tests and A/B runs: "attn_variant" (-1 = by size, the default), "tile_cfg" (0; flag bits such as
+ * VC_GEMM_PREFER_STREAMK ride along), "fuse_qnorm" (2, the default: query QKNorm + RoPE + the softmax scale in the qkv GEMM's
+ * epilogue wherever the key heads are normalised there, VcGemmProblem.qn_scale / VcAttention.q_prescaled; 1: inside the attention
+ * kernel, VcAttention.q_scale; 0: by the pre-pass), "fuse_vt" (1: V^T from the qkv GEMM's epilogue, VC_EPI_QKV);
  * "qkv_heads" (0; = num_heads when the caller bound HEAD-PERMUTED qkv weights - every `*_attn.qkv` and the first
  * 3 * hidden rows of every `linear1`, with their biases, in the row order VcGemmProblem.kn_heads describes) and, with it,
  * "fuse_knorm" (0; 1: QKNorm + RoPE of the key heads inside the qkv GEMM's epilogue - with fuse_qnorm and fuse_vt the
- * projection, the norms, RoPE and the V transpose are then ONE GEMM launch + the attention kernel: no pre-pass);
+ * projection, the norms, RoPE and the V transpose are then ONE GEMM launch + the attention kernel: no pre-pass, no prologue);
  * "logit_bound_milli" (0; 1000 * VcAttention.logit_bound for every attention call of the model, from the bound QK-norm
- * scales: 16330 * max|query_norm.scale| * max|key_norm.scale| over all blocks, rounded up). */
+ * scales: 16330 * max|query_norm.scale| * max|key_norm.scale| over all blocks, rounded up); "mlp_first", "splitk" (1: split-K /
+ * stream remainders where the launcher takes them). */
 int vc_flux_set_option(void* handle, const char* name, int32_t value);
 int64_t vc_flux_workspace_bytes(void* handle, int32_t B, int32_t T, int32_t N, int32_t max_steps);
 

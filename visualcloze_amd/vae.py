@@ -212,6 +212,24 @@ class _HipExec(nn.Module):
         return out
 
 
+def _level(cin: int, cout: int, n_blocks: int, resample_name: str, resample) -> nn.Module:
+    """One resolution level of the encoder / decoder: `n_blocks` ResnetBlocks (the first maps cin -> cout), an empty `attn` list
+    (the FLUX AutoEncoder has none outside `mid`) and, except at the last level of the walk, a Downsample / Upsample - registered
+    in the order that gives the reference's state-dict key order (autoencoder.py:128-147, 212-232)."""
+    lvl = nn.Module()
+    lvl.block = nn.ModuleList(ResnetBlock(cin if j == 0 else cout, cout) for j in range(n_blocks))
+    lvl.attn = nn.ModuleList()
+    if resample is not None:
+        setattr(lvl, resample_name, resample(cout))
+    return lvl
+
+
+def _mid(width: int) -> nn.Module:
+    m = nn.Module()
+    m.block_1, m.attn_1, m.block_2 = ResnetBlock(width, width), AttnBlock(width), ResnetBlock(width, width)
+    return m
+
+
 class Encoder(_HipExec):             # autoencoder.py:109-180
     def __init__(self, resolution: int, in_channels: int, ch: int, ch_mult: List[int], num_res_blocks: int, z_channels: int):
         super().__init__()
@@ -219,30 +237,15 @@ class Encoder(_HipExec):             # autoencoder.py:109-180
         self.num_resolutions = len(ch_mult)
         self.num_res_blocks = num_res_blocks
         self.resolution, self.in_channels = resolution, in_channels
+        self.in_ch_mult = (1,) + tuple(ch_mult)
+        widths = [ch * m for m in self.in_ch_mult]                    # channel count entering level i = widths[i], leaving = widths[i + 1]
         self.conv_in = _Conv(in_channels, ch, 3)
-        in_ch_mult = (1,) + tuple(ch_mult)
-        self.in_ch_mult = in_ch_mult
-        self.down = nn.ModuleList()
-        block_in = ch
-        for i_level in range(self.num_resolutions):
-            block = nn.ModuleList()
-            block_in = ch * in_ch_mult[i_level]
-            block_out = ch * ch_mult[i_level]
-            for _ in range(self.num_res_blocks):
-                block.append(ResnetBlock(block_in, block_out))
-                block_in = block_out
-            down = nn.Module()
-            down.block = block
-            down.attn = nn.ModuleList()
-            if i_level != self.num_resolutions - 1:
-                down.downsample = Downsample(block_in)
-            self.down.append(down)
-        self.mid = nn.Module()
-        self.mid.block_1 = ResnetBlock(block_in, block_in)
-        self.mid.attn_1 = AttnBlock(block_in)
-        self.mid.block_2 = ResnetBlock(block_in, block_in)
-        self.norm_out = _GroupNorm(block_in)
-        self.conv_out = _Conv(block_in, 2 * z_channels, 3)
+        last = self.num_resolutions - 1
+        self.down = nn.ModuleList(_level(widths[i], widths[i + 1], num_res_blocks, "downsample", None if i == last else Downsample)
+                                  for i in range(self.num_resolutions))
+        self.mid = _mid(widths[-1])
+        self.norm_out = _GroupNorm(widths[-1])
+        self.conv_out = _Conv(widths[-1], 2 * z_channels, 3)
 
     def _moments_one(self, img):
         """img [in_channels, H, W] -> (moments NHWC [h*w, pad8(2z)], h, w)   (Encoder.forward, :159-180)"""
@@ -302,27 +305,16 @@ class Decoder(_HipExec):             # autoencoder.py:183-259
         self.num_res_blocks = num_res_blocks
         self.resolution, self.in_channels = resolution, in_channels
         self.ffactor = 2 ** (self.num_resolutions - 1)
-        block_in = ch * ch_mult[self.num_resolutions - 1]
-        self.conv_in = _Conv(z_channels, block_in, 3)
-        self.mid = nn.Module()
-        self.mid.block_1 = ResnetBlock(block_in, block_in)
-        self.mid.attn_1 = AttnBlock(block_in)
-        self.mid.block_2 = ResnetBlock(block_in, block_in)
-        self.up = nn.ModuleList()
-        for i_level in reversed(range(self.num_resolutions)):
-            block = nn.ModuleList()
-            block_out = ch * ch_mult[i_level]
-            for _ in range(self.num_res_blocks + 1):
-                block.append(ResnetBlock(block_in, block_out))
-                block_in = block_out
-            up = nn.Module()
-            up.block = block
-            up.attn = nn.ModuleList()
-            if i_level != 0:
-                up.upsample = Upsample(block_in)
-            self.up.insert(0, up)
-        self.norm_out = _GroupNorm(block_in)
-        self.conv_out = _Conv(block_in, out_ch, 3)
+        widths = [ch * m for m in ch_mult]                            # level i runs at widths[i]; the walk goes from the last level down to 0
+        top = widths[-1]
+        self.conv_in = _Conv(z_channels, top, 3)
+        self.mid = _mid(top)
+        enter = [top] + widths[:0:-1]                                 # channels entering levels n-1, n-2, ..., 0 (the previous level's width)
+        levels = [_level(cin, widths[i], num_res_blocks + 1, "upsample", None if i == 0 else Upsample)
+                  for cin, i in zip(enter, reversed(range(self.num_resolutions)))]
+        self.up = nn.ModuleList(levels[::-1])                         # stored by level index, as the state dict names them
+        self.norm_out = _GroupNorm(widths[0])
+        self.conv_out = _Conv(widths[0], out_ch, 3)
 
     def forward(self, z: torch.Tensor) -> torch.Tensor:
         """z: [B, z_channels, h, w] (f32 or bf16) -> image [B, out_ch, 8h, 8w] bf16 (the reference's Decoder.forward)."""

@@ -67,10 +67,9 @@ typedef struct VcGemmProblem {
   int64_t vt_bstride;
   int32_t vt_col0, vt_rpb, vt_row0, vt_lpad;
   /* VC_EPI_QKV, kn_heads = H > 0 (N = 3 * 128 * H): W's rows / bias arrive HEAD-PERMUTED so that every 192-column tile holds one
-   * whole query or key head and half a value head, 64 head + 32 V columns in each 96-column half - permuted column p is logical
-   * column (t = p / 192, half = (p % 192) / 96, r = p % 96)
-   *     r < 64:    128 t + 64 half + r               (t < H: query head t; t >= H: key head t - H)
-   *     else:      256 H + 64 t + 32 half + r - 64   (V columns 64 t .. 64 t + 63; vt_col0 = 256 H)
+   * whole query or key head and half a value head - permuted column p is logical column (t = p / 192, j = p % 192)
+   *     j < 128:   128 t + j             (t < H: query head t; t >= H: key head t - H)
+   *     else:      256 H + 64 t + j - 128 (V columns 64 t .. 64 t + 63; vt_col0 = 256 H)
    * and C is written at the logical columns ("B L (K H D)", layers.py:166,236) by any tile shape (only the 256x192 tile writes V^T
    * in whole 16-B runs).  With kn_scale and / or qn_scale != NULL (forces the 256x192 tile) the epilogue ALSO applies QKNorm with
    * kn_scale / qn_scale [128] bf16 and RoPE from kn_rope ([B?][L][64][2] f32, row vt_row0 + m % vt_rpb of batch element

@@ -52,17 +52,6 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
   constexpr int NS = PP == 2 ? 256 : NT;              // threads that stage operand tiles
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int MI = TM / 16, NI = TN / 16;
-  // VSWAP (the qkv launch on the 192-wide loader-wave tile): with head-permuted weights every wave's 96 columns are 64 head columns
-  // (accumulator blocks j = 0..3) and 32 V columns (j = 4, 5).  The MFMAs of blocks j >= 4 run with their operands the other way
-  // round (D = A_frag x W_frag), so a lane ends up with 4 consecutive TOKENS of one column instead of 4 consecutive columns of one
-  // token - the same dot products, laid out as the transposed V^T staging image wants them: ONE 8-byte LDS write per block where
-  // the column-major lane layout needed four 2-byte writes (the LDS write port was the epilogue's bottleneck: pass 1 took 9.8 k
-  // ticks per tile against 2.8 k for a plain tile, tools/qkv_epilogue_phases.py).  Compile-time per block: one main loop.
-#if !defined(VC_GEMM_NO_VSWAP) && !defined(VC_GEMM_NO_LDSREAD) && !defined(VC_GEMM_NO_MFMA) && !defined(VC_GEMM_NO_SLOT_UNROLL)      /* (A/B and analysis builds) */
-  constexpr bool VSWAP = EPI == VC_EPI_QKV && BN == 192 && WN == 2 && PP == 2 && !PERSIST && !CONV && !SPLITK;
-#else
-  constexpr bool VSWAP = false;
-#endif
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
   constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
   constexpr int A_CH = BM * 8, B_CH = BN * 8;                       // 16-B chunks per operand tile
@@ -202,6 +191,7 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
   const int m0 = tile_cur.m0, n0 = tile_cur.n0;
   const int M = P.M, N = P.N, K = P.K;
   const bool has_next = PERSIST && id_cur + id_step < id_end;
+
   // K-tiles [kt_lo, kt_lo + nk) of this work item (the whole K unless it is a split-K slice)
   int kt_lo = 0, nk = K / BK;
   if constexpr (SPLITK) {
@@ -421,12 +411,7 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
           const int col = n0 + wn * TN + j * 16 + fq * 4;
           u32x2 bb = {0u, 0u};
           if (col < N) bb = *(const u32x2*)((const bf16_t*)P.bias + col);
-          f32x4 b4 = {lo_bf(bb[0]), hi_bf(bb[0]), lo_bf(bb[1]), hi_bf(bb[1])};
-          if (VSWAP && j >= 4) {                      // a swapped block: the lane owns ONE column (fr) and 4 rows
-            const int vcol = n0 + wn * TN + j * 16 + fr;
-            const float bv = vcol < N ? bf2f(((const bf16_t*)P.bias)[vcol]) : 0.f;
-            b4 = f32x4{bv, bv, bv, bv};
-          }
+          const f32x4 b4 = {lo_bf(bb[0]), hi_bf(bb[0]), lo_bf(bb[1]), hi_bf(bb[1])};
 #pragma unroll
           for (int i = 0; i < MI; ++i) acc[i][j] = b4;
         }
@@ -467,10 +452,8 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-              for (int j = 0; j < NI; ++j) {
-                if (VSWAP && j >= 4) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-                else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-              }
+              for (int j = 0; j < NI; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
             bar();
           }
         };
@@ -650,45 +633,34 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
   // leaves as 16-B runs of 8 consecutive tokens per (head, dim) row of vt; a tile that straddles vt_col0 (or unaligned
   // row geometry) takes the ordinary path and scatters its V elements one by one (test geometries only).
   constexpr int EPT_LD = BM * 2 + 16;
-  // EPI_QKV with kn_heads = H > 0: the weight rows (output columns) arrive HEAD-PERMUTED (vcloze_hip.h): 2H blocks of 192 =
-  // [head t columns 0..63 | V columns 64 t .. 64 t + 31 | head t columns 64..127 | V columns 64 t + 32 .. 64 t + 63] (head t = query
-  // head t for t < H, key head t - H after) - every 192-wide tile holds ONE whole query or key head, which with qn_scale / kn_scale
-  // the epilogue QK-norms and rotates (layers.py:63-84, math.py:112-117) before the row leaves: the "QKV + RoPE fused projection";
-  // each of its two column halves (= the 96 columns of one wave column) is 64 head + 32 V columns, so the V accumulators are the
-  // blocks j = 4, 5 of EVERY wave (VSWAP).  C is always written at the LOGICAL columns (q | k | v).  Staging image of a 192- or
-  // 128-wide tile (vkind 4): [BM] rows of 256 + 16 B for the non-V columns (192: by head column; 128: in place), then the tile's V
-  // columns by their index in their block - transposed, [64][BM * 2 + 16 B], when vt takes whole 16-B runs (vfast), else [BM] rows
-  // of 128 + 16 B (192-wide tiles only).  Every other case (vkind 5) maps each 16-B chunk of the generic pass 2 to its logical place.
-  int vkind = 0;
+  // EPI_QKV with kn_heads = H > 0: the weight rows (output columns) arrive HEAD-PERMUTED (vcloze_hip.h): 2H blocks of
+  // [head t (128): query head t for t < H, key head t - H after | V columns 64 t .. 64 t + 63] - every 192-wide tile holds ONE
+  // whole query or key head, and with qn_scale / kn_scale the epilogue applies QKNorm + RoPE to it (layers.py:63-84,
+  // math.py:112-117) before the row leaves: the "QKV + RoPE fused projection"; its 64 V columns leave transposed into vt.  C is
+  // always written at the LOGICAL columns (q | k | v).  A 192- or 128-wide tile holds at most ONE run of 64 V columns, at tile
+  // column v_lo; its staging image (vkind 4) is [BM] rows of 256 + 16 B for the other columns (in place), then the V run -
+  // transposed, [64][BM * 2 + 16 B], when vt takes whole 16-B runs (vfast), else [BM] rows of 128 + 16 B (192-wide tiles only).
+  // Every other case (vkind 5) maps each 16-B chunk of the generic pass 2 to its logical place.
+  int vkind = 0, v_lo = -1;
   const int knH = EPI == VC_EPI_QKV ? P.kn_heads : 0;
   constexpr bool MIXED = EPI == VC_EPI_QKV && (BN == 192 || BN == 128);
   constexpr int EPH_LD = 128 * 2 + 16, EPV_LD = 64 * 2 + 16, EPV0 = BM * EPH_LD;
   bool vfast = false;
   auto qkv_col = [&](int n) {        // permuted column (multiple of 8) -> logical column
-    const int t = n / 192, c = n - 192 * t, half = c >= 96 ? 1 : 0, r = c - 96 * half;
-    return r < 64 ? 128 * t + 64 * half + r : 256 * knH + 64 * t + 32 * half + r - 64;
-  };
-  const int blk0 = n0 % 192;         // where in its 192-block the tile starts (0 for 192-wide tiles; 0 / 128 / 64 for 128-wide ones)
-  auto v_index = [&](int col) {      // tile column -> index of that V column among the 64 of its block, or -1 for a head column
-    int c = blk0 + col;
-    if (c >= 192) c -= 192;
-    const int half = c >= 96 ? 1 : 0, r = c - 96 * half;
-    return r >= 64 ? 32 * half + r - 64 : -1;
-  };
-  auto h_index = [&](int col) {      // (192-wide tiles) tile column -> column of the head, 0..127
-    const int half = col >= 96 ? 1 : 0;
-    return col - 32 * half;
+    const int t = n / 192, j = n - 192 * t;
+    return j < 128 ? 128 * t + j : 256 * knH + 64 * t + j - 128;
   };
   if constexpr (EPI == VC_EPI_QKV) {
     const bool aligned = P.vt && ((P.vt_rpb | P.vt_row0 | P.vt_lpad | (int)(P.vt_bstride & 7)) & 7) == 0;
     if (knH > 0) {
       vkind = 5;
-      if (BN == 192) { vkind = 4; vfast = aligned; }
-      else if (BN == 128 && aligned) { vkind = 4; vfast = true; }
+      if (BN == 192) { vkind = 4; v_lo = 128; vfast = aligned; }
+      else if (BN == 128 && aligned && n0 % 384 != 0) { vkind = 4; v_lo = n0 % 384 == 128 ? 0 : 64; vfast = true; }
     } else if (P.vt) {
       vkind = n0 >= P.vt_col0 ? (aligned ? 1 : 2) : (n0 + BN > P.vt_col0 ? 2 : 0);
     }
     vkind = __builtin_amdgcn_readfirstlane(vkind);
+    v_lo = __builtin_amdgcn_readfirstlane(v_lo);
   }
   const bf16_t* __restrict__ bias = (const bf16_t*)P.bias;
 #pragma unroll
@@ -699,28 +671,6 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
     for (int j = 0; j < NI; ++j) {
       const int col = wn * TN + j * 16 + efq * 4;
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      if (VSWAP && j >= 4) {
-        // a swapped block: v[r] = t(token wm TM + 16 i + 4 fq + r, tile column wn TN + 16 j + fr), bias already inside (PP == 2).
-        // With the transposed image (the product's case) that is 8 B of one image row; every other staging form takes the
-        // four values one by one (test geometries: unaligned or absent vt, natural-order weights)
-        const int rowb = wm * TM + i * 16 + efq * 4, colb = wn * TN + j * 16 + efr;
-        u32x2 o;
-        o[0] = pack2bf(v[0], v[1]);
-        o[1] = pack2bf(v[2], v[3]);
-        if (vkind == 4 && vfast) {
-          *(u32x2*)(smem + EPV0 + v_index(colb) * EPT_LD + rowb * 2) = o;
-        } else if (vkind == 1) {
-          *(u32x2*)(smem + colb * EPT_LD + rowb * 2) = o;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const bf16_t x = (bf16_t)(o[e >> 1] >> (16 * (e & 1)));
-            if (vkind == 4) *(bf16_t*)(smem + EPV0 + (rowb + e) * EPV_LD + v_index(colb) * 2) = x;
-            else *(bf16_t*)(smem + (rowb + e) * EP_LD + colb * 2) = x;
-          }
-        }
-        continue;
-      }
       if (PP == 2) {
         // bias already in the accumulators
       } else if (bias && n0 + col < N) {
@@ -734,14 +684,13 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
 #pragma unroll
         for (int e = 0; e < 4; ++e) *(bf16_t*)(smem + (col + e) * EPT_LD + row * 2) = (bf16_t)(o[e >> 1] >> (16 * (e & 1)));
       } else if (MIXED && vkind == 4) {
-        const int vi = v_index(col);
-        if (vi < 0) {
-          *(u32x2*)(smem + row * EPH_LD + (BN == 192 ? h_index(col) : col) * 2) = o;
+        if (col < v_lo || col >= v_lo + 64) {
+          *(u32x2*)(smem + row * EPH_LD + col * 2) = o;
         } else if (vfast) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) *(bf16_t*)(smem + EPV0 + (vi + e) * EPT_LD + row * 2) = (bf16_t)(o[e >> 1] >> (16 * (e & 1)));
+          for (int e = 0; e < 4; ++e) *(bf16_t*)(smem + EPV0 + (col - v_lo + e) * EPT_LD + row * 2) = (bf16_t)(o[e >> 1] >> (16 * (e & 1)));
         } else {
-          *(u32x2*)(smem + EPV0 + row * EPV_LD + vi * 2) = o;
+          *(u32x2*)(smem + EPV0 + row * EPV_LD + (col - v_lo) * 2) = o;
         }
       } else {
         *(u32x2*)(smem + row * EP_LD + col * 2) = o;
@@ -812,7 +761,7 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
       // scale, RoPE on the interleaved pairs with the token's f32 (cos, sin) row; qknorm_rope8 (common.h) is the one definition
       // the pre-pass kernels of norm.hip use too: same bits as GEMM + pre-pass.  A head whose scale is NULL leaves as it is, and
       // so do the 64 columns of a 128-wide tile that are not its V run.
-      const int t = n0 / 192;                            // the 192-block the tile's V columns (and, BN == 192, the head) belong to
+      const int t = (n0 + v_lo) / 192;                   // the 192-block the V run (and, BN == 192, the head) belongs to
       const bf16_t* __restrict__ hsc = BN == 192 ? (const bf16_t*)(t < knH ? P.qn_scale : P.kn_scale) : nullptr;
       const float post = (t < knH && P.qn_prescale) ? VC_QK_PRESCALE : 1.0f;
       float g[8] = {};
@@ -821,60 +770,31 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
 #pragma unroll
         for (int e = 0; e < 4; ++e) { g[2 * e] = lo_bf(sw[e]); g[2 * e + 1] = hi_bf(sw[e]); }
       }
-      if (hsc) {
-        // every chunk of this thread first requests its LDS row piece and the token's (cos, sin) values, then the arithmetic runs
-        // over chunks whose operands are in flight together (one iteration at a time the loop was a chain of L2 round trips:
-        // 9 k of the 13 k ticks of pass 2, tools/qkv_epilogue_phases.py)
-        constexpr int NCH = (BM * 16 + NT - 1) / NT, GRP = 3;      // in groups of 3 chunks (36 operand registers: no spill at 168)
-#pragma unroll
-        for (int g0 = 0; g0 < NCH; g0 += GRP) {
-          u32x4 tw[GRP];
-          f32x4 r0[GRP], r1[GRP];
-#pragma unroll
-          for (int k = 0; k < GRP; ++k) {
-            int c = etid + (g0 + k) * NT;
-            if (g0 + k >= NCH || c >= BM * 16) c = etid;      // (a whole 16-lane group at a time: NT and BM * 16 are multiples of 16)
-            const int row = c >> 4, sub = c & 15;
-            const int m = min(m0 + row, M - 1);
-            tw[k] = *(const u32x4*)(smem + row * EPH_LD + sub * 16);
-            const int b = m / P.vt_rpb;
-            const float* rp = P.kn_rope + (long)b * P.kn_rope_bstride + (long)(P.vt_row0 + (m - b * P.vt_rpb)) * 128 + sub * 8;
-            r0[k] = *(const f32x4*)rp;
-            r1[k] = *(const f32x4*)(rp + 4);
-          }
-#pragma unroll
-          for (int k = 0; k < GRP; ++k) {
-            const int c = etid + (g0 + k) * NT;
-            const bool live = g0 + k < NCH && c < BM * 16;
-            const int row = (live ? c : etid) >> 4, sub = c & 15;
-            const int m = min(m0 + row, M - 1);
-            const float cs[8] = {r0[k][0], r0[k][1], r0[k][2], r0[k][3], r1[k][0], r1[k][1], r1[k][2], r1[k][3]};
-            const u32x4 o = qknorm_rope8(tw[k], g, cs, post);
-            const long crow = P.c_rpb > 0 ? (long)(m / P.c_rpb) * P.c_bstride + (long)(m % P.c_rpb) * P.ldc : (long)m * P.ldc;
-            if (live && m0 + row < M) *(u32x4*)(C + crow + 128 * t + sub * 8) = o;
-          }
+      for (int c = etid; c < BM * 16; c += NT) {          // NT % 16 == 0: a row's 16 lanes stay together
+        const int row = c >> 4, sub = c & 15;
+        if (BN == 128 && sub * 8 >= v_lo && sub * 8 < v_lo + 64) continue;      // (never with a head to normalise)
+        const int m = min(m0 + row, M - 1);
+        u32x4 o = *(const u32x4*)(smem + row * EPH_LD + sub * 16);
+        if (hsc) {
+          const int b = m / P.vt_rpb;
+          const float* rp = P.kn_rope + (long)b * P.kn_rope_bstride + (long)(P.vt_row0 + (m - b * P.vt_rpb)) * 128 + sub * 8;
+          const f32x4 c0 = *(const f32x4*)rp;
+          const f32x4 c1 = *(const f32x4*)(rp + 4);
+          const float cs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+          o = qknorm_rope8(o, g, cs, post);
         }
-      } else {
-        for (int c = etid; c < BM * 16; c += NT) {
-          const int row = c >> 4, sub = c & 15;
-          if (BN == 128 && v_index(sub * 8) >= 0) continue;          // (a V chunk: it left transposed)
-          const int m = m0 + row;
-          if (m >= M) continue;
-          const long crow = P.c_rpb > 0 ? (long)(m / P.c_rpb) * P.c_bstride + (long)(m % P.c_rpb) * P.ldc : (long)m * P.ldc;
-          *(u32x4*)(C + crow + qkv_col(n0 + sub * 8)) = *(const u32x4*)(smem + row * EPH_LD + sub * 16);
-        }
+        const long crow = P.c_rpb > 0 ? (long)(m / P.c_rpb) * P.c_bstride + (long)(m % P.c_rpb) * P.ldc : (long)m * P.ldc;
+        if (m0 + row < M) *(u32x4*)(C + crow + qkv_col(n0 + sub * 8)) = o;
       }
-      // the tile's V columns: 64 t + index; a 128-wide tile holds indices 0..31 (it starts its block), 32..63 (it starts at block
-      // column 128) or all 64 (block column 64)
+      // the V run: V columns 64 t .. 64 t + 63
       bf16_t* __restrict__ vtp = (bf16_t*)P.vt;
       if (vfast) {         // a lane moves 8 consecutive tokens of one V column = 16 B of one vt row
         constexpr int CPRT = BM / 8;
-        const int v_first = BN == 128 && blk0 == 128 ? 32 : 0, v_end = BN == 128 && blk0 == 0 ? 32 : 64;
 #pragma unroll 2
         for (int c = etid; c < 64 * CPRT; c += NT) {
           const int trow = c / CPRT, cc = c % CPRT;
           const int m = m0 + cc * 8;
-          if (m >= M || trow < v_first || trow >= v_end) continue;
+          if (m >= M) continue;
           const u32x4 tw = *(const u32x4*)(smem + EPV0 + trow * EPT_LD + cc * 16);
           const int b = m / P.vt_rpb;
           bf16_t* d = vtp + (long)b * P.vt_bstride + (long)(64 * t + trow) * P.vt_lpad + P.vt_row0 + (m - b * P.vt_rpb);

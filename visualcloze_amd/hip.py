@@ -234,20 +234,13 @@ def _bf16(t: torch.Tensor, name: str) -> None:
 # op wrappers (2-D row-major views; the last dim must be contiguous)
 # ------------------------------------------------------------------------------------------------
 def qkv_head_permutation(H: int) -> torch.Tensor:
-    """Row order of a HEAD-PERMUTED qkv weight [3 * 128 * H, K] (VcGemmProblem.kn_heads): 2H blocks of 192 rows = [head t rows 0..63 |
-    V rows 64 t .. 64 t + 31 | head t rows 64..127 | V rows 64 t + 32 .. 64 t + 63] (head t = query head t for t < H, key head t - H
-    after) - every 192-column GEMM tile then holds one whole query or key head (QKNorm + RoPE in its epilogue) and half a value
-    head, 64 head + 32 V columns in each of its two wave columns.  perm[p] = the original row."""
+    """Row order of a HEAD-PERMUTED qkv weight [3 * 128 * H, K] (VcGemmProblem.kn_heads): 2H blocks of 192 rows = [head t (128
+    rows: query head t for t < H, key head t - H after) | V rows 64 t .. 64 t + 63] - every 192-column GEMM tile then holds one
+    whole query or key head (QKNorm + RoPE in its epilogue) and half a value head.  perm[p] = the original row."""
     D = 128 * H
     idx = []
-    if os.environ.get("VC_QKV_LAYOUT") == "1":      # A/B runs against a library BUILD of round 5's first layout ([head 128 | V 64] per block)
-        for t in range(2 * H):
-            idx += list(range(128 * t, 128 * t + 128)) + list(range(2 * D + 64 * t, 2 * D + 64 * t + 64))
-        return torch.tensor(idx, dtype=torch.long)
     for t in range(2 * H):
-        for half in range(2):
-            idx += list(range(128 * t + 64 * half, 128 * t + 64 * half + 64))
-            idx += list(range(2 * D + 64 * t + 32 * half, 2 * D + 64 * t + 32 * half + 32))
+        idx += list(range(128 * t, 128 * t + 128)) + list(range(2 * D + 64 * t, 2 * D + 64 * t + 64))
     return torch.tensor(idx, dtype=torch.long)
 
 

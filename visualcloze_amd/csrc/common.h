@@ -60,8 +60,12 @@ VC_DEV float silu_f(float x) {
 // QKNorm (layers.py:63-84: x * rsqrt(mean(x^2) + 1e-6) -> bf16, * scale -> bf16) and RoPE on the interleaved pairs
 // (math.py:112-117) of the 8 consecutive elements a lane owns of a 128-wide head row; the row's 16 lanes are neighbours
 // (lane & 15 = position in the row).  ONE definition for the pre-pass kernels (norm.hip) and the qkv GEMM's epilogue
-// (gemm.hip), with floating-point contraction OFF: every product and sum is rounded as written (what torch's separate
-// mul / add kernels do), so the call sites give the same bits whatever the compiler would fuse around them.
+// (gemm.hip), with floating-point contraction OFF and every fused multiply-add WRITTEN OUT: the call sites give the same bits
+// whatever the compiler would fuse around them.  In the GEMM's epilogue this function is VALU-bound (12 waves per CU, 5.3
+// chunks per lane and tile: tools/qkv_epilogue_phases.py), so it is written for instruction count (round 5): the sum of squares
+// and the rotation as explicit FMAs, rsqrt as the hardware's v_rsq_f32 (1 ulp; torch.rsqrt is no IEEE division either) - 96
+// instead of 130 instructions per chunk.  Its rounding POINTS are the reference's: (x * rrms) -> bf16, * scale -> bf16, the
+// rotated value -> bf16.
 //
 // `post` multiplies the rotated value before its ONE rounding to bf16: 1.0f (exact: the reference's q / k) or VC_QK_PRESCALE,
 // the softmax scale 128^-0.5 * log2(e) folded into the QUERY rows, which the one-wave-per-SIMD attention kernel then loads
@@ -72,19 +76,20 @@ VC_DEV u32x4 qknorm_rope8(const u32x4 w, const float (&g)[8], const float (&cs)[
   float x[8];
 #pragma unroll
   for (int e = 0; e < 4; ++e) { x[2 * e] = lo_bf(w[e]); x[2 * e + 1] = hi_bf(w[e]); }
-  float ss = 0.f;
+  float ss = x[0] * x[0];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) ss += x[e] * x[e];
+  for (int e = 1; e < 8; ++e) ss = __builtin_fmaf(x[e], x[e], ss);
 #pragma unroll
   for (int o = 1; o < 16; o <<= 1) ss += __shfl_xor(ss, o, 64);
-  const float rrms = 1.0f / sqrtf(ss * (1.0f / 128.0f) + 1e-6f);
+  const float rrms = __builtin_amdgcn_rsqf(__builtin_fmaf(ss, 1.0f / 128.0f, 1e-6f));
 #pragma unroll
   for (int e = 0; e < 8; ++e) x[e] = rbf(rbf(x[e] * rrms) * g[e]);
   u32x4 o;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const float co = cs[2 * e], si = cs[2 * e + 1];
-    o[e] = pack2bf((co * x[2 * e] - si * x[2 * e + 1]) * post, (si * x[2 * e] + co * x[2 * e + 1]) * post);
+    const float re = __builtin_fmaf(co, x[2 * e], -(si * x[2 * e + 1])), im = __builtin_fmaf(si, x[2 * e], co * x[2 * e + 1]);
+    o[e] = pack2bf(re * post, im * post);
   }
   return o;
 }

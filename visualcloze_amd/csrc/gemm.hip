@@ -663,38 +663,73 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
     v_lo = __builtin_amdgcn_readfirstlane(v_lo);
   }
   const bf16_t* __restrict__ bias = (const bf16_t*)P.bias;
+  // The staging form is decided ONCE, outside the unrolled (i, j) loops: KIND and the wave's first V block JV0 are compile-time
+  // inside `stage`.  (Decided per accumulator block - vkind, vfast and the column test as run-time branches inside the loops -
+  // pass 1 of the qkv tiles was a maze of ~6 scalar branches per block, 24 blocks per lane: 9.8 k ticks against 2.8 k for the
+  // plain epilogue, tools/qkv_epilogue_phases.py.)
+  //   KIND 0 row-major [BM][EP_LD]     1 transposed [BN][EPT_LD] (natural-order V tile)
+  //        2 head-permuted tile, V run transposed (vfast)     3 head-permuted tile, V run row-major [BM][EPV_LD]
+  //   blocks j >= JV0 of this wave are the tile's V columns (KIND 2 / 3; NI = none)
+  auto stage = [&](auto KIND, auto JV0c) {
+    constexpr int KD = decltype(KIND)::value, JV0 = decltype(JV0c)::value;
 #pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    if (PP == 2 && wave >= NCW) break;   // loader waves hold no accumulators
-    const int row = wm * TM + i * 16 + efr;
+    for (int i = 0; i < MI; ++i) {
+      const int row = wm * TM + i * 16 + efr;
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int col = wn * TN + j * 16 + efq * 4;
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      if (PP == 2) {
-        // bias already in the accumulators
-      } else if (bias && n0 + col < N) {
-        const u32x2 bb = *(const u32x2*)(bias + n0 + col);
-        v[0] += lo_bf(bb[0]); v[1] += hi_bf(bb[0]); v[2] += lo_bf(bb[1]); v[3] += hi_bf(bb[1]);
-      }
-      u32x2 o;
-      o[0] = pack2bf(v[0], v[1]);
-      o[1] = pack2bf(v[2], v[3]);
-      if (EPI == VC_EPI_QKV && vkind == 1) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) *(bf16_t*)(smem + (col + e) * EPT_LD + row * 2) = (bf16_t)(o[e >> 1] >> (16 * (e & 1)));
-      } else if (MIXED && vkind == 4) {
-        if (col < v_lo || col >= v_lo + 64) {
-          *(u32x2*)(smem + row * EPH_LD + col * 2) = o;
-        } else if (vfast) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) *(bf16_t*)(smem + EPV0 + (col - v_lo + e) * EPT_LD + row * 2) = (bf16_t)(o[e >> 1] >> (16 * (e & 1)));
-        } else {
-          *(u32x2*)(smem + EPV0 + row * EPV_LD + (col - v_lo) * 2) = o;
+      for (int j = 0; j < NI; ++j) {
+        const int col = wn * TN + j * 16 + efq * 4;
+        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        if (PP == 2) {
+          // bias already in the accumulators
+        } else if (bias && n0 + col < N) {
+          const u32x2 bb = *(const u32x2*)(bias + n0 + col);
+          v[0] += lo_bf(bb[0]); v[1] += hi_bf(bb[0]); v[2] += lo_bf(bb[1]); v[3] += hi_bf(bb[1]);
         }
-      } else {
-        *(u32x2*)(smem + row * EP_LD + col * 2) = o;
+        u32x2 o;
+        o[0] = pack2bf(v[0], v[1]);
+        o[1] = pack2bf(v[2], v[3]);
+        if constexpr (KD == 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) *(bf16_t*)(smem + (col + e) * EPT_LD + row * 2) = (bf16_t)(o[e >> 1] >> (16 * (e & 1)));
+        } else if constexpr (KD >= 2) {
+          if (j < JV0) {
+            *(u32x2*)(smem + row * EPH_LD + col * 2) = o;
+          } else if constexpr (KD == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) *(bf16_t*)(smem + EPV0 + (col - v_lo + e) * EPT_LD + row * 2) = (bf16_t)(o[e >> 1] >> (16 * (e & 1)));
+          } else {
+            *(u32x2*)(smem + EPV0 + row * EPV_LD + (col - v_lo) * 2) = o;
+          }
+        } else {
+          *(u32x2*)(smem + row * EP_LD + col * 2) = o;
+        }
       }
+    }
+  };
+  using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
+  using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
+  using JN = std::integral_constant<int, NI>; using J0 = std::integral_constant<int, 0>;
+  using J2 = std::integral_constant<int, (NI > 2 ? 2 : 0)>;
+  if (!(PP == 2 && wave >= NCW)) {     // loader waves hold no accumulators
+    if constexpr (MIXED) {
+      if (vkind == 4) {
+        // a wave's TN columns are whole 16-column blocks on one side of the V run or the other: 192-wide tiles (TN = 96) put the
+        // run [128, 192) into blocks j >= 2 of the wn = 1 waves; 128-wide tiles (TN = 64) give one wave column the whole run
+        static_assert(TN == (BN == 192 ? 96 : 64), "the V run must start on a block boundary of one wave column");
+        const bool v_wave = BN == 192 ? wn == 1 : wn * TN == v_lo;
+        if (!v_wave) stage(K2{}, JN{});
+        else if (BN == 192) { if (vfast) stage(K2{}, J2{}); else stage(K3{}, J2{}); }
+        else stage(K2{}, J0{});           // (128-wide tiles take vkind 4 only with vfast)
+      } else if (vkind == 1) {
+        stage(K1{}, JN{});
+      } else {
+        stage(K0{}, JN{});
+      }
+    } else if constexpr (EPI == VC_EPI_QKV) {
+      if (vkind == 1) stage(K1{}, JN{});
+      else stage(K0{}, JN{});
+    } else {
+      stage(K0{}, JN{});
     }
   }
   if constexpr (PERSIST) {

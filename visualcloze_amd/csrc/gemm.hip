@@ -797,6 +797,24 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
       // the pre-pass kernels of norm.hip use too: same bits as GEMM + pre-pass.  A head whose scale is NULL leaves as it is, and
       // so do the 64 columns of a 128-wide tile that are not its V run.
       const int t = (n0 + v_lo) / 192;                   // the 192-block the V run (and, BN == 192, the head) belongs to
+      // Batch element of a tile row WITHOUT a division per row: with rows-per-batch >= BM a tile meets at most one batch edge, so
+      // the index is the tile's first (one scalar division) + (row beyond the edge).  (m / vt_rpb, m / c_rpb and m % c_rpb per
+      // 16-B chunk were ~70 of the ~170 vector instructions of a chunk in this VALU-bound pass.)
+      struct RowSplit { int rpb, lo, edge; bool fast; };
+      auto split_of = [&](int rpb) {
+        RowSplit r;
+        r.rpb = rpb; r.fast = rpb >= BM;
+        r.lo = rpb > 0 ? __builtin_amdgcn_readfirstlane(m0 / rpb) : 0;
+        r.edge = (r.lo + 1) * rpb;
+        return r;
+      };
+      auto batch_of = [&](const RowSplit& r, int m) { return r.fast ? r.lo + (m >= r.edge ? 1 : 0) : m / r.rpb; };
+      const RowSplit vsp = split_of(P.vt_rpb), csp = split_of(P.c_rpb);
+      auto c_row = [&](int m) -> long {                  // element offset of C's row m (batch-strided rows: see VcGemmProblem)
+        if (P.c_rpb <= 0) return (long)m * P.ldc;
+        const int b = batch_of(csp, m);
+        return (long)b * P.c_bstride + (long)(m - b * P.c_rpb) * P.ldc;
+      };
       const bf16_t* __restrict__ hsc = BN == 192 ? (const bf16_t*)(t < knH ? P.qn_scale : P.kn_scale) : nullptr;
       const float post = (t < knH && P.qn_prescale) ? VC_QK_PRESCALE : 1.0f;
       float g[8] = {};
@@ -811,15 +829,15 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
         const int m = min(m0 + row, M - 1);
         u32x4 o = *(const u32x4*)(smem + row * EPH_LD + sub * 16);
         if (hsc) {
-          const int b = m / P.vt_rpb;
+          const int b = batch_of(vsp, m);
           const float* rp = P.kn_rope + (long)b * P.kn_rope_bstride + (long)(P.vt_row0 + (m - b * P.vt_rpb)) * 128 + sub * 8;
           const f32x4 c0 = *(const f32x4*)rp;
           const f32x4 c1 = *(const f32x4*)(rp + 4);
           const float cs[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
           o = qknorm_rope8(o, g, cs, post);
         }
-        const long crow = P.c_rpb > 0 ? (long)(m / P.c_rpb) * P.c_bstride + (long)(m % P.c_rpb) * P.ldc : (long)m * P.ldc;
-        if (m0 + row < M) *(u32x4*)(C + crow + qkv_col(n0 + sub * 8)) = o;
+        // (192-wide tile: the chunk is 8 columns of head t; a 128-wide one maps its chunk through the general formula)
+        if (m0 + row < M) *(u32x4*)(C + c_row(m) + (BN == 192 ? 128 * t + sub * 8 : qkv_col(n0 + sub * 8))) = o;
       }
       // the V run: V columns 64 t .. 64 t + 63
       bf16_t* __restrict__ vtp = (bf16_t*)P.vt;
@@ -831,7 +849,7 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
           const int m = m0 + cc * 8;
           if (m >= M) continue;
           const u32x4 tw = *(const u32x4*)(smem + EPV0 + trow * EPT_LD + cc * 16);
-          const int b = m / P.vt_rpb;
+          const int b = batch_of(vsp, m);
           bf16_t* d = vtp + (long)b * P.vt_bstride + (long)(64 * t + trow) * P.vt_lpad + P.vt_row0 + (m - b * P.vt_rpb);
           if (m + 8 <= M) {
             *(u32x4*)d = tw;               // vt_rpb % 8 == 0 and m % 8 == 0: the 8 tokens share a batch element

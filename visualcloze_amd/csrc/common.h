@@ -57,6 +57,12 @@ VC_DEV float silu_f(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
 
+// the value of another lane of the same 16-lane row, selected by a DPP control (folded into the consuming VALU instruction)
+template <int CTRL>
+VC_DEV float dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
 // QKNorm (layers.py:63-84: x * rsqrt(mean(x^2) + 1e-6) -> bf16, * scale -> bf16) and RoPE on the interleaved pairs
 // (math.py:112-117) of the 8 consecutive elements a lane owns of a 128-wide head row; the row's 16 lanes are neighbours
 // (lane & 15 = position in the row).  ONE definition for the pre-pass kernels (norm.hip) and the qkv GEMM's epilogue
@@ -79,8 +85,13 @@ VC_DEV u32x4 qknorm_rope8(const u32x4 w, const float (&g)[8], const float (&cs)[
   float ss = x[0] * x[0];
 #pragma unroll
   for (int e = 1; e < 8; ++e) ss = __builtin_fmaf(x[e], x[e], ss);
-#pragma unroll
-  for (int o = 1; o < 16; o <<= 1) ss += __shfl_xor(ss, o, 64);
+  // the row's 16 lanes: an xor butterfly (every lane ends with the same bits) as four DPP adds - lanes ^1 and ^2 by quad_perm,
+  // then, all four lanes of a quad being equal, ^4 = row_half_mirror and ^8 = row_mirror.  (__shfl_xor compiles to
+  // ds_bpermute_b32: four dependent LDS round trips per chunk in a loop that runs 5 chunks per lane and tile.)
+  ss += dpp_f32<0xB1>(ss);      // quad_perm [1, 0, 3, 2]
+  ss += dpp_f32<0x4E>(ss);      // quad_perm [2, 3, 0, 1]
+  ss += dpp_f32<0x141>(ss);     // row_half_mirror
+  ss += dpp_f32<0x140>(ss);     // row_mirror
   const float rrms = __builtin_amdgcn_rsqf(__builtin_fmaf(ss, 1.0f / 128.0f, 1e-6f));
 #pragma unroll
   for (int e = 0; e < 8; ++e) x[e] = rbf(rbf(x[e] * rrms) * g[e]);

@@ -42,6 +42,7 @@ struct Buffers {   // the workspace carve-up
   void* ATT_SCRATCH = nullptr;
   int64_t att_scratch_bytes = 0;
   void* SK_WS = nullptr;               // f32 partial tiles of split-K GEMM remainders (VcGemmArgs.splitk_ws)
+  int64_t sk_ws_bytes = 0;
 };
 
 struct Flux : Buffers {
@@ -136,7 +137,11 @@ int64_t carve(Buffers& f, const Flux& g, char* base, int B, int T, int N, int S)
   f.STEP = c.take<int32_t>(1);               f.KVLEN = c.take<int32_t>(B);  f.KVGAP = c.take<int32_t>(2 * B);
   f.att_scratch_bytes = vc_attention_scratch_bytes_impl();
   f.ATT_SCRATCH = c.take<char>(f.att_scratch_bytes);
-  f.SK_WS = c.take<char>(VC_GEMM_SPLITK_WS_BYTES);
+  // one split-K scratch serves every geometry of a handle (all its launches are ordered on one stream): a caller-bound one
+  // ("splitk_ws", vc_flux_bind_weight) keeps the 100 MB out of every cached workspace (advisor r04); without it, it is carved here
+  auto sk = g.bound.find("splitk_ws");
+  if (sk != g.bound.end()) { f.SK_WS = const_cast<void*>(sk->second.w); f.sk_ws_bytes = (int64_t)sk->second.N * sk->second.K * 4; }
+  else { f.SK_WS = c.take<char>(VC_GEMM_SPLITK_WS_BYTES); f.sk_ws_bytes = VC_GEMM_SPLITK_WS_BYTES; }
   return c.off;
 }
 
@@ -252,7 +257,7 @@ int gemm(Flux& f, const VcGemmProblem* ps, int n, int epi, const int32_t* step_p
   memset(&a, 0, sizeof(a));
   for (int i = 0; i < n; ++i) a.p[i] = ps[i];
   a.nprob = n; a.epi = epi; a.step_ptr = step_ptr; a.gate_step_stride = gate_step_stride;
-  if (f.splitk) { a.splitk_ws = f.SK_WS; a.splitk_ws_bytes = VC_GEMM_SPLITK_WS_BYTES; }   // the launcher's cost model decides
+  if (f.splitk) { a.splitk_ws = f.SK_WS; a.splitk_ws_bytes = f.sk_ws_bytes; }   // the launcher's cost model decides
   return vc_gemm_launch(a, f.tile_cfg, s, e.buf, e.len);
 }
 int lin(Flux& f, const Lin& w, const void* A, int64_t lda, void* C, int64_t ldc, int M, int epi, hipStream_t s, Err e) {

@@ -86,6 +86,11 @@ class FluxHandle:
         self._bind("modulation", weights.mod_w, weights.mod_b, *weights.mod_w.shape)
         hip._check(L.vc_flux_bind_weight(self.h, b"timestep_freqs", weights.temb_freqs.data_ptr(), None, 1, 128, 128),
                    "vc_flux_bind_weight(timestep_freqs)")      # torch's own f32 table: bit-equal to the Python-ordered plan
+        # ONE split-K scratch for every geometry of this handle (its launches are ordered on one stream), instead of 100 MB carved
+        # into each of the up to nine cached workspaces (advisor r04)
+        self._sk_ws = hip.splitk_workspace(dev)
+        nf = self._sk_ws.numel() // 4
+        hip._check(L.vc_flux_bind_weight(self.h, b"splitk_ws", self._sk_ws.data_ptr(), None, 1, nf, nf), "vc_flux_bind_weight(splitk_ws)")
         self._ws: Dict[tuple, torch.Tensor] = {}
         self._opts: Dict[str, int] = {}
         self.geom: Optional[Tuple[int, int, int, int]] = None

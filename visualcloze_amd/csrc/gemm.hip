@@ -598,6 +598,13 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
   // twice inside pass 2 (pass 2 was 10.6 k cycles per block against 2.7 k for the plain epilogue) ----
   constexpr int CPR = BN / 8;  // 16-B chunks per tile row
   constexpr int P2_IT = (BM * CPR + NT - 1) / NT;
+  // pass 2 walks chunks c = etid + it * NT; where NT is a multiple of CPR (every product tile: 768 = 32 * 24 = 48 * 16) the
+  // iterations of a thread are ROW_STEP rows apart in ONE 16-B column, so (row, column) need one division per thread, not one per
+  // iteration, and C's row offset advances by a constant (the index arithmetic was ~25 of the ~150 instructions of an iteration
+  // of this VALU-bound loop)
+  constexpr bool STEP_ROWS = NT % CPR == 0;
+  constexpr int ROW_STEP = NT / CPR;
+  const int row_first = etid / CPR, cc_first = etid - row_first * CPR;
   constexpr bool PREF = PP == 2 && EPI == VC_EPI_GATE_RES && NT % CPR == 0;
   u32x4 rr_pre[PREF ? P2_IT : 1], gg_pre = {0u, 0u, 0u, 0u};
   int gg_batch = -1;
@@ -609,17 +616,17 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
   auto gate_batch = [&](int m) { return P.rows_per_batch >= BM ? gb_lo + (m >= gb_edge ? 1 : 0) : m / P.rows_per_batch; };
   if constexpr (PREF) {
     const bf16_t* __restrict__ res = (const bf16_t*)P.res;
-    const int n = n0 + (etid % CPR) * 8;
+    const int n = n0 + cc_first * 8;
 #pragma unroll
     for (int it = 0; it < P2_IT; ++it) {
-      const int m = m0 + (etid + it * NT) / CPR;
+      const int m = m0 + (STEP_ROWS ? row_first + it * ROW_STEP : (etid + it * NT) / CPR);
       rr_pre[it] = u32x4{0u, 0u, 0u, 0u};
       if (m < M && n < N && (etid + it * NT) < BM * CPR) {
         const long rrow = P.c_rpb > 0 ? (long)(m / P.c_rpb) * P.c_bstride + (long)(m % P.c_rpb) * P.ldc : (long)m * P.ldres;
         rr_pre[it] = *(const u32x4*)(res + rrow + n);
       }
     }
-    const int mf = m0 + etid / CPR;
+    const int mf = m0 + row_first;
     if (mf < M && n < N) {
       gg_batch = gate_batch(mf);
       gg_pre = *(const u32x4*)((const bf16_t*)P.gate + gate_step + (long)gg_batch * P.gate_bstride + n);
@@ -880,14 +887,16 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
       return;
     }
   }
+  const long crow_first = (long)(m0 + row_first) * P.ldc, crow_step = (long)ROW_STEP * P.ldc;
 #pragma unroll PREF ? P2_IT : 4
   for (int it = 0; it < (PREF ? P2_IT : BM * CPR); ++it) {
     const int c = etid + it * NT;
     if ((!PREF || BM * CPR % NT != 0) && c >= BM * CPR) break;
-    const int row = c / CPR, cc = c % CPR;
+    const int row = STEP_ROWS ? row_first + it * ROW_STEP : c / CPR, cc = STEP_ROWS ? cc_first : c % CPR;
     const int m = m0 + row, n = n0 + cc * 8;
     if (m >= M || n >= N) continue;
-    const long crow = P.c_rpb > 0 ? (long)(m / P.c_rpb) * P.c_bstride + (long)(m % P.c_rpb) * P.ldc : (long)m * P.ldc;
+    const long crow = P.c_rpb > 0 ? (long)(m / P.c_rpb) * P.c_bstride + (long)(m % P.c_rpb) * P.ldc
+                                  : (STEP_ROWS ? crow_first + it * crow_step : (long)m * P.ldc);
     const u32x4 tw = *(const u32x4*)(smem + row * EP_LD + cc * 16);
     float v[8];
 #pragma unroll

@@ -333,3 +333,82 @@ def test_board_sampler_reads_hwmon_nodes(tmp_path):
     with BoardSampler(None, root=str(tmp_path / "nothing")) as b:
         pass
     assert b.summary()["source"] == "unavailable"
+
+
+def test_qkv_head_permutation_layout():
+    """hip.qkv_head_permutation (VcGemmProblem.kn_heads): a bijection of the 3 * 128 * H qkv rows whose every 192-row block is one whole
+    query or key head followed by 64 V rows - the layout the qkv GEMM's epilogue relies on (one head to normalise per 192-column
+    tile, half a value head to transpose), and its inverse is the `qkv_col` map of csrc/gemm.hip."""
+    from visualcloze_amd import hip
+    for H in (1, 2, 3, 24):
+        D = 128 * H
+        perm = hip.qkv_head_permutation(H).tolist()
+        assert sorted(perm) == list(range(3 * D))
+        for t in range(2 * H):
+            blk = perm[192 * t:192 * t + 192]
+            assert blk[:128] == list(range(128 * t, 128 * t + 128))              # q head t (t < H) or k head t - H: logical columns 128 t ...
+            assert blk[128:] == list(range(2 * D + 64 * t, 2 * D + 64 * t + 64))  # V columns 64 t ... 64 t + 63
+        # the device-side map permuted column -> logical column (gemm.hip: qkv_col)
+        def qkv_col(n):
+            t, j = divmod(n, 192)
+            return 128 * t + j if j < 128 else 256 * H + 64 * t + j - 128
+        assert [qkv_col(p) for p in range(3 * D)] == perm
+
+
+def test_stream_remainder_partition_properties():
+    """The stream form of the split-K remainder (VcGemmArgs.sk_stream; csrc/gemm.hip): n work items share I = rem * nk K-iterations,
+    item p owning [p I / n, (p + 1) I / n).  Restated here as the device code computes it - the writer's (tile, k range, slot) per
+    segment and the reducer's piece list per tile - and checked for what correctness needs: every iteration of every tile is
+    covered exactly once, an item has at most two segments (n >= rem), the reducer enumerates exactly the slots the writers
+    filled, in K order, the first piece starting at K = 0 (it carries the bias), and at most three pieces per tile where the
+    launcher takes the form by itself (rem > n / 2)."""
+    import random
+
+    def writer(p, rem, nk, n):
+        I = rem * nk
+        it, end, seg, out = p * I // n, (p + 1) * I // n, 0, []
+        while it < end:
+            t = it // nk
+            k0, k1 = it - t * nk, min(nk, end - t * nk)
+            out.append((t, k0, k1, 2 * p + seg))
+            it += k1 - k0
+            seg += 1
+        return out
+
+    def reducer(r, rem, nk, n):
+        I = rem * nk
+        it0 = lambda q: q * I // n  # noqa: E731
+        u0, u1 = r * nk, (r + 1) * nk
+        q = u0 * n // I
+        while q > 0 and it0(q) > u0:
+            q -= 1
+        while q + 1 < n and it0(q + 1) <= u0:
+            q += 1
+        slots = []
+        while q < n and it0(q) < u1:
+            b = it0(q)
+            if b != it0(q + 1):
+                slots.append(2 * q + (0 if b // nk == r else 1))
+            q += 1
+        return slots
+
+    rng = random.Random(5)
+    cases = [(160, 192, 256), (160, 240, 256), (208, 192, 256), (176, 240, 256), (4, 64, 21), (24, 32, 64), (33, 25, 68), (1, 4, 1), (240, 48, 256)]
+    cases += [(rem, nk, n) for rem, nk, n in ((rng.randint(1, 256), rng.randint(1, 240), 0) for _ in range(200))]
+    for rem, nk, n in cases:
+        if n == 0:
+            n = rng.randint(rem, max(rem, min(256, rem * nk)))
+        segs = {}
+        for p in range(n):
+            w = writer(p, rem, nk, n)
+            assert len(w) <= 2, (rem, nk, n, p, w)
+            for t, k0, k1, slot in w:
+                assert 0 <= t < rem and 0 <= k0 < k1 <= nk
+                segs.setdefault(t, []).append((k0, k1, slot))
+        for r in range(rem):
+            pieces = sorted(segs[r])
+            assert pieces[0][0] == 0 and pieces[-1][1] == nk                      # covered from K = 0 to the end ...
+            assert all(a[1] == b[0] for a, b in zip(pieces, pieces[1:]))          # ... without gap or overlap
+            assert reducer(r, rem, nk, n) == [s for _, _, s in pieces], (rem, nk, n, r)     # the reducer's list = the writers' slots, in K order
+            if 2 * rem > n:
+                assert len(pieces) <= 3

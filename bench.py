@@ -478,6 +478,9 @@ def timed_region(job, steps, warmup, barrier=None, max_over_ranks=None, board=No
     t0 = time.perf_counter()
     for _ in range(steps):
         job.step()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    timed_region.own_elapsed = time.perf_counter() - t0     # this rank's own K steps, before it waits for the others (`per_rank`)
     barrier()                                       # synchronize + barrier + synchronize
     elapsed = time.perf_counter() - t0
     if board is not None:
@@ -485,8 +488,9 @@ def timed_region(job, steps, warmup, barrier=None, max_over_ranks=None, board=No
     return (max_over_ranks or par.max_over_ranks)(elapsed)
 
 
-def result_record(a, wl, world, elapsed, T, N, bcast_s, weight_bytes):
-    """The ONE JSON line of the contract (rank 0 adds roofline / cpu_baseline)."""
+def result_record(a, wl, world, elapsed, T, N, bcast_s, weight_bytes, rccl_ranks=0):
+    """The ONE JSON line of the contract (rank 0 adds roofline / cpu_baseline).  `rccl_ranks` is what RCCL itself counted
+    (parallel.rccl_rank_count: an all-reduce of ones over the "nccl" communicator; 0 = no RCCL communicator in this run)."""
     PB = a.per_gpu_batch
     lin, attn = flops_per_eval(T, N)
     value = world * PB * a.steps / elapsed          # a replay advances PB grids by one solver step each
@@ -502,11 +506,22 @@ def result_record(a, wl, world, elapsed, T, N, bcast_s, weight_bytes):
         "model_tflops_per_eval": round((lin + attn) / 1e12, 2),
         "achieved_model_tflops_per_gpu": round((lin + attn) / 1e12 * value / world, 1),
         "per_gpu_batch": PB,
-        "rccl_ranks": world,
+        "rccl_ranks": rccl_ranks,
         "weight_broadcast_s": round(bcast_s, 3),
         "weight_broadcast_gbps": round(weight_bytes / bcast_s / 1e9, 1) if bcast_s > 0 else None,
     }
     return rec
+
+
+def rank_record(rank, local, a, own_elapsed, board=None, numa=None, device=None):
+    """What every rank contributes to the line's `per_rank` list: its own rate over its own wall time (the job's `value` uses
+    the slowest rank's), its board's power / shader clock during the timed steps and where it ran - so a throttling GPU that
+    sets max-over-ranks is visible in the one JSON line."""
+    b = board.summary() if board is not None else {}
+    return {"rank": rank, "local_rank": local, "device": device, "numa_node": numa,
+            "steps_per_s": round(a.steps * a.per_gpu_batch / own_elapsed, 4), "elapsed_s": round(own_elapsed, 4),
+            "power_w_avg": b.get("power_w_avg"), "power_cap_w": b.get("power_cap_w"), "sclk_mhz_avg": b.get("sclk_mhz_avg"),
+            "board_source": b.get("source")}
 
 
 def self_launch(a, argv):
@@ -554,7 +569,8 @@ def main(argv=None):
         wl = WORKLOADS[a.workload]
         elapsed = timed_region(StubJob(rank), a.steps, a.warmup)
         N = sum((h // 2) * (w // 2) for h, w in wl["row_latents"])
-        rec = result_record(a, wl, world, elapsed, 512, N, bcast_s=0.0, weight_bytes=0)
+        rec = result_record(a, wl, world, elapsed, 512, N, bcast_s=0.0, weight_bytes=0, rccl_ranks=par.rccl_rank_count())
+        rec["per_rank"] = par.gather_records(rank_record(rank, local, a, timed_region.own_elapsed))
         rec["data"] = "stub engine (driver test, no GPU)"
         rec["stub"] = True                          # NOT a measurement: the timings are time.sleep (advisor r04)
         rec["metric"] = "stub-driver-test"
@@ -568,6 +584,9 @@ def main(argv=None):
     hip.require_gpu()                       # fails loudly: there is no CPU path to fall back to
     if a.device_index is not None:
         local = a.device_index              # (tests: every rank on the same GPU)
+    elif torch.cuda.device_count() < world or local >= torch.cuda.device_count():
+        raise SystemExit(f"--gpus {a.gpus}: this node exposes {torch.cuda.device_count()} GPU(s) to rank {rank} (LOCAL_RANK {local}); "
+                         f"one process per GPU needs {world} (ranks never share a device outside the --device-index tests)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     from visualcloze_amd import parallel as par
@@ -597,7 +616,9 @@ def main(argv=None):
     job = Job(model, x, kw, wl["steps"], t0=wl.get("t0", 0.0), do_shift=wl.get("do_shift", True))
 
     from visualcloze_amd.board import BoardSampler, pci_bus_id_of
-    board = BoardSampler(pci_bus_id_of(local), index=local)       # this rank's GPU: socket power, power cap, shader clock (sysfs hwmon)
+    # every rank samples ITS GPU (socket power, power cap, shader clock; sysfs hwmon) at 10 Hz - one small file read per
+    # 100 ms beside a loop that issues one graph launch per ~50 ms; the rate is in the record (`board.hz`)
+    board = BoardSampler(pci_bus_id_of(local), index=local, hz=10.0)
     with torch.cuda.stream(eng.stream):
         elapsed = timed_region(job, a.steps, a.warmup, max_over_ranks=lambda s: par.max_over_ranks(s, dev), board=board)
     with torch.cuda.stream(eng.stream):
@@ -606,8 +627,9 @@ def main(argv=None):
     assert torch.isfinite(final).all(), "non-finite latent"
 
     T, N = 512, x.shape[1]
-    rec = result_record(a, wl, world, elapsed, T, N, bcast_s, weight_bytes)
+    rec = result_record(a, wl, world, elapsed, T, N, bcast_s, weight_bytes, rccl_ranks=par.rccl_rank_count(dev))
     rec["numa_node"] = numa
+    rec["per_rank"] = par.gather_records(rank_record(rank, local, a, timed_region.own_elapsed, board, numa, pci_bus_id_of(local)))
     rec["hbm_resident_gb"] = round(torch.cuda.memory_allocated(dev) / 1e9, 1)        # merged weights + workspaces while sampling
     rec["hbm_peak_gb"] = round(torch.cuda.max_memory_allocated(dev) / 1e9, 1)        # during the one-time LoRA merge
     if tiny:

@@ -113,8 +113,18 @@ BENCH_WORKER = textwrap.dedent("""
     elapsed = bench.timed_region(job, a.steps, a.warmup)
     assert job.steps == a.steps + a.warmup and job.restarts == 1 and job.first_after_restart == a.warmup
     assert elapsed >= 0.002 * w * a.steps                      # max over ranks: everyone reports the slowest rank's time
-    rec = bench.result_record(a, wl, w, elapsed, 512, x.shape[1], bcast_s=0.5, weight_bytes=26.3e9)
-    assert rec["n_gpus"] == w and rec["rccl_ranks"] == w and rec["scaling"] == "weak"
+    rec = bench.result_record(a, wl, w, elapsed, 512, x.shape[1], bcast_s=0.5, weight_bytes=26.3e9, rccl_ranks=par.rccl_rank_count())
+    assert rec["n_gpus"] == w and rec["scaling"] == "weak"
+    assert rec["rccl_ranks"] == 0                              # a gloo world: RCCL saw no rank, and the record says so
+    per_rank = par.gather_records(bench.rank_record(r, r, a, bench.timed_region.own_elapsed, numa=None))
+    if r == 0:
+        assert [q["rank"] for q in per_rank] == list(range(w))
+        rates = [q["steps_per_s"] for q in per_rank]
+        assert all(x > 0 for x in rates) and rates[0] > rates[-1]          # rank w-1 sleeps longest: the slow rank is visible
+        assert abs(min(q["steps_per_s"] for q in per_rank) * w - rec["value"]) / rec["value"] < 0.25
+        rec["per_rank"] = per_rank
+    else:
+        assert per_rank is None
     assert abs(rec["value"] - w * a.steps / elapsed) < 1e-3 and rec["config"]["parallelism"] == f"dp{w}"
     assert rec["weight_broadcast_gbps"] == 52.6
     # per-rank inputs come from the GLOBAL sample index: distinct across ranks, reproducible without the job
@@ -153,6 +163,7 @@ def test_bench_driver_world8_gloo_stub_engine(tmp_path):
         assert f"rank {r} ok" in o
     rec = json.loads([ln for ln in outs[0].splitlines() if ln.startswith("{")][0])
     assert rec["n_gpus"] == 8 and rec["metric"] == "denoising-steps/sec" and rec["higher_is_better"] is True
+    assert rec["rccl_ranks"] == 0 and len(rec["per_rank"]) == 8
 
 
 def test_bench_bare_gpus_flag_launches_its_own_ranks():
@@ -168,7 +179,9 @@ def test_bench_bare_gpus_flag_launches_its_own_ranks():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout + r.stderr                      # ONE line, from rank 0 of the child job
     rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["steps"] == 5 and rec["config"]["parallelism"] == "dp2"
+    assert rec["n_gpus"] == 2 and rec["steps"] == 5 and rec["config"]["parallelism"] == "dp2"
+    assert rec["rccl_ranks"] == 0                                    # gloo ranks: no RCCL communicator existed
+    assert [q["rank"] for q in rec["per_rank"]] == [0, 1] and rec["per_rank"][0]["steps_per_s"] > rec["per_rank"][1]["steps_per_s"]
     assert rec["stub"] is True and rec["metric"] == "stub-driver-test"      # a --stub-engine line can never be scraped as a measurement
     assert rec["value"] <= 2 * 5 / (5 * 0.004) * 1.01                # whole-job steps over the SLOWEST rank's time (rank 1: 4 ms / step)
     # a WORLD_SIZE that contradicts --gpus is still an error, not a silent single-rank run

@@ -47,6 +47,7 @@ WORKER = textwrap.dedent("""
     out = par.gather_latents(lat, 1, force=True)
     assert len(out) == 1 and out[0].device.type == "cpu" and out[0].dtype == torch.bfloat16 and float(out[0].float().mean()) == 3.0
     assert par.max_over_ranks(1.25, dev, force=True) == 1.25
+    assert par.rccl_rank_count(dev) == 1         # what bench.py reports as `rccl_ranks`: RCCL's own count of the communicator
     par.barrier()
     torch.distributed.destroy_process_group()
     print("rccl world-1 ok: %%.1f MB in %%.4f s, 256 MiB bucket pair in %%.4f s" %% (n_bytes / 1e6, secs, secs_big))

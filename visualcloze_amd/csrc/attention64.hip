@@ -60,7 +60,7 @@ struct Attn64Args {
   // optional in-kernel QKNorm + RoPE of the query rows (q_scale != nullptr): as vc_qknorm_rope_vt
   const bf16_t* q_scale; const bf16_t* q_scale2; const float* rope; int64_t rope_bstride; int32_t split;
   int32_t q_pre;        // the q columns hold normalised, rotated queries times 128^-0.5 * log2(e) (VcAttention.q_prescaled)
-  uint64_t* debug_ts;   // profiling builds only (-DVC_ATTN_TIMESTAMPS): per workgroup (start, end, tiles)
+  uint64_t* debug_ts;   // profiling builds only (-DVC_ATTN_TIMESTAMPS): 32 words per workgroup (start, end, tiles, items; 8 per work item)
 };
 // BOUNDED (VcAttention.logit_bound): the caller guarantees |c q.k| <= bound (log2 domain) for every query / key pair - with
 // QK-normed operands |q|, |k| <= sqrt(128) max|scale|, so the bound is a property of the model's norm scales.  A softmax
@@ -232,7 +232,11 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
 
 #ifdef VC_ATTN_TIMESTAMPS
   const uint64_t ts0 = __builtin_amdgcn_s_memtime();
-  int ts_tiles = 0;
+  int ts_tiles = 0, ts_seg = 0;
+  // per work item of the workgroup (up to 3): start, prologue done, first tile done, loop done, epilogue done, tiles
+#define TS_SEG(k) do { if (a.debug_ts && tid == 0 && ts_seg < 3) a.debug_ts[blockIdx.x * 32 + 8 + ts_seg * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TS_SEG(k) do { } while (0)
 #endif
   const int G = gridDim.x;
   const int nkt_all = (a.L + KVB - 1) / KVB;
@@ -277,7 +281,9 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
     if (kt1 < 0) kt1 = nkt;
 #ifdef VC_ATTN_TIMESTAMPS
     ts_tiles += kt1 - kt0;
+    if (a.debug_ts && tid == 0 && ts_seg < 3) a.debug_ts[blockIdx.x * 32 + 8 + ts_seg * 8 + 5] = kt1 - kt0;
 #endif
+    TS_SEG(0);
 
     const bf16_t* __restrict__ qbase = a.qkv + (long)b * a.bstride + h * 128;
     const char* kbytes = (const char*)(qbase + a.H * 128);
@@ -367,6 +373,7 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
     wait_vm<0>();
     __builtin_amdgcn_s_barrier();
     SB();
+    TS_SEG(1);
 
     f32x16 SBk[6];                     // S^T blocks; roles rotate with the tile (see tile())
     u32x4 P[2][4];                     // [query block][16-key step]
@@ -506,6 +513,7 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
     wait_lgkm<0>();
     __builtin_amdgcn_s_barrier();      // every wave holds its K(kt0+1) fragments before tile kt0 sends K(kt0+4) into that slot
     SB();
+    TS_SEG(2);
 
     // ---- one tile of the steady state; J = (tile - kt0) % 3 selects ring slots and the S block roles:
     //      S(kt) = blocks (4J + i) % 6, S(kt+1) = blocks (4J + 4 + i) % 6, i = chain = 2*qb + u  (the last two chains of
@@ -636,6 +644,7 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
     }
 
     // ---- epilogue ----
+    TS_SEG(3);
     asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");     // ring quiet, last P.V MFMAs retired
     if (piece >= 0) {          // part of an item's keys only: (O / l, m, l) of this key range, merged by attn64_merge_kernel
       char* pp = (char*)a.part + (long)piece * PART64_BYTES;
@@ -670,12 +679,18 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
     }
     // no barrier here: every wave passed the last tile's s_barrier after its final LDS reads, and a wave's own
     // vmcnt(0) above orders its in-flight pieces before the next item's prologue DMA into the same slots
+#ifdef VC_ATTN_TIMESTAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (profiling build: the stamp sees the stores complete)
+    TS_SEG(4);
+    ++ts_seg;
+#endif
   }  // work items
 #ifdef VC_ATTN_TIMESTAMPS
   if (a.debug_ts && tid == 0) {
-    a.debug_ts[blockIdx.x * 4 + 0] = ts0;
-    a.debug_ts[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime();
-    a.debug_ts[blockIdx.x * 4 + 2] = ts_tiles;
+    a.debug_ts[blockIdx.x * 32 + 0] = ts0;
+    a.debug_ts[blockIdx.x * 32 + 1] = __builtin_amdgcn_s_memtime();
+    a.debug_ts[blockIdx.x * 32 + 2] = ts_tiles;
+    a.debug_ts[blockIdx.x * 32 + 3] = ts_seg;
   }
 #endif
 }

@@ -136,6 +136,27 @@ def max_over_ranks(seconds: float, device: Optional[torch.device] = None, force:
     return float(t.item())
 
 
+def rccl_rank_count(device: Optional[torch.device] = None) -> int:
+    """How many ranks RCCL ITSELF has seen: the sum of a device-tensor all-reduce of ones over the "nccl" (= RCCL on ROCm)
+    communicator - 0 when there is no process group or its backend is not RCCL (gloo test worlds, a bare single-GPU run).
+    bench.py reports it as `rccl_ranks`: a record with n_gpus = 8 and rccl_ranks != 8 did not run over RCCL."""
+    if not dist.is_initialized() or dist.get_backend() != "nccl":
+        return 0
+    dev = device or torch.device("cuda", torch.cuda.current_device())
+    one = torch.ones(1, dtype=torch.int32, device=dev)
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    return int(one.item())
+
+
+def gather_records(record: dict) -> Optional[List[dict]]:
+    """Every rank's small dict on rank 0, in rank order (None elsewhere); a world of one returns [record]."""
+    if world() == 1:
+        return [record]
+    objs = [None] * world() if rank() == 0 else None
+    dist.gather_object(record, objs, dst=0)
+    return objs
+
+
 def gather_latents(local: Sequence[torch.Tensor], n_samples: int, force: bool = False,
                    to_host: bool = True) -> Optional[List[torch.Tensor]]:
     """Collect the final latents (0.44 MB per sample at cfg 2) on rank 0 in global sample order.  `to_host` (default):

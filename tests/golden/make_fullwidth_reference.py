@@ -11,7 +11,12 @@ Weights and inputs are procedural (tests/procedural.py: closed form, identical o
 only: `Flux.forward` [1, 3456, 64] whole, and strided samples of the DoubleStreamBlock's (img, txt) and the
 SingleStreamBlock's outputs (layers.py:158-245), taken with forward hooks.
 
-    python tests/golden/make_fullwidth_reference.py        # -> tests/golden/fullwidth_reference.npz (about a minute on 8 cores)
+Round 6 adds the reference's own BF16 run of the same model and inputs - bf16 parameters (models/util.py:402), bf16 inputs
+and guidance (visualcloze.py:399,413) under `torch.autocast("cpu", torch.bfloat16)` (visualcloze.py:363; SURVEY.md §8c names
+this mode) - as `flux_bf16` and `double_img_bf16 / double_txt_bf16 / single_bf16` (bf16 bit patterns, uint16): the oracle's
+bf16 mode (`Prec("bf16", "ref")`: WHERE it rounds) is held to it at D = 3072 / 24 heads / r = 256, not only at the tiny geometry.
+
+    python tests/golden/make_fullwidth_reference.py        # -> tests/golden/fullwidth_reference.npz (a few minutes on 8 cores)
 """
 import importlib.util
 import os
@@ -72,6 +77,24 @@ def main():
                double_img=sample(taps["double_img"]).numpy(), double_txt=sample(taps["double_txt"]).numpy(),
                single=sample(taps["single"]).numpy(),
                torch_version=np.array(torch.__version__))
+    # ---- the reference's own bf16 run (autocast on the CPU), same weights and inputs ----
+    t1 = time.time()
+    mb = model.to(torch.bfloat16)
+    tapsb = {}
+    mb.double_blocks[0]._forward_hooks.clear()
+    mb.single_blocks[0]._forward_hooks.clear()
+    mb.double_blocks[0].register_forward_hook(lambda m, a, out: tapsb.update(double_img=out[0], double_txt=out[1]))
+    mb.single_blocks[0].register_forward_hook(lambda m, a, out: tapsb.update(single=out))
+    with torch.no_grad(), torch.autocast("cpu", torch.bfloat16):
+        yb = mb(torch.cat((inp["x"], inp["cond"]), -1).bfloat16(), timesteps=torch.tensor([T_MODEL]), txt=inp["txt"].bfloat16(),
+                txt_ids=inp["txt_ids"], txt_mask=inp["txt_mask"], y=inp["y"].bfloat16(), img_ids=inp["img_ids"],
+                img_mask=inp["img_mask"], guidance=inp["guidance"].bfloat16())
+    assert yb.shape == y.shape and torch.isfinite(yb.float()).all()
+    bits = lambda t: t.to(torch.bfloat16).contiguous().view(torch.int16).numpy().view(np.uint16)  # noqa: E731
+    out.update(flux_bf16=bits(yb), double_img_bf16=bits(sample(tapsb["double_img"])), double_txt_bf16=bits(sample(tapsb["double_txt"])),
+               single_bf16=bits(sample(tapsb["single"])), flux_bf16_dtype=np.array(str(yb.dtype)))
+    print(f"bf16 autocast run: {time.time() - t1:.0f} s, output dtype {yb.dtype}; reference bf16-vs-fp32 on Flux.forward: rel-L2 "
+          f"{float((yb.float() - y).norm() / y.norm()):.3e}")
     path = os.path.join(HERE, "fullwidth_reference.npz")
     np.savez_compressed(path, **out)
     print(f"wrote {path} ({os.path.getsize(path)} bytes) in {time.time() - t0:.0f} s; |flux| rms {float(y.pow(2).mean().sqrt()):.4f}")

@@ -237,3 +237,44 @@ def test_oracle_at_full_width_against_the_reference_itself():
     err = ((y - torch.tensor(fx["flux"])).norm() / torch.tensor(fx["flux"]).norm()).item()
     print(f"oracle fp32 vs the reference at full width (1+1 blocks, L = 3968): rel-L2 {err:.2e}")
     assert err < 1e-5
+
+
+def test_oracle_bf16_mode_at_full_width_against_the_reference_bf16_run():
+    """The oracle's BF16 mode - WHERE `Prec.r` rounds - held to the reference's own bf16 run at FLUX width (the
+    reference with bf16 parameters under `torch.autocast("cpu", torch.bfloat16)`, visualcloze.py:363; bf16 inputs and bf16
+    guidance, visualcloze.py:399,413): `flux_bf16` / `*_bf16` of tests/golden/fullwidth_reference.npz, written by
+    tests/golden/make_fullwidth_reference.py from the reference's FluxLoraWrapper (1 + 1 blocks, hidden 3072, 24 heads, LoRA
+    r256 executed as lora.py:92-98 writes it, L = 3968).  Two bf16 implementations of one function differ by rounding noise
+    that depends on summation order (mkldnn's bf16 GEMM vs the oracle's f32 matmul of bf16-rounded operands), so the bound
+    is a tolerance, STATED: `Flux.forward` <= 1e-2, block outputs <= 5e-3 rel-L2 (measured 4.9e-3 and 1.7-2.2e-3; the
+    bf16-vs-fp32 noise floor of the same evaluation is 9e-3 - the oracle's bf16 mode sits closer to the reference's bf16 run
+    than bf16 sits to exact arithmetic).  bf16 guidance matters: 1000 * 30 rounds to 29952 before the sinusoid
+    (`guidance_is_bf16`), which moves the output by 17 % - the fixture pins that too."""
+    import importlib.util
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    fx = np.load(os.path.join(here, "fullwidth_reference.npz"))
+    assert "flux_bf16" in fx.files, "regenerate tests/golden/fullwidth_reference.npz (make_fullwidth_reference.py, round 6)"
+    spec = importlib.util.spec_from_file_location("make_fullwidth_traj", os.path.join(here, "make_fullwidth_traj.py"))
+    FT = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(FT)
+    inp = FT.inputs("cfg2")
+    sd = {k: procedural_param(k, s, device="cpu").to(torch.bfloat16).float() for k, s in FT.key_shapes()}
+    Gw = O.FluxGeometry(depth=1, depth_single_blocks=1)
+    bf = lambda a: torch.tensor(a.view(np.int16)).view(torch.bfloat16).float()  # noqa: E731
+    rel = lambda a, b: ((a - b).norm() / b.norm()).item()  # noqa: E731
+    taps = {}
+    with torch.no_grad():             # compute_vec's default: guidance_is_bf16 = True, the production dtype
+        y = O.flux_forward(sd, Gw, torch.cat((inp["x"], inp["cond"]), -1), inp["img_ids"], inp["txt"], inp["txt_ids"],
+                           torch.tensor(fx["t"]), inp["y"], inp["txt_mask"], inp["img_mask"], inp["guidance"],
+                           P=O.Prec("bf16", "ref"), taps=taps)
+    rs, cs_ = int(fx["row_stride"]), int(fx["col_stride"])
+    ref = bf(fx["flux_bf16"]).reshape(y.shape)
+    e = rel(y, ref)
+    eb = {n: rel(taps[k][0, ::rs, ::cs_], bf(fx[n + "_bf16"])) for n, k in
+          (("double_img", "double.0.img"), ("double_txt", "double.0.txt"), ("single", "single.0"))}
+    floor = rel(ref, torch.tensor(fx["flux"]).reshape(y.shape))
+    print(f"oracle bf16/ref vs the reference's bf16 autocast run at full width: Flux.forward {e:.2e}, blocks {eb}; "
+          f"reference bf16-vs-fp32 (bf16 guidance included) {floor:.2e}")
+    assert e < 1e-2 and all(v < 5e-3 for v in eb.values()), (e, eb)
+    assert floor > 0.1                # the fixture really ran with bf16 guidance (29952, not 30000)

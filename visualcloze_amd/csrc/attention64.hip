@@ -44,6 +44,7 @@
 #include <type_traits>
 #include "common.h"
 #include "vcloze_internal.h"
+#include "attention64_sched.h"
 
 namespace {
 
@@ -120,6 +121,11 @@ VC_DEV void sfor(F&& f) {
   }
 }
 #define SB() __builtin_amdgcn_sched_barrier(0)
+template <int PH, int I>
+constexpr a64s::Tok tok_at() {      // token I of phase PH (0 = S = K.Q^T phase, 1 = P.V phase) of the generated filler schedule
+  if constexpr (PH == 0) return a64s::A_TOK[I];
+  else return a64s::B_TOK[I];
+}
 
 // ---- asm-owned instructions ----
 template <int KA, int QA, bool ZERO>
@@ -292,16 +298,19 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
     // LDS-DMA of source tile min(n, kt1 - 1) into ring slot SLOT (4 K + 4 V^T pieces per wave and tile)
     // (the wave's LDS destination base is re-derived from one SGPR per use: hoisted out of the loop body the distinct
     // M0 values - and their spills - cost more than one s_add each)
+    // (VC_WL_PIN re-derives the base from one SGPR per use; the bounded tile, whose pieces sit in both phases, hits
+    // "illegal VGPR to SGPR copy" in hipcc's backend with the pin and compiles to the same per-use s_add without it)
+#define VC_WL_PIN do { if constexpr (!BOUNDED) asm volatile("" : "+s"(wave_lds)); } while (0)
     int wave_lds = wave * 1024;
     auto dma_k = [&](auto SLOT, int n, int i) {
       const int kt = min(n, kt1 - 1);
       const uint32_t off = min(k_off[i] + (uint32_t)kt * k_step, k_max);
-      asm volatile("" : "+s"(wave_lds));
+      VC_WL_PIN;
       glds16(kbytes + off, smem + wave_lds + (decltype(SLOT)::value * K_TILE + i * 4096));
     };
     auto dma_v = [&](auto SLOT, int n, int i) {
       const int kt = min(n, kt1 - 1);
-      asm volatile("" : "+s"(wave_lds));
+      VC_WL_PIN;
       glds16(vbytes + (v_off[i] + (uint32_t)kt * (KVB * 2)), smem + wave_lds + (V_RING0 + decltype(SLOT)::value * V_TILE + i * 4096));
     };
     using I0 = std::integral_constant<int, 0>;
@@ -377,23 +386,10 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
 
     f32x16 SBk[6];                     // S^T blocks; roles rotate with the tile (see tile())
     u32x4 P[2][4];                     // [query block][16-key step]
-#ifdef VC_A64_NO_SOFTMAX
+    // (VGPRs from the start: the bounded form writes single words of P across the tile boundary, and an undefined
+    // vector on the loop's back edge ends in "illegal VGPR to SGPR copy" in the backend)
 #pragma unroll
     for (int i = 0; i < 8; ++i) asm volatile("" : "=v"(P[i >> 2][i & 3]));
-#endif
-    // BOUNDED: the first EARLY pairs of a tile's probabilities (block 0 of S, query block 0, keys 0..2*EARLY-1 of the lane)
-    // are exponentiated one phase early - in phase B of the PREVIOUS tile, in the MFMA gaps the row max used to fill - and
-    // wait in pn / l_early until phase A of their own tile opens (P(kt) itself is still feeding the P.V MFMAs then)
-#ifndef VC_A64_EARLY
-#define VC_A64_EARLY 6        /* A/B builds: 1 .. 8 (6 and 8 measure alike: +0.5 % steps/s over the same kernel without it) */
-#endif
-    constexpr int EARLY = BOUNDED ? VC_A64_EARLY : 0;
-    static_assert(!BOUNDED || (EARLY >= 1 && EARLY <= 8), "phase A has 32 gaps for (32 - EARLY) pairs + the pack of the last one");
-    uint32_t pn[8];
-    float l_early;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) asm volatile("" : "=v"(pn[i]));      // (VGPRs from the start; written before they are read)
-    asm volatile("" : "=v"(l_early));
     u32x4 vf[8];                       // V^T fragment ring
     float m_run[2] = {0.f, 0.f};       // running row max (log2 domain), always bf16-representable: -m_run sits in q_aug
     float l_acc[2] = {0.f, 0.f}, alpha[2] = {1.f, 1.f};
@@ -502,12 +498,12 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
     }
     resc = false;                                                   // O = 0, l = 0: nothing to rescale on the first tile
     if constexpr (BOUNDED) {                                        // the early pairs of the item's first tile (no phase B before it)
-      sfor<0, EARLY>([&](auto Kc) {
-        constexpr int k = decltype(Kc)::value;
-        const float e0 = __builtin_amdgcn_exp2f(SBk[0][2 * k]), e1 = __builtin_amdgcn_exp2f(SBk[0][2 * k + 1]);
-        if constexpr (k == 0) l_early = e0; else l_early += e0;
-        l_early += e1;
-        pn[k] = v_cvt_pk(e0, e1);
+      sfor<0, a64s::N_EARLY>([&](auto Ic) {
+        constexpr int k = a64s::EARLY_PAIR[decltype(Ic)::value], pq = k >> 4, idx = k & 15, pu = idx >> 3, r0 = (idx & 7) * 2;
+        const float e0 = __builtin_amdgcn_exp2f(SBk[pq * 2 + pu][r0]), e1 = __builtin_amdgcn_exp2f(SBk[pq * 2 + pu][r0 + 1]);
+        l_acc[pq] += e0;
+        l_acc[pq] += e1;
+        P[pq][pu * 2 + (r0 >> 3)][(r0 & 7) >> 1] = v_cvt_pk(e0, e1);
       });
     }
     wait_lgkm<0>();
@@ -518,57 +514,45 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
     // ---- one tile of the steady state; J = (tile - kt0) % 3 selects ring slots and the S block roles:
     //      S(kt) = blocks (4J + i) % 6, S(kt+1) = blocks (4J + 4 + i) % 6, i = chain = 2*qb + u  (the last two chains of
     //      S(kt+1) take the blocks of S(kt) that phase A has finished exponentiating by then) ----
-    auto tile = [&](auto Jc, int kt) {
+    // (a) running-max form: the row max of S(kt+1) and the rescale decision fill the P.V phase
+    auto tile_r = [&](auto Jc, int kt) {
       constexpr int J = decltype(Jc)::value;
       constexpr int BASE = (4 * J) % 6;
       using SLOT_V = std::integral_constant<int, J>;                 // V^T(kt)
       using SLOT_K2 = std::integral_constant<int, (J + 2) % 3>;      // K(kt+2) fragments / V^T(kt+2) DMA
       using SLOT_K4 = std::integral_constant<int, (J + 1) % 3>;      // K(kt+4) DMA
-      if constexpr (!BOUNDED) rescale_o();
+      rescale_o();
       u32x4 ka[2] = {make_kaug(kt + 1, 0), make_kaug(kt + 1, 1)};
-      const bool msk1 = BOUNDED && tile_masked(min(kt + 1, kt1 - 1));
       SB();
       // ---------------- phase A: S(kt+1) = K(kt+1) . Q^T - m  ||  P(kt), l  ||  V^T(kt) fragments 0..7 ----------------
       float pe0 = 0.f, pe1 = 0.f;
-      if constexpr (BOUNDED) {           // the pairs exponentiated one phase early join P(kt) and l
-        sfor<0, EARLY>([&](auto Kc) { constexpr int k = decltype(Kc)::value; P[0][k >> 2][k & 3] = pn[k]; });
-        l_acc[0] += l_early;
-      }
       sfor<0, 36>([&](auto Gp) {
         constexpr int g = decltype(Gp)::value, c = g / 9, t = g % 9;
-        // filler position: the running-max kernel fills all 36 MFMA gaps (pair g at gap g, V^T fragments in the four thin
-        // gaps behind the (-m) steps); BOUNDED has 32 gaps h = 8c + t (the (-m) gaps exist in masked tiles only and stay
-        // empty), pairs EARLY.. at h = 0.., one V^T fragment in each of the last eight
-        constexpr int h = BOUNDED ? (t < 8 ? c * 8 + t : -1) : g;
-        constexpr int NP = 32 - EARLY;    // pairs done in this phase
+        // every one of the 36 MFMA gaps takes a pair; the V^T fragments sit in the four thin gaps behind the (-m) steps
 #ifndef VC_A64_NO_MFMA
-        qk_step(SBk[(BASE + 4 + c) % 6], std::integral_constant<int, c>{}, std::integral_constant<int, t>{}, ka[c & 1], msk1);
+        qk_step(SBk[(BASE + 4 + c) % 6], std::integral_constant<int, c>{}, std::integral_constant<int, t>{}, ka[c & 1], true);
 #else
         if constexpr (t == 0) asm volatile("" : "=v"(SBk[(BASE + 4 + c) % 6]));
 #endif
 #ifndef VC_A64_NO_SOFTMAX
-        if constexpr (h > 0 && h <= NP) {   // pair h-1: row sum and bf16 pack of the two probabilities exponentiated one gap earlier
-          constexpr int k = h - 1 + EARLY, pq = k >> 4, idx = k & 15, pu = idx >> 3, r0 = (idx & 7) * 2;
+        if constexpr (g > 0 && g <= 32) {   // pair g-1: row sum and bf16 pack of the two probabilities exponentiated one gap earlier
+          constexpr int k = g - 1, pq = k >> 4, idx = k & 15, pu = idx >> 3, r0 = (idx & 7) * 2;
           l_acc[pq] += pe0;
           l_acc[pq] += pe1;
           PIN(l_acc[pq]);
           P[pq][pu * 2 + (r0 >> 3)][(r0 & 7) >> 1] = v_cvt_pk(pe0, pe1);
         }
-        if constexpr (h >= 0 && h < NP) {
-          constexpr int k = h + EARLY, pq = k >> 4, idx = k & 15, pu = idx >> 3, r0 = (idx & 7) * 2;
+        if constexpr (g < 32) {
+          constexpr int k = g, pq = k >> 4, idx = k & 15, pu = idx >> 3, r0 = (idx & 7) * 2;
           pe0 = __builtin_amdgcn_exp2f(SBk[(BASE + pq * 2 + pu) % 6][r0]);
           pe1 = __builtin_amdgcn_exp2f(SBk[(BASE + pq * 2 + pu) % 6][r0 + 1]);
         }
 #endif
 #ifndef VC_A64_NO_LDS
-        if constexpr (!BOUNDED && g >= 32) {          // the four thin gaps at the end take the first eight V^T fragments
+        if constexpr (g >= 32) {          // the four thin gaps at the end take the first eight V^T fragments
           constexpr int f = (g - 32) * 2;   // fragment (dt = f >> 2, s = f & 3)
           lds_v<SLOT_V::value * V_TILE + (f >> 2) * 4096>(vf[f], v_rd[f & 3]);
           lds_v<SLOT_V::value * V_TILE + ((f + 1) >> 2) * 4096>(vf[f + 1], v_rd[(f + 1) & 3]);
-        }
-        if constexpr (BOUNDED && h >= 24) {
-          constexpr int f = h >= 24 ? h - 24 : 0;
-          lds_v<SLOT_V::value * V_TILE + (f >> 2) * 4096>(vf[f], v_rd[f & 3]);
         }
 #else
         if constexpr (g >= 32) { asm volatile("" : "=v"(vf[(g - 32) * 2])); asm volatile("" : "=v"(vf[(g - 32) * 2 + 1])); }
@@ -587,30 +571,14 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
 #endif
 #ifndef VC_A64_NO_SOFTMAX
         // S(kt+1) was completed by the last MFMAs of phase A: its first VALU read comes two MFMA gaps later
-        if constexpr (BOUNDED) {            // pairs 0..EARLY-1 of S(kt+1) (its block 0 was complete 27 MFMAs ago): exp at the even
-          if constexpr (g >= 2 && g < 2 + 2 * EARLY && (g & 1) == 0) {            // gaps 2, 4, ..., sum and pack one gap later
-            constexpr int k = (g - 2) / 2;
-            pe0 = __builtin_amdgcn_exp2f(SBk[(BASE + 4) % 6][2 * k]);
-            pe1 = __builtin_amdgcn_exp2f(SBk[(BASE + 4) % 6][2 * k + 1]);
-          }
-          if constexpr (g >= 3 && g < 3 + 2 * EARLY && (g & 1) == 1) {
-            constexpr int k = (g - 3) / 2;
-            if constexpr (k == 0) l_early = pe0; else l_early += pe0;
-            l_early += pe1;
-            PIN(l_early);
-            pn[k] = v_cvt_pk(pe0, pe1);
-          }
-        }
-        if constexpr (!BOUNDED) {
-          if constexpr (g >= 2 && g <= 9)
-            sfor<0, 4>([&](auto Cc) { max_step(SBk[(BASE + 4 + decltype(Cc)::value) % 6], Cc, std::integral_constant<int, g - 2>{}); });
-          if constexpr (g == 10) decide0();
-          if constexpr (g == 11) decide1(I0{});
-          if constexpr (g == 12) decide1(I1{});
+        if constexpr (g >= 2 && g <= 9)
+          sfor<0, 4>([&](auto Cc) { max_step(SBk[(BASE + 4 + decltype(Cc)::value) % 6], Cc, std::integral_constant<int, g - 2>{}); });
+        if constexpr (g == 10) decide0();
+        if constexpr (g == 11) decide1(I0{});
+        if constexpr (g == 12) decide1(I1{});
 #ifndef VC_A64_NO_AUG
-          if constexpr (g == 13) decide2(std::integral_constant<int, (BASE + 4) % 6>{}, false);
+        if constexpr (g == 13) decide2(std::integral_constant<int, (BASE + 4) % 6>{}, false);
 #endif
-        }
 #endif
 #ifndef VC_A64_NO_LDS
         if constexpr ((g & 1) && g < 16) {          // V^T fragment (dt + 2, s) into the register (dt, s) just retired
@@ -635,6 +603,108 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
       __builtin_amdgcn_s_barrier();
 #endif
       SB();
+    };
+
+    // (b) bounded-logit form: no row max, so the fillers of a tile are exp / add / pack, the 32 fragment reads and the 8
+    // LDS-DMA pieces - dealt out over the 64 MFMA gaps by tools/gen_a64_sched.py (attention64_sched.h) so that every gap
+    // carries about the same issue price.  12 pairs of P(kt+1) are exponentiated in the P.V phase of tile kt, straight into
+    // the P registers that the s-major order of that phase has already retired (and into l: nothing rescales it here).
+    float pe0[32], pe1[32];              // probabilities between their v_exp and their row-sum add / pack (2-3 pairs live)
+    float l_e[2] = {0.f, 0.f};           // row sums of the pairs exponentiated one tile early: they join l when their tile opens
+                                         // (the last tile of an item exponentiates pairs of a tile that does not exist)
+    auto run_tok = [&](auto PH, auto TI, auto SBASE, auto SLOT_V, auto SLOT_K2, auto SLOT_K4, int kt) {
+      constexpr a64s::Tok t = tok_at<decltype(PH)::value, decltype(TI)::value>();
+      constexpr int k = t.a, pq = k >> 4, idx = k & 15, pu = idx >> 3, r0 = (idx & 7) * 2;
+      constexpr int blk = (decltype(SBASE)::value + pq * 2 + pu) % 6;
+      if constexpr (t.kind == a64s::T_E0) { pe0[k & 31] = __builtin_amdgcn_exp2f(SBk[blk][r0 & 15]); PIN(pe0[k & 31]); }
+      else if constexpr (t.kind == a64s::T_E1) { pe1[k & 31] = __builtin_amdgcn_exp2f(SBk[blk][(r0 + 1) & 15]); PIN(pe1[k & 31]); }
+      else if constexpr (t.kind == a64s::T_A0) {
+        if constexpr (decltype(PH)::value == 0) { l_acc[pq & 1] += pe0[k & 31]; PIN(l_acc[pq & 1]); }
+        else if constexpr (k != a64s::EARLY_FIRST[pq & 1]) { l_e[pq & 1] += pe0[k & 31]; PIN(l_e[pq & 1]); }
+      } else if constexpr (t.kind == a64s::T_A1) {
+        if constexpr (decltype(PH)::value == 0) { l_acc[pq & 1] += pe1[k & 31]; PIN(l_acc[pq & 1]); }
+        else if constexpr (k != a64s::EARLY_FIRST[pq & 1]) { l_e[pq & 1] += pe1[k & 31]; PIN(l_e[pq & 1]); }
+        else { l_e[pq & 1] = pe0[k & 31] + pe1[k & 31]; PIN(l_e[pq & 1]); }      // the first early pair of a query block opens the sum
+      }
+      else if constexpr (t.kind == a64s::T_CV) P[pq & 1][(pu * 2 + (r0 >> 3)) & 3][(r0 & 7) >> 1] = v_cvt_pk(pe0[k & 31], pe1[k & 31]);
+#ifndef VC_A64_NO_LDS
+      else if constexpr (t.kind == a64s::T_RV)       // V^T(kt) fragment (dt = f & 3, s = f >> 2), s = 0, 1
+        lds_v<decltype(SLOT_V)::value * V_TILE + (t.a & 3) * 4096>(vf[t.a & 7], v_rd[(t.a >> 2) & 3]);
+      else if constexpr (t.kind == a64s::T_RV2)      // fragment (dt, s + 2) into the register of (dt, s), retired by MFMA 8 s + 2 dt + 1
+        lds_v<decltype(SLOT_V)::value * V_TILE + (t.a & 3) * 4096>(vf[((t.b & 1) * 4 + t.a) & 7], v_rd[(t.b + 2) & 3]);
+      else if constexpr (t.kind == a64s::T_RK) read_k(SLOT_K2, std::integral_constant<int, t.a & 15>{});
+      else if constexpr (t.kind == a64s::T_WAIT) wait_lgkm<t.a & 15>();
+#endif
+#ifndef VC_A64_NO_DMA
+      else if constexpr (t.kind == a64s::T_DMA) {
+        if constexpr (t.a < 4) dma_v(SLOT_K2, kt + 2, t.a & 3);
+        else dma_k(SLOT_K4, kt + 4, t.a & 3);
+      }
+#endif
+    };
+    auto tile_b = [&](auto Jc, auto Mc, int kt) {
+      constexpr int J = decltype(Jc)::value;
+      constexpr bool MASKED = decltype(Mc)::value;    // S(kt+1) covers masked keys: its chains take the (0, -29952) k-step
+      constexpr int BASE = (4 * J) % 6;
+      using SLOT_V = std::integral_constant<int, J>;                 // V^T(kt)
+      using SLOT_K2 = std::integral_constant<int, (J + 2) % 3>;      // K(kt+2) fragments / V^T(kt+2) DMA
+      using SLOT_K4 = std::integral_constant<int, (J + 1) % 3>;      // K(kt+4) DMA
+      using SA = std::integral_constant<int, BASE>;                  // S(kt)
+      using SB1 = std::integral_constant<int, (BASE + 4) % 6>;       // S(kt+1)
+      SB();
+      // ---------------- phase A: S(kt+1) = K(kt+1) . Q^T  ||  20 pairs of P(kt), V^T(kt) fragments (s = 0, 1), V^T(kt+2) DMA ----
+      sfor<0, 32>([&](auto Gp) {
+        constexpr int g = decltype(Gp)::value, c = g >> 3, t = g & 7;
+#ifndef VC_A64_NO_MFMA
+        mfma_qk<A_K + ((c & 1) * 8 + t) * 4, A_Q + ((c >> 1) * 8 + t) * 4, t == 0>(SBk[(BASE + 4 + c) % 6]);
+        if constexpr (t == 7 && MASKED) {  // masked keys (a tile that crosses kv_len or the gap)
+          const u32x4 ka = make_kaug(kt + 1, c & 1);
+          mfma_aug(SBk[(BASE + 4 + c) % 6], ka, qaug[c >> 1]);
+        }
+#else
+        if constexpr (t == 0) asm volatile("" : "=v"(SBk[(BASE + 4 + c) % 6]));
+#endif
+#ifndef VC_A64_NO_SOFTMAX
+        if constexpr (g == 0) {            // the pairs of P(kt) that phase B of the previous tile exponentiated join the row sums
+          l_acc[0] += l_e[0];
+          l_acc[1] += l_e[1];
+        }
+        sfor<a64s::A_FIRST[g], a64s::A_FIRST[g + 1]>([&](auto Ti) {
+          run_tok(I0{}, Ti, SA{}, SLOT_V{}, SLOT_K2{}, SLOT_K4{}, kt);
+        });
+#endif
+        SB();
+      });
+      // ---------------- phase B: O += V^T(kt) . P(kt)^T, 16-key step major  ||  12 pairs of P(kt+1), V^T(kt) fragments
+      //                  (s = 2, 3), K(kt+2) -> AGPRs, K(kt+4) DMA ----------------
+      sfor<0, 32>([&](auto Gp) {
+        constexpr int g = decltype(Gp)::value, s = g >> 3, dt = (g >> 1) & 3, qb = g & 1;
+#ifndef VC_A64_NO_MFMA
+        mfma_pv<A_O + (qb * 4 + dt) * 16>(vf[(s & 1) * 4 + dt], P[qb][s]);
+#else
+        asm volatile("" ::"v"(vf[(s & 1) * 4 + dt]), "v"(P[qb][s]));
+#endif
+#ifndef VC_A64_NO_SOFTMAX
+        sfor<a64s::B_FIRST[g], a64s::B_FIRST[g + 1]>([&](auto Ti) {
+          run_tok(I1{}, Ti, SB1{}, SLOT_V{}, SLOT_K2{}, SLOT_K4{}, kt);
+        });
+#endif
+        SB();
+      });
+#ifndef VC_A64_NO_DMA
+      wait_vm<8>();
+#endif
+      wait_lgkm<0>();
+#ifndef VC_A64_NO_BARRIER
+      __builtin_amdgcn_s_barrier();
+#endif
+      SB();
+    };
+    auto tile = [&](auto Jc, int kt) {
+      if constexpr (BOUNDED) {           // two instruction streams: tiles with masked keys are the last of an item, or none
+        if (tile_masked(min(kt + 1, kt1 - 1))) tile_b(Jc, std::true_type{}, kt);
+        else tile_b(Jc, std::false_type{}, kt);
+      } else tile_r(Jc, kt);
     };
 
     for (int kt = kt0;;) {

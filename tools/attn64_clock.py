@@ -1,12 +1,14 @@
 """Where a workgroup of the one-wave-per-SIMD attention kernel spends its ticks: per work item prologue (DMA + query load up to
 the first barrier), first tile (not overlapped), steady-state loop, epilogue (stores complete) - from the s_memtime stamps of the
 profiling build:   make -C visualcloze_amd/csrc debug; VC_HIP_LIB=visualcloze_amd/lib/libvcloze_hip_dbg.so python tools/attn64_clock.py
-Optional arguments: lengths (default 3968 6656)."""
+Optional arguments: lengths (default 3968 6656).  Launch form: the product's (bounded logits, prescaled queries = the stream
+kernel); VC_CLOCK_FORM=runmax times the running-max template instead."""
 import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from visualcloze_amd import hip
 dev = "cuda:0"
 H = 24
+KW = {} if os.environ.get("VC_CLOCK_FORM") == "runmax" else dict(logit_bound=16.65, q_prescaled=True)
 Ls = [int(x) for x in sys.argv[1:]] or [3968, 6656]
 for L in Ls:
     Lp = (L + 63) // 64 * 64
@@ -16,11 +18,11 @@ for L in Ls:
     for variant in (8, 12):
         ts = torch.zeros(256, 32, dtype=torch.int64, device=dev)
         for _ in range(3):
-            hip.attention(qkv, vt, o, L, H, variant=variant)
+            hip.attention(qkv, vt, o, L, H, variant=variant, **KW)
         torch.cuda.synchronize()
         hip.lib().vc_debug_set_attn_ts(ctypes.c_void_p(ts.data_ptr()))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); hip.attention(qkv, vt, o, L, H, variant=variant); e1.record()
+        e0.record(); hip.attention(qkv, vt, o, L, H, variant=variant, **KW); e1.record()
         torch.cuda.synchronize()
         hip.lib().vc_debug_set_attn_ts(ctypes.c_void_p(0))
         us = e0.elapsed_time(e1) * 1e3

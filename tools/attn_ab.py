@@ -1,5 +1,6 @@
 """A/B timing of attention variants (library builds x kernel variant) interleaved in one process.
-    python tools/attn_ab.py main:1 main:0 nodma:1 main:12:b ...      (":b" = bounded logits, VcAttention.logit_bound = 16.65: the no-running-max template)"""
+    python tools/attn_ab.py main:1 main:0 nodma:1 main:12:b ...      (":b" = bounded logits, VcAttention.logit_bound = 16.65: the no-running-max template; ":bp" = also q_prescaled = 1: the
+    queries are taken as normalised / rotated / scaled already - the product's launch form, the stream kernel of round 6)"""
 import sys, os, ctypes as C, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from visualcloze_amd import hip
@@ -27,15 +28,23 @@ for L in (3968, 6656):
     def run(l, var, mode=""):
         a = hip.Attention()
         a.logit_bound = 16.65 if "b" in mode else 0.0
+        a.q_prescaled = 1 if "p" in mode else 0
         a.qkv, a.ld, a.bstride, a.vt, a.out, a.ldo, a.out_bstride = qkv.data_ptr(), qkv.stride(0), 0, vt.data_ptr(), o.data_ptr(), o.stride(0), 0
         a.B, a.L, a.Lpad, a.H, a.variant = 1, L, Lpad, H, var
         a.scratch, a.scratch_bytes = scr.data_ptr(), scr.numel()
         rc = l.vc_attention(C.byref(a), C.c_void_p(stream))
         assert rc == 0, rc
-    run(getlib("main"), 1); ref = o.clone()
+    refs = {}
     for v in variants:
         print("  check", v, flush=True)
-        o.zero_(); run(getlib(v[0]), v[1], v[2]); torch.cuda.synchronize()
+        if "p" in v[2]:          # prescaled queries: another function of the operands - compared among themselves (first one = reference)
+            o.zero_(); run(getlib(v[0]), v[1], v[2]); torch.cuda.synchronize()
+            ref = refs.setdefault("p", o.clone())
+        else:
+            if "" not in refs:
+                run(getlib("main"), 1); torch.cuda.synchronize(); refs[""] = o.clone()
+            ref = refs[""]
+            o.zero_(); run(getlib(v[0]), v[1], v[2]); torch.cuda.synchronize()
         if not torch.equal(o, ref):
             d = (o.float() - ref.float()).abs().max().item()
             rel = ((o.float() - ref.float()).norm() / ref.float().norm()).item()

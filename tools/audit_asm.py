@@ -36,6 +36,24 @@ print(f"{n_insn} instructions; compiler-generated accvgpr / scratch instructions
 for b in bad[:20]:
     print("   ", b)
 ok = not bad and yfield('vgpr_spill_count') == '0' and yfield('private_segment_fixed_size') == '0'
+# between the kernel's first and last s_barrier (the tile stream) every LDS wait is a COUNTED lgkmcnt and every LDS-DMA wait a
+# counted vmcnt: a scalar load (s_load: lgkmcnt, returns out of order), a scratch access or a compiler-placed global load there
+# would break the counts silently
+lines = body.splitlines()
+bar = [i for i, ln in enumerate(lines) if ln.strip() == "s_barrier"]
+stray = []
+if len(bar) >= 2:
+    inasm = False
+    for ln in lines[bar[0]:bar[-1]]:
+        t = ln.strip()
+        if t.startswith(";;#ASMSTART"): inasm = True
+        elif t.startswith(";;#ASMEND"): inasm = False
+        elif not inasm and re.match(r"(s_load|s_buffer_load|scratch_)", t):
+            stray.append(t)
+print(f"scalar loads / scratch accesses between the first and the last s_barrier: {len(stray)}")
+for t in stray[:10]:
+    print("   ", t)
+ok = ok and not stray
 # per-gap histogram of the main loop: instructions between consecutive MFMAs
 gaps, cur = [], None
 for ln in body.splitlines():

@@ -15,15 +15,16 @@ six others).  Everything else the tile needs is a TOKEN with a measured issue pr
 
 This script deals the tokens out so that every gap carries about the same price, under the data dependences of the tile:
 
-  phase A(t):  S(t+1) = K(t+1) . Q^T (32 MFMAs: 4 chains of 8)  ||  20 pairs of P(t) (8..15, 20..31), V^T(t) fragments
-               (s = 0, 1), the 4 V^T(t+2) LDS-DMA pieces
+  phase A(t):  S(t+1) = K(t+1) . Q^T (32 MFMAs: 4 chains of 8)  ||  20 pairs of P(t) (8..15, 20..31), the four V^T(t)
+               fragments of the first 16-key step, the 4 V^T(t+2) LDS-DMA pieces and one K(t+4) piece
   phase B(t):  O += V^T(t) . P(t)^T, 16-key step s major (MFMA j: s = j >> 3, dt = (j >> 1) & 3, qb = j & 1)  ||  12 pairs
                of P(t+1) written straight into the P registers that the s-major order has retired (pairs 0..3 -> P[0][0] after
-               MFMA 6, 16..19 -> P[1][0] after MFMA 7, 4..7 -> P[0][1] after MFMA 14), V^T(t) fragments (s = 2, 3) into the
-               registers of (s = 0, 1) as they retire, the 16 K(t+2) fragments, the 4 K(t+4) LDS-DMA pieces
+               MFMA 6, 16..19 -> P[1][0] after MFMA 7, 4..7 -> P[0][1] after MFMA 14), V^T(t) fragment (dt, s + 1) into the
+               register of (dt, s) as it retires (a ring of FOUR fragments: 16 registers), the 16 K(t+2) fragments, 3 K(t+4) pieces
   waits:       lgkmcnt is in order for LDS reads, so each first use of a fragment waits with the COUNT of reads issued after it.
 
-    python tools/gen_a64_sched.py            # rewrites the header, prints the per-gap prices
+    python tools/gen_a64_sched.py            # rewrites attention64_sched.h (ring of 4 fragment registers), prints the per-gap prices
+    python tools/gen_a64_sched.py --ring8    # attention64_sched8.h: ring of 8 (two 16-key steps; -DVC_A64_RING8 builds use it)
 """
 import os
 import sys
@@ -91,13 +92,29 @@ def pair_chain(pairs, pos0, pos1):
     return out
 
 
+RING = 4            # V^T fragment registers: 4 (one 16-key step; set by main()) or 8 (two)
+
+
+def vreg(dt, s):
+    """register of V^T fragment (dt, s)"""
+    return dt if RING == 4 else (s & 1) * 4 + dt
+
+
 def phase_a():
     toks = [dict(kind=kind, a=k, b=0, earliest=0, order=pos) for kind, k, pos in pair_chain(LATE_PAIRS, 0.0, 32.0)]
-    # V^T(t) fragments (s = 0, 1): register f = s * 4 + dt, in the order the P.V MFMAs use them; all issued by gap ~27
-    for f in range(8):
-        toks.append(dict(kind=RV, a=f, b=0, earliest=0, order=1.0 + f * 3.6))
-    for i in range(4):                                # V^T(t+2) pieces
-        toks.append(dict(kind=DMA, a=i, b=0, earliest=0, order=3.0 + i * 8.0))
+    if RING == 8:
+        # V^T(t) fragments of the first two 16-key steps, in the order the P.V MFMAs use them; all issued by gap ~27
+        for f in range(8):
+            toks.append(dict(kind=RV, a=(f & 3) + 4 * (f >> 2), b=vreg(f & 3, f >> 2), earliest=0, order=1.0 + f * 3.6))
+        for i in range(4):                                # V^T(t+2) pieces
+            toks.append(dict(kind=DMA, a=i, b=0, earliest=0, order=3.0 + i * 8.0))
+        return deal(toks)
+    # V^T(t) fragments of the first 16-key step (s = 0): register dt; the ring is FOUR fragments deep - fragment (dt, s + 1)
+    # is read into register dt as soon as MFMA (s, dt, qb = 1) has issued, eight MFMAs before its first use
+    for f in range(4):
+        toks.append(dict(kind=RV, a=f, b=vreg(f, 0), earliest=0, order=14.0 + f * 4.0))
+    for i in range(5):                                # the 4 V^T(t+2) pieces and the first K(t+4) piece
+        toks.append(dict(kind=DMA, a=i, b=0, earliest=0, order=2.0 + i * 6.4))
     return deal(toks)
 
 
@@ -114,42 +131,55 @@ def phase_b():
     for kind, k, pos in pair_chain(EARLY_PAIRS, 7.0, 32.0):
         e = p_free_gap(k) + 1 if kind == CV else 0
         toks.append(dict(kind=kind, a=k, b=0, earliest=e, order=max(pos, e + 0.01 * (kind == CV))))
-    # V^T(t) fragments (dt, s + 2) into register s * 4 + dt behind MFMA (s, dt, qb = 1) = 8 s + 2 dt + 1
-    for s in range(2):
+    if RING == 8:
+        # fragment (dt, s + 2) into the register of (dt, s) behind MFMA (s, dt, qb = 1) = 8 s + 2 dt + 1
+        for s in range(2):
+            for dt in range(4):
+                j = 8 * s + 2 * dt + 1
+                toks.append(dict(kind=RV2, a=dt + 4 * (s + 2), b=vreg(dt, s + 2), earliest=j, order=j + 0.05))
+        for i, pos in enumerate([0.0, 2.0, 4.0, 6.0]):
+            toks.append(dict(kind=DMA, a=4 + i, b=0, earliest=0, order=pos))
+        for ut in range(16):
+            toks.append(dict(kind=RK, a=ut, b=0, earliest=0, order=(0.6 + ut * 2.0) if ut < 2 else 7.5 + (ut - 2) * 1.72))
+        return deal(toks)
+    # V^T(t) fragment (dt, s) for s = 1..3 into register dt behind MFMA (s - 1, dt, qb = 1) = 8 (s - 1) + 2 dt + 1
+    for s in range(1, 4):
         for dt in range(4):
-            j = 8 * s + 2 * dt + 1
-            toks.append(dict(kind=RV2, a=dt, b=s, earliest=j, order=j + 0.05))
-    # the 4 K(t+4) pieces open the phase (its first gaps have no pair work), the 16 K(t+2) fragments are spread over the rest
-    for i, pos in enumerate([0.0, 2.0, 4.0, 6.0]):
-        toks.append(dict(kind=DMA, a=4 + i, b=0, earliest=0, order=pos))
+            j = 8 * (s - 1) + 2 * dt + 1
+            toks.append(dict(kind=RV2, a=dt + 4 * s, b=vreg(dt, s), earliest=j, order=j + 0.05))
+    # the other 3 K(t+4) pieces open the phase (its first gaps have no pair work), the 16 K(t+2) fragments are spread over the rest
+    for i, pos in enumerate([0.0, 2.5, 5.0]):
+        toks.append(dict(kind=DMA, a=5 + i, b=0, earliest=0, order=pos))
     for ut in range(16):
-        toks.append(dict(kind=RK, a=ut, b=0, earliest=0, order=(0.6 + ut * 2.0) if ut < 2 else 7.5 + (ut - 2) * 1.72))
+        toks.append(dict(kind=RK, a=ut, b=0, earliest=0, order=(0.6 + ut * 2.0) if ut < 3 else 8.5 + (ut - 3) * 1.78))
     return deal(toks)
 
 
 def add_waits(ga, gb):
-    """lgkmcnt waits: LDS reads return in order, so the first use of a fragment group waits until at most N reads issued AFTER
-    the group's last read are outstanding.  Four waits per tile - one per 16-key step s of the P.V phase, in front of its first
-    MFMA (for s = 0: at the end of phase A) - besides the lgkmcnt(0) before the barrier."""
+    """lgkmcnt waits: LDS reads return in order, so the first use of a fragment waits until at most N reads issued AFTER it are
+    outstanding.  One wait in front of every first use (P.V MFMA 8 s + 2 dt; for MFMA 0 at the end of phase A) that an earlier
+    wait does not already cover, besides the lgkmcnt(0) before the barrier."""
     reads = []                                        # tokens in issue order with their (phase, gap)
     for ph, gaps in ((0, ga), (1, gb)):
         for g, toks in enumerate(gaps):
             for t in toks:
                 if t["kind"] in (RV, RV2, RK):
                     reads.append((ph, g, t))
-    out = []
-    for s in range(4):
-        if s < 2:
-            group = [t for g in ga for t in g if t["kind"] == RV and t["a"] // 4 == s]
-        else:
-            group = [t for g in gb for t in g if t["kind"] == RV2 and t["b"] == s - 2]
-        assert len(group) == 4
-        where = (0, 31) if s == 0 else (1, 8 * s - 1)
-        idx = max(next(i for i, r in enumerate(reads) if r[2] is t) for t in group)
+    out, done = [], -1                                # reads[0..done] are known complete
+    for j in range(0, 32, 2):
+        p = pv(j)
+        code = p["dt"] + 4 * p["s"]
+        tok = next(t for g in ga + gb for t in g if t["kind"] in (RV, RV2) and t["a"] == code)
+        where = (0, 31) if j == 0 else (1, j - 1)
+        idx = next(i for i, r in enumerate(reads) if r[2] is tok)
         issued = sum(1 for (ph, g, t) in reads if (ph, g) <= where)
-        assert idx < issued, (s, idx, issued)
-        out.append((where, min(15, issued - 1 - idx)))
-    # the counter is 4 bits: never more than 15 reads in flight (the tile's last wait is lgkmcnt(0) before the barrier)
+        assert idx < issued, (j, idx, issued)
+        if idx <= done:
+            continue
+        n = min(15, issued - 1 - idx)
+        done = issued - 1 - n
+        out.append((where, n))
+    # the counter is 4 bits: never more than 15 reads in flight
     outstanding = 0
     waits = dict(out)
     for ph, gaps in ((0, ga), (1, gb)):
@@ -179,11 +209,14 @@ def emit(ga, gb, path):
     early = ", ".join(map(str, EARLY_PAIRS))
     txt = f"""// GENERATED by tools/gen_a64_sched.py - do not edit: the filler schedule of attn64_kernel<true>'s tile (attention64.hip).
 // Token (kind, a, b) executed in the gap BEHIND MFMA g of its phase:  E0 / E1 k (v_exp of the pair's first / second probability) |
-// A0 / A1 k (row-sum adds) | CV k (bf16 pack into P) | RV f | RV2 dt s | RK ut (ds_read_b128) | DMA i | WAIT lgkmcnt
+// A0 / A1 k (row-sum adds) | CV k (bf16 pack into P) | RV / RV2 (dt + 4 s, register): V^T fragment (dt, s) | RK ut (ds_read_b128) |
+// DMA i | WAIT lgkmcnt
 #pragma once
 namespace a64s {{
 enum : int {{ T_E0 = {E0}, T_E1 = {E1}, T_A0 = {A0}, T_A1 = {A1}, T_CV = {CV}, T_RV = {RV}, T_RV2 = {RV2}, T_RK = {RK}, T_DMA = {DMA}, T_WAIT = {WAIT} }};
 struct Tok {{ int kind, a, b; }};
+constexpr int V_REGS = {RING};                           // V^T fragment registers (u32x4 each)
+constexpr int PV_REG[32] = {{{", ".join(str(vreg(pv(j)["dt"], pv(j)["s"])) for j in range(32))}}};      // the one P.V MFMA j reads
 constexpr int N_EARLY = {len(EARLY_PAIRS)};
 constexpr int EARLY_PAIR[N_EARLY] = {{{early}}};      // pairs of P(t+1) exponentiated in phase B of tile t
 constexpr int EARLY_FIRST[2] = {{{next(k for k in EARLY_PAIRS if k < 16)}, {next(k for k in EARLY_PAIRS if k >= 16)}}};      // the first of them per query block
@@ -193,15 +226,17 @@ constexpr int EARLY_FIRST[2] = {{{next(k for k in EARLY_PAIRS if k < 16)}, {next
 
 
 def main():
+    global RING
+    RING = 8 if "--ring8" in sys.argv else 4
     ga, gb = phase_a(), phase_b()
     ga, gb = add_waits(ga, gb)
     for name, gaps in (("A", ga), ("B", gb)):
         print(f"phase {name}: total {sum(price(g) for g in gaps):.1f} slots, max gap {max(price(g) for g in gaps):.1f}, "
               f"est. cycles {sum(gap_cycles(price(g)) for g in gaps):.0f}")
         for g, toks in enumerate(gaps):
-            print(f"  {g:2d} {price(toks):5.1f}  " + " ".join(f"{NAMES[t['kind']]}{t['a']}" + (f".{t['b']}" if t['kind'] == RV2 else "") for t in toks))
+            print(f"  {g:2d} {price(toks):5.1f}  " + " ".join(f"{NAMES[t['kind']]}{t['a']}" + (f">{t['b']}" if t['kind'] in (RV, RV2) else "") for t in toks))
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    emit(ga, gb, os.path.join(here, "visualcloze_amd", "csrc", "attention64_sched.h"))
+    emit(ga, gb, os.path.join(here, "visualcloze_amd", "csrc", "attention64_sched.h" if RING == 4 else "attention64_sched8.h"))
 
 
 if __name__ == "__main__":

@@ -44,7 +44,11 @@
 #include <type_traits>
 #include "common.h"
 #include "vcloze_internal.h"
-#include "attention64_sched.h"
+#ifdef VC_A64_RING4
+#include "attention64_sched.h"       // A/B builds: a ring of four V^T fragment registers (16 VGPRs less, -0.2 % per step: r06e)
+#else
+#include "attention64_sched8.h"      // a ring of eight (two 16-key steps)
+#endif
 
 namespace {
 
@@ -171,6 +175,11 @@ VC_DEV uint32_t v_cvt_pk(float lo, float hi) {
   uint32_t r;
   asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
   return r;
+}
+// one LDS-DMA piece, `global_load_lds_dwordx4 v_off, s[base]`, with M0 = lds_wave + imm written in the same statement (one wait
+// state before the DMA reads it)
+VC_DEV void glds16_m0(const char* sbase, uint32_t voff, uint32_t lds_wave, int imm) {
+  asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_wave), "i"(imm) : "memory", "m0", "scc");
 }
 template <int A> VC_DEV float agpr_read() {
   float r;
@@ -619,8 +628,8 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
       if constexpr (t.kind == a64s::T_E0) { pe0[k & 31] = __builtin_amdgcn_exp2f(SBk[blk][r0 & 15]); PIN(pe0[k & 31]); }
       else if constexpr (t.kind == a64s::T_E1) { pe1[k & 31] = __builtin_amdgcn_exp2f(SBk[blk][(r0 + 1) & 15]); PIN(pe1[k & 31]); }
       else if constexpr (t.kind == a64s::T_A0) {
-        if constexpr (decltype(PH)::value == 0) { l_acc[pq & 1] += pe0[k & 31]; PIN(l_acc[pq & 1]); }
-        else if constexpr (k != a64s::EARLY_FIRST[pq & 1]) { l_e[pq & 1] += pe0[k & 31]; PIN(l_e[pq & 1]); }
+        if constexpr (decltype(PH)::value == 0) l_acc[pq & 1] += pe0[k & 31];
+        else if constexpr (k != a64s::EARLY_FIRST[pq & 1]) l_e[pq & 1] += pe0[k & 31];
       } else if constexpr (t.kind == a64s::T_A1) {
         if constexpr (decltype(PH)::value == 0) { l_acc[pq & 1] += pe1[k & 31]; PIN(l_acc[pq & 1]); }
         else if constexpr (k != a64s::EARLY_FIRST[pq & 1]) { l_e[pq & 1] += pe1[k & 31]; PIN(l_e[pq & 1]); }
@@ -628,10 +637,10 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
       }
       else if constexpr (t.kind == a64s::T_CV) P[pq & 1][(pu * 2 + (r0 >> 3)) & 3][(r0 & 7) >> 1] = v_cvt_pk(pe0[k & 31], pe1[k & 31]);
 #ifndef VC_A64_NO_LDS
-      else if constexpr (t.kind == a64s::T_RV)       // V^T(kt) fragment (dt = f & 3, s = f >> 2), s = 0, 1
-        lds_v<decltype(SLOT_V)::value * V_TILE + (t.a & 3) * 4096>(vf[t.a & 7], v_rd[(t.a >> 2) & 3]);
-      else if constexpr (t.kind == a64s::T_RV2)      // fragment (dt, s + 2) into the register of (dt, s), retired by MFMA 8 s + 2 dt + 1
-        lds_v<decltype(SLOT_V)::value * V_TILE + (t.a & 3) * 4096>(vf[((t.b & 1) * 4 + t.a) & 7], v_rd[(t.b + 2) & 3]);
+      else if constexpr (t.kind == a64s::T_RV)       // V^T(kt) fragment (dt = a & 3, s = a >> 2) -> register b
+        lds_v<decltype(SLOT_V)::value * V_TILE + (t.a & 3) * 4096>(vf[t.b % a64s::V_REGS], v_rd[(t.a >> 2) & 3]);
+      else if constexpr (t.kind == a64s::T_RV2)      // the same, into a register the P.V phase has just retired
+        lds_v<decltype(SLOT_V)::value * V_TILE + (t.a & 3) * 4096>(vf[t.b % a64s::V_REGS], v_rd[(t.a >> 2) & 3]);
       else if constexpr (t.kind == a64s::T_RK) read_k(SLOT_K2, std::integral_constant<int, t.a & 15>{});
       else if constexpr (t.kind == a64s::T_WAIT) wait_lgkm<t.a & 15>();
 #endif
@@ -651,16 +660,17 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
       using SLOT_K4 = std::integral_constant<int, (J + 1) % 3>;      // K(kt+4) DMA
       using SA = std::integral_constant<int, BASE>;                  // S(kt)
       using SB1 = std::integral_constant<int, (BASE + 4) % 6>;       // S(kt+1)
+      // (built at the head of the tile: an MFMA in an asm statement reads a register the VALU has just written without the
+      // wait states hipcc would have inserted for its own instructions)
+      u32x4 ka[2];
+      if constexpr (MASKED) { ka[0] = make_kaug(kt + 1, 0); ka[1] = make_kaug(kt + 1, 1); }
       SB();
       // ---------------- phase A: S(kt+1) = K(kt+1) . Q^T  ||  20 pairs of P(kt), V^T(kt) fragments (s = 0, 1), V^T(kt+2) DMA ----
       sfor<0, 32>([&](auto Gp) {
         constexpr int g = decltype(Gp)::value, c = g >> 3, t = g & 7;
 #ifndef VC_A64_NO_MFMA
         mfma_qk<A_K + ((c & 1) * 8 + t) * 4, A_Q + ((c >> 1) * 8 + t) * 4, t == 0>(SBk[(BASE + 4 + c) % 6]);
-        if constexpr (t == 7 && MASKED) {  // masked keys (a tile that crosses kv_len or the gap)
-          const u32x4 ka = make_kaug(kt + 1, c & 1);
-          mfma_aug(SBk[(BASE + 4 + c) % 6], ka, qaug[c >> 1]);
-        }
+        if constexpr (t == 7 && MASKED) mfma_aug(SBk[(BASE + 4 + c) % 6], ka[c & 1], qaug[c >> 1]);     // masked keys (a tile that crosses kv_len or the gap)
 #else
         if constexpr (t == 0) asm volatile("" : "=v"(SBk[(BASE + 4 + c) % 6]));
 #endif
@@ -680,9 +690,9 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
       sfor<0, 32>([&](auto Gp) {
         constexpr int g = decltype(Gp)::value, s = g >> 3, dt = (g >> 1) & 3, qb = g & 1;
 #ifndef VC_A64_NO_MFMA
-        mfma_pv<A_O + (qb * 4 + dt) * 16>(vf[(s & 1) * 4 + dt], P[qb][s]);
+        mfma_pv<A_O + (qb * 4 + dt) * 16>(vf[a64s::PV_REG[g]], P[qb][s]);
 #else
-        asm volatile("" ::"v"(vf[(s & 1) * 4 + dt]), "v"(P[qb][s]));
+        asm volatile("" ::"v"(vf[a64s::PV_REG[g]]), "v"(P[qb][s]));
 #endif
 #ifndef VC_A64_NO_SOFTMAX
         sfor<a64s::B_FIRST[g], a64s::B_FIRST[g + 1]>([&](auto Ti) {
@@ -755,6 +765,463 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
     ++ts_seg;
 #endif
   }  // work items
+#ifdef VC_ATTN_TIMESTAMPS
+  if (a.debug_ts && tid == 0) {
+    a.debug_ts[blockIdx.x * 32 + 0] = ts0;
+    a.debug_ts[blockIdx.x * 32 + 1] = __builtin_amdgcn_s_memtime();
+    a.debug_ts[blockIdx.x * 32 + 2] = ts_tiles;
+    a.debug_ts[blockIdx.x * 32 + 3] = ts_seg;
+  }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// STREAM form of the bounded-logit kernel (round 6): the product's launches at cfg 2 / 3 / 5 - bounded logits AND queries that
+// arrive normalised, rotated and scaled from the qkv GEMM's epilogue (VcAttention.q_prescaled), so an item has no arithmetic
+// of its own.  Same tile (tile_b's generated schedule), but the K / V^T LDS-DMA stream of a workgroup does NOT stop at the
+// end of a work item: the look-ahead pieces of an item's last tiles are the next item's first tiles, the next item's query
+// fragments are requested at the start of the last tile (the Q registers are idle then: the last tile has no S(t+1) to
+// compute), and the item boundary is  last tile (P.V only) -> O out (16-byte stores, no wait) -> S'(0) = K'(0) . Q'^T with the
+// zeroing of O in its MFMA gaps -> first regular tile.  What round 5's timeline (profiles/r06a_attn64_timeline.log) charged
+// per boundary - epilogue 10.8 k ticks, prologue 7.9 k (a full DMA round trip with the matrix pipe idle), first tile 2.5 k, and
+// the 32 MFMAs of an S(t+1) that does not exist - becomes ~2 k + ~2 k.  An item of fewer than 4 tiles ends in a HARD boundary
+// (drain, prologue as below): the look-ahead beyond it was issued before its successor was known.
+template <int UNUSED>
+__global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  asm volatile("" ::: "a0", "a15", "a31", "a47", "a63", "a79", "a95", "a111", "a127", "a143", "a159", "a175", "a191", "a207",
+               "a223", "a239", "a255");
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lq = lane & 31, hh = lane >> 5;
+  const float MASKED = -29952.0f;
+
+  uint32_t k_rd[8], v_rd[4];
+  const int krow = swap23(lq);
+  {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) k_rd[t] = krow * 256 + (((2 * t + hh) ^ (krow & 15)) << 4);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) v_rd[s] = V_RING0 + lq * 128 + (((2 * s + hh) ^ ((lq >> 1) & 7)) << 4);
+  }
+  // LDS-DMA source offsets of this lane's piece 0; piece i of a tile is 16 K rows (32 V^T rows) further on - a SCALAR step (the
+  // swizzled 16-byte column of a lane is the same in all four: row & 15 and (d >> 1) & 7 do not depend on i)
+  const uint32_t k_off0 = (uint32_t)(tid >> 4) * (uint32_t)a.ld * 2u + (uint32_t)(((tid & 15) ^ ((tid >> 4) & 15)) << 4);
+  const uint32_t v_off0 = ((uint32_t)(tid >> 3) * (uint32_t)a.Lpad + (uint32_t)((((tid & 7) ^ ((tid >> 4) & 7))) << 3)) * 2u;
+  const uint32_t k_piece = 32u * (uint32_t)a.ld, v_piece = 64u * (uint32_t)a.Lpad;
+  const uint32_t k_step = (uint32_t)KVB * (uint32_t)a.ld * 2u;
+  // rows past L - 1 (the last tile of a sequence whose length is no multiple of 64) must not be fetched: their offsets are
+  // clamped to the LAST 16 bytes of row L - 1's head - a SCALAR bound (row L - 1 itself never exceeds it, every later row does);
+  // what such a lane then reads is some chunk of a real key row, and its key is masked whatever it holds
+  const uint32_t k_bound = (uint32_t)(a.L - 1) * (uint32_t)a.ld * 2u + 240u;
+  const uint32_t aug_on = hh == 0 ? 0xffffffffu : 0u;
+  const uint32_t kaug_one = 0x3f80u & aug_on;
+  const uint32_t qaug_mask = ((uint32_t)f2bf(MASKED) << 16) & aug_on;
+
+#ifdef VC_ATTN_TIMESTAMPS
+  const uint64_t ts0 = __builtin_amdgcn_s_memtime();
+  int ts_tiles = 0, ts_seg = 0;
+#endif
+  // ---- work schedule: identical to attn64_kernel's (whole items per round, then this workgroup's chunk of the XCD's tail) ----
+  const int G = gridDim.x;
+  const int L = a.L;
+  const int nkt_all = (L + KVB - 1) / KVB;
+  const bool split = a.full_rounds >= 0;
+  int tu = 0, tu_end = 0, it_first = 0, rounds_left = 0x7fffffff, id_full = blockIdx.x, id_step = G, id_tail = 0;
+  if (split) {
+    const int slot = blockIdx.x >> 3;
+    const Sched64 sc = sched64(blockIdx.x & 7, G, a.items, nkt_all);
+    tu = chunk_begin64(slot, sc.units, sc.W);
+    tu_end = chunk_begin64(slot + 1, sc.units, sc.W);
+    it_first = tu / nkt_all;
+    rounds_left = sc.rounds;
+    id_full = sc.start + slot;
+    id_step = sc.W;
+    id_tail = sc.start + sc.rounds * sc.W;
+  }
+  // one work item (or the part of a tail item) of this workgroup, as plain scalars (a struct handed to the lambdas by reference
+  // ended up in scratch memory): id, tile range, partial index, the batch element's masks, and the byte offsets of the head's
+  // K rows in qkv / V^T rows in vt (32 bits: checked by the launcher) - scalars added to the lane offset; the 64-bit bases stay
+  // the kernel arguments (hipcc moves a selected 64-bit pointer into VGPRs, which an "s" asm operand cannot take)
+#define VC_SEG(p) int p##id = 0, p##kt0 = 0, p##kt1 = 0, p##piece = -1, p##kvlen = 0, p##gap_lo = 0, p##gap_hi = 0; uint32_t p##ko = 0, p##vo = 0
+  VC_SEG(c_);
+  VC_SEG(n_);
+  bool have_next = false;
+  // fetch the next work item into the n_ set; false when the workgroup has none left
+  auto next_seg = [&]() -> bool {
+    int id, kt0 = 0, kt1 = -1, piece = -1;
+    if (rounds_left > 0) {
+      if (!split && id_full >= a.items) return false;
+      id = split ? id_full : xcd_remap(id_full, a.items);
+      id_full += id_step;
+      --rounds_left;
+    } else {
+      if (tu >= tu_end) return false;
+      const int it = tu / nkt_all;
+      kt0 = tu - it * nkt_all;
+      kt1 = min(nkt_all, kt0 + (tu_end - tu));
+      tu += kt1 - kt0;
+      id = id_tail + it;
+      if (kt1 - kt0 != nkt_all) piece = blockIdx.x * 2 + (it - it_first);
+    }
+    const int bh = id / a.qblocks;
+    const int h = bh % a.H, b = bh / a.H;
+    n_id = id; n_kt0 = kt0; n_piece = piece;
+    n_kvlen = a.kv_len ? __builtin_amdgcn_readfirstlane(a.kv_len[b]) : L;
+    n_gap_lo = a.kv_gap ? __builtin_amdgcn_readfirstlane(a.kv_gap[2 * b]) : 0;
+    n_gap_hi = a.kv_gap ? __builtin_amdgcn_readfirstlane(a.kv_gap[2 * b + 1]) : 0;
+    n_kt1 = kt1 < 0 ? (n_kvlen + KVB - 1) / KVB : kt1;
+    n_ko = ((uint32_t)b * (uint32_t)a.bstride + (uint32_t)(h * 128 + a.H * 128)) * 2u;
+    n_vo = (uint32_t)(b * a.H + h) * 128u * (uint32_t)a.Lpad * 2u;
+    return true;
+  };
+#define VC_SEG_ADVANCE do { c_id = n_id; c_kt0 = n_kt0; c_kt1 = n_kt1; c_piece = n_piece; c_kvlen = n_kvlen; c_gap_lo = n_gap_lo; \
+                            c_gap_hi = n_gap_hi; c_ko = n_ko; c_vo = n_vo; have_next = next_seg(); } while (0)
+  if (!next_seg()) return;
+  VC_SEG_ADVANCE;
+
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+
+  // LDS-DMA of stream tile n (counted in cur's tile indices: n >= c_kt1 is tile n - c_kt1 of the NEXT item) into ring slot
+  // SLOT.  Beyond the end of what is known the last tile is fetched again (never read as a real tile).
+  // M0 (the wave's LDS destination) is written INSIDE the asm statement, one s_add from ONE scalar: handed the builtin, hipcc
+  // hoists the 24 distinct destinations of the three rotations out of the loop, spills them and reloads each with a v_readlane
+  const uint32_t wave_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lptr_t)(smem + wave * 1024));
+  // Source of stream tile n (counted in cur's tile indices).  An item occupies a whole number of rotations: its tiles, then
+  // 0-2 EMPTY steps, so that every item starts at J = 0 (one instruction stream for the first step, a single-entry tile loop).
+  // n in [kt1, pad1): an empty step, nothing to fetch (the item's last tile is fetched again: never read); n >= pad1: tile
+  // n - pad1 of the NEXT item, if one is known.
+  int pad1 = 0;          // c_kt0 + 3 * ceil((c_kt1 - c_kt0) / 3), set per item
+  auto src_tile = [&](int n, bool& fwd) -> int {
+    fwd = n >= pad1 && have_next;
+    return fwd ? min(n_kt0 + (n - pad1), n_kt1 - 1) : min(n, c_kt1 - 1);
+  };
+  const char* const k_base = (const char*)a.qkv;
+  const char* const v_base = (const char*)a.vt;
+  auto dma_k = [&](auto SLOT, int n, int i) {
+    bool fwd;
+    const int kt = src_tile(n, fwd);
+    const uint32_t so = fwd ? n_ko : c_ko;
+    const uint32_t tp = (uint32_t)kt * k_step + (uint32_t)i * k_piece;
+#ifndef VC_A64_NO_DMA      // analysis builds only (wrong results): the loop without one of its ingredients
+    glds16_m0(k_base, min(k_off0 + (tp + so), k_bound + so), wave_lds, decltype(SLOT)::value * K_TILE + i * 4096);
+#endif
+  };
+  auto dma_v = [&](auto SLOT, int n, int i) {
+    bool fwd;
+    const int kt = src_tile(n, fwd);
+    const uint32_t so = fwd ? n_vo : c_vo;
+#ifndef VC_A64_NO_DMA
+    glds16_m0(v_base, v_off0 + (so + (uint32_t)kt * (KVB * 2) + (uint32_t)i * v_piece), wave_lds, V_RING0 + decltype(SLOT)::value * V_TILE + i * 4096);
+#endif
+  };
+  // the 16 query fragments of item g -> a[128:191] (waited for with vmcnt by the caller)
+  auto load_queries = [&](int g_id) {
+    const int qb_i = g_id % a.qblocks;
+    const int bh = g_id / a.qblocks;
+    const int h = bh % a.H, b = bh / a.H;
+    const bf16_t* qbase = a.qkv + (long)b * a.bstride + h * 128;
+    const int q0 = qb_i * QB + wave * QW;
+    sfor<0, 2>([&](auto QBc) {
+      constexpr int qb = decltype(QBc)::value;
+      const int tok = min(q0 + qb * 32 + lq, L - 1);
+      const bf16_t* qp = qbase + (long)tok * a.ld + hh * 8;
+      sfor<0, 8>([&](auto T) { constexpr int t = decltype(T)::value; load_q<A_Q + (qb * 8 + t) * 4, t * 32>(qp); });
+    });
+  };
+
+  f32x16 SBk[6];
+  u32x4 P[2][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) asm volatile("" : "=v"(P[i >> 2][i & 3]));
+  u32x4 vf[a64s::V_REGS];            // V^T fragment ring
+#pragma unroll
+  for (int i = 0; i < a64s::V_REGS; ++i) asm volatile("" : "=v"(vf[i]));
+  float l_acc[2] = {0.f, 0.f}, l_e[2] = {0.f, 0.f};
+  float pe0[32], pe1[32];
+
+  auto read_k = [&](auto SLOT, auto UT) {
+    constexpr int ut = decltype(UT)::value, u = ut >> 3, t = ut & 7;
+    lds_k<A_K + ut * 4, decltype(SLOT)::value * K_TILE + u * 8192>(k_rd[t]);
+  };
+  auto make_kaug = [&](int n, int u) -> u32x4 {
+    const int key = n * KVB + u * 32 + krow;
+    const uint32_t m = (key >= c_kvlen || (key >= c_gap_lo && key < c_gap_hi)) ? (0x3f800000u & aug_on) : 0u;
+    return u32x4{kaug_one | m, 0u, 0u, 0u};
+  };
+  // the 9th k-step of an S chain over a tile with masked keys: S^T += k_aug . q_aug = -29952 on the masked keys (reference
+  // point 0: bounded logits).  Cold path - both fragments are built here, with the wait states between a VALU write and an
+  // MFMA read that hipcc inserts for its own instructions and an asm statement has to bring along
+  auto masked_step = [&](f32x16& Sx, int n, int u) {
+    u32x4 ka = make_kaug(n, u);
+    u32x4 qa = {qaug_mask, 0u, 0u, 0u};
+    asm volatile("s_nop 7\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(Sx) : "v"(ka), "v"(qa));
+  };
+  auto tile_masked = [&](int n) { return n * KVB + KVB > c_kvlen || (n * KVB < c_gap_hi && n * KVB + KVB > c_gap_lo); };
+
+  // ---- one filler token of the generated schedule (attention64_sched.h); LAST: the item's last tile, which has no S(t+1) -
+  // no exponentials of it, no K fragments of the tile after it (the K registers keep K'(0) of the next item), and its counted
+  // waits, sized for the full read stream, become lgkmcnt(0) ----
+  auto run_tok = [&](auto PH, auto TI, auto LASTc, auto RKc, auto SBASE, auto SLOT_V, auto SLOT_K2, auto SLOT_K4, int kt) {
+    constexpr a64s::Tok t = tok_at<decltype(PH)::value, decltype(TI)::value>();
+    constexpr bool LAST = decltype(LASTc)::value, PB = decltype(PH)::value == 1, RK = decltype(RKc)::value;
+    constexpr int k = t.a, pq = k >> 4, idx = k & 15, pu = idx >> 3, r0 = (idx & 7) * 2;
+    constexpr int blk = (decltype(SBASE)::value + pq * 2 + pu) % 6;
+    constexpr bool is_pair = t.kind <= a64s::T_CV;
+    constexpr bool is_lds = t.kind == a64s::T_RV || t.kind == a64s::T_RV2 || t.kind == a64s::T_RK || t.kind == a64s::T_WAIT;
+#ifdef VC_A64_NO_SOFTMAX      // analysis builds only (wrong results)
+    if constexpr (is_pair) return;
+#endif
+#ifdef VC_A64_NO_LDS
+    if constexpr (is_lds) return;
+#endif
+    if constexpr (is_pair && PB && LAST) { }
+    else if constexpr (t.kind == a64s::T_E0) { pe0[k & 31] = __builtin_amdgcn_exp2f(SBk[blk][r0 & 15]); PIN(pe0[k & 31]); }
+    else if constexpr (t.kind == a64s::T_E1) { pe1[k & 31] = __builtin_amdgcn_exp2f(SBk[blk][(r0 + 1) & 15]); PIN(pe1[k & 31]); }
+    else if constexpr (t.kind == a64s::T_A0) {
+      if constexpr (!PB) l_acc[pq & 1] += pe0[k & 31];
+      else if constexpr (k != a64s::EARLY_FIRST[pq & 1]) l_e[pq & 1] += pe0[k & 31];
+    } else if constexpr (t.kind == a64s::T_A1) {
+      if constexpr (!PB) { l_acc[pq & 1] += pe1[k & 31]; PIN(l_acc[pq & 1]); }
+      else if constexpr (k != a64s::EARLY_FIRST[pq & 1]) { l_e[pq & 1] += pe1[k & 31]; PIN(l_e[pq & 1]); }
+      else { l_e[pq & 1] = pe0[k & 31] + pe1[k & 31]; PIN(l_e[pq & 1]); }
+    }
+    else if constexpr (t.kind == a64s::T_CV) P[pq & 1][(pu * 2 + (r0 >> 3)) & 3][(r0 & 7) >> 1] = v_cvt_pk(pe0[k & 31], pe1[k & 31]);
+    else if constexpr (t.kind == a64s::T_RV)
+      lds_v<decltype(SLOT_V)::value * V_TILE + (t.a & 3) * 4096>(vf[t.b % a64s::V_REGS], v_rd[(t.a >> 2) & 3]);
+    else if constexpr (t.kind == a64s::T_RV2)
+      lds_v<decltype(SLOT_V)::value * V_TILE + (t.a & 3) * 4096>(vf[t.b % a64s::V_REGS], v_rd[(t.a >> 2) & 3]);
+    else if constexpr (t.kind == a64s::T_RK) { if constexpr (RK) read_k(SLOT_K2, std::integral_constant<int, t.a & 15>{}); }
+    else if constexpr (t.kind == a64s::T_WAIT) { if constexpr (LAST) wait_lgkm<0>(); else wait_lgkm<t.a & 15>(); }
+    else if constexpr (t.kind == a64s::T_DMA) {
+      if constexpr (t.a < 4) dma_v(SLOT_K2, kt + 2, t.a & 3);
+      else dma_k(SLOT_K4, kt + 4, t.a & 3);
+    }
+  };
+  // ---- one tile: J = (stream tile index) % 3 selects ring slots and S block roles (attn64_kernel's tile_b) ----
+  // LAST: the item's last tile - no S(t+1), no exponentials of it.  The K registers must hold K'(0) of the next item when its
+  // first step runs: the step TWO positions before it reads them (a regular tile's K(t+2) read; with one empty step after the
+  // last tile that is the last tile itself: J = 1), the step in between reads none.
+  auto tile_s = [&](auto Jc, auto LASTc, int kt) {
+    constexpr int J = decltype(Jc)::value;
+    constexpr bool LAST = decltype(LASTc)::value;
+    using RKc = std::integral_constant<bool, !LAST || J == 1>;
+    constexpr int BASE = (4 * J) % 6;
+    using SLOT_V = std::integral_constant<int, J>;
+    using SLOT_K2 = std::integral_constant<int, (J + 2) % 3>;
+    using SLOT_K4 = std::integral_constant<int, (J + 1) % 3>;
+    using SA = std::integral_constant<int, BASE>;
+    using SB1 = std::integral_constant<int, (BASE + 4) % 6>;
+    // S(kt+1) covers masked keys (it crosses kv_len or the gap: an item's last tile, or none): its four chains take the
+    // (0, -29952) k-step.  ONE scalar decides (a second instruction stream per J for the masked tile cost 48 registers of
+    // allocation slack); the k_aug fragments are built at the head of the tile - an MFMA in an asm statement reads a register
+    // the VALU has just written without the wait states hipcc inserts for its own instructions (masked_step pads them).
+    const bool msk = !LAST && tile_masked(kt + 1);
+    SB();
+    sfor<0, 32>([&](auto Gp) {
+      constexpr int g = decltype(Gp)::value, c = g >> 3, t = g & 7;
+      if constexpr (!LAST) {
+        mfma_qk<A_K + ((c & 1) * 8 + t) * 4, A_Q + ((c >> 1) * 8 + t) * 4, t == 0>(SBk[(BASE + 4 + c) % 6]);
+        if constexpr (t == 7) { if (__builtin_expect(msk, 0)) masked_step(SBk[(BASE + 4 + c) % 6], kt + 1, c & 1); }
+      }
+      if constexpr (g == 0) {
+        l_acc[0] += l_e[0];
+        l_acc[1] += l_e[1];
+      }
+      sfor<a64s::A_FIRST[g], a64s::A_FIRST[g + 1]>([&](auto Ti) { run_tok(I0{}, Ti, LASTc, RKc{}, SA{}, SLOT_V{}, SLOT_K2{}, SLOT_K4{}, kt); });
+      SB();
+    });
+    sfor<0, 32>([&](auto Gp) {
+      constexpr int g = decltype(Gp)::value, s = g >> 3, dt = (g >> 1) & 3, qb = g & 1;
+      mfma_pv<A_O + (qb * 4 + dt) * 16>(vf[a64s::PV_REG[g]], P[qb][s]);
+      sfor<a64s::B_FIRST[g], a64s::B_FIRST[g + 1]>([&](auto Ti) { run_tok(I1{}, Ti, LASTc, RKc{}, SB1{}, SLOT_V{}, SLOT_K2{}, SLOT_K4{}, kt); });
+      SB();
+    });
+#ifndef VC_A64_NO_DMA
+    wait_vm<8>();
+#endif
+    wait_lgkm<0>();
+#ifndef VC_A64_NO_BARRIER
+    __builtin_amdgcn_s_barrier();
+#endif
+    SB();
+  };
+  // ---- an EMPTY step of rotation J at stream position n (between an item's last tile and the rotation boundary): only the
+  // stream's LDS-DMA (V^T(n+2), K(n+4): the next item's first tiles) and the step's waits; READ_K: the K'(0) fragments ----
+  auto empty_s = [&](auto Jc, auto RKc, int n) {
+    constexpr int J = decltype(Jc)::value;
+    using SLOT_K2 = std::integral_constant<int, (J + 2) % 3>;
+    using SLOT_K4 = std::integral_constant<int, (J + 1) % 3>;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_v(SLOT_K2{}, n + 2, i);
+    if constexpr (decltype(RKc)::value) sfor<0, 16>([&](auto UT) { read_k(SLOT_K2{}, UT); });
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_k(SLOT_K4{}, n + 4, i);
+    wait_vm<8>();
+    wait_lgkm<0>();
+    __builtin_amdgcn_s_barrier();
+    SB();
+  };
+  // ---- the first step of an item (always rotation J = 0): S(kt0) = K(kt0) . Q^T from the K fragments in a[192:255], O
+  // cleared in the MFMA gaps; then the K fragments of the item's second tile (ring slot 1) and the pairs that the P.V phase
+  // of a previous tile would have exponentiated ----
+  auto first_s = [&](bool hard_start) {
+    const bool msk0 = tile_masked(c_kt0);
+    SB();
+    sfor<0, 32>([&](auto Gp) {
+      constexpr int g = decltype(Gp)::value, c = g >> 3, t = g & 7;
+      mfma_qk<A_K + ((c & 1) * 8 + t) * 4, A_Q + ((c >> 1) * 8 + t) * 4, t == 0>(SBk[c]);
+      if constexpr (t == 7) {
+        if (__builtin_expect(msk0, 0)) masked_step(SBk[c], c_kt0, c & 1);
+      }
+      sfor<0, 4>([&](auto Zc) { agpr_write<A_O + g * 4 + decltype(Zc)::value>(0.f); });
+      SB();
+    });
+    if (hard_start) {                   // K(kt0+1) landed (V^T(0), K(2), V^T(1), K(3) behind it), in every wave
+      wait_vm<16>();
+      __builtin_amdgcn_s_barrier();
+    }
+    sfor<0, 16>([&](auto UT) { read_k(I1{}, UT); });
+    asm volatile("s_nop 15" ::: "memory");                          // S complete before the VALU reads it
+    SB();
+    l_acc[0] = l_acc[1] = 0.f;
+    l_e[0] = l_e[1] = 0.f;
+    sfor<0, a64s::N_EARLY>([&](auto Ic) {
+      constexpr int k = a64s::EARLY_PAIR[decltype(Ic)::value], pq = k >> 4, idx = k & 15, pu = idx >> 3, r0 = (idx & 7) * 2;
+      const float e0 = __builtin_amdgcn_exp2f(SBk[pq * 2 + pu][r0]), e1 = __builtin_amdgcn_exp2f(SBk[pq * 2 + pu][r0 + 1]);
+      l_e[pq] += e0;
+      l_e[pq] += e1;
+      P[pq][pu * 2 + (r0 >> 3)][(r0 & 7) >> 1] = v_cvt_pk(e0, e1);
+    });
+    if (hard_start) wait_vm<8>();       // V^T(0) and K(2) landed: the first tile reads them
+    wait_lgkm<0>();
+    __builtin_amdgcn_s_barrier();      // every wave holds the fragments of the item's second K tile: the tile after next may overwrite the slot
+    SB();
+  };
+  // ---- O of cur -> out (or the partial of a tail piece); no wait: the stores drain behind the next tiles ----
+  auto store_out = [&]() {
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");               // the last P.V MFMAs retired before a[0:127] is read
+    const int qb_i = c_id % a.qblocks;
+    const int bh = c_id / a.qblocks;
+    const int h = bh % a.H, b = bh / a.H;
+    const int q0 = qb_i * QB + wave * QW;
+    if (c_piece >= 0) {
+      char* pp = (char*)a.part + (long)c_piece * PART64_BYTES;
+      sfor<0, 2>([&](auto QBc) {
+        constexpr int qb = decltype(QBc)::value;
+        const float l_tot = xsum32(l_acc[qb]);
+        const float inv = 1.0f / l_tot;
+        sfor<0, 16>([&](auto Gq) {
+          constexpr int g = decltype(Gq)::value, A0 = A_O + (qb * 4 + (g >> 2)) * 16 + (g & 3) * 4;
+          const f16x4 w = {(_Float16)(agpr_read<A0 + 0>() * inv), (_Float16)(agpr_read<A0 + 1>() * inv),
+                           (_Float16)(agpr_read<A0 + 2>() * inv), (_Float16)(agpr_read<A0 + 3>() * inv)};
+          *(f16x4*)(pp + (((wave * 2 + qb) * 16 + g) * 64 + lane) * 8) = w;
+        });
+        const f32x2 ml = {0.f, l_tot};                                // reference point 0: bounded logits
+        *(f32x2*)(pp + PART64_O_BYTES + ((wave * 2 + qb) * 64 + lane) * 8) = ml;
+      });
+    } else {
+      sfor<0, 2>([&](auto QBc) {
+        constexpr int qb = decltype(QBc)::value;
+        const float l_tot = xsum32(l_acc[qb]);
+        const int q = q0 + qb * 32 + lq;
+        const float inv = (q < c_kvlen && !(q >= c_gap_lo && q < c_gap_hi)) ? 1.0f / l_tot : 0.0f;     // padded query rows -> 0
+        bf16_t* orow = a.out + (long)b * a.out_bstride + (long)min(q, L - 1) * a.ldo + h * 128 + hh * 8;
+        // a lane holds d = 8 g + 4 hh + (0..3) of its query per 4 registers: the half-waves exchange so that the lower one owns
+        // d = 16 m .. 16 m + 7 and the upper one 16 m + 8 .. 16 m + 15 - one 16-byte store per pair of groups
+        sfor<0, 8>([&](auto Mq) {
+          constexpr int m = decltype(Mq)::value, dt = m >> 1, A0 = A_O + (qb * 4 + dt) * 16 + (m & 1) * 8;
+          uint32_t x0 = pack2bf(agpr_read<A0 + 0>() * inv, agpr_read<A0 + 1>() * inv), x1 = pack2bf(agpr_read<A0 + 2>() * inv, agpr_read<A0 + 3>() * inv);
+          uint32_t y0 = pack2bf(agpr_read<A0 + 4>() * inv, agpr_read<A0 + 5>() * inv), y1 = pack2bf(agpr_read<A0 + 6>() * inv, agpr_read<A0 + 7>() * inv);
+          asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x0), "+v"(y0));
+          asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x1), "+v"(y1));
+          const u32x4 w = {x0, x1, y0, y1};
+          if (q < L) *(u32x4*)(orow + dt * 32 + (m & 1) * 16) = w;
+        });
+      });
+    }
+  };
+
+  // =================================================== the item loop ===================================================
+#ifdef VC_ATTN_TIMESTAMPS
+#define TS_S(k) do { if (a.debug_ts && tid == 0 && ts_seg < 3) a.debug_ts[blockIdx.x * 32 + 8 + ts_seg * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TS_S(k) do { } while (0)
+#endif
+  bool hard = true;
+  for (;;) {
+    pad1 = c_kt0 + (c_kt1 - c_kt0 + 2) / 3 * 3;
+#ifdef VC_ATTN_TIMESTAMPS
+    ts_tiles += c_kt1 - c_kt0;
+    if (a.debug_ts && tid == 0 && ts_seg < 3) a.debug_ts[blockIdx.x * 32 + 8 + ts_seg * 8 + 5] = c_kt1 - c_kt0;
+#endif
+    TS_S(0);
+    if (hard) {
+      // ---- HARD start: every wait stands in front of its first consumer.  Issue order K(0), Q, K(1), V^T(0), K(2), V^T(1)
+      // [then K(3)]: S(kt0) needs K(0) and Q only; the rest lands under it (first_s waits for K(1) before it reads its fragments,
+      // for V^T(0) and K(2) before the first tile; V^T(1) and K(3) are covered by that tile's own counted wait) ----
+      const int kt0 = c_kt0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dma_k(I0{}, kt0, i);
+      load_queries(c_id);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dma_k(I1{}, kt0 + 1, i);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dma_v(I0{}, kt0, i);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dma_k(I2{}, kt0 + 2, i);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dma_v(I1{}, kt0 + 1, i);
+      wait_vm<16>();                     // K(kt0) and the query fragments have landed
+      __builtin_amdgcn_s_barrier();
+      SB();
+      sfor<0, 16>([&](auto UT) { read_k(I0{}, UT); });
+      wait_lgkm<0>();
+      __builtin_amdgcn_s_barrier();      // every wave holds its K(kt0) fragments: slot 0 may take K(kt0+3)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dma_k(I0{}, kt0 + 3, i);
+      SB();
+    }
+    TS_S(1);
+    first_s(hard);
+    TS_S(2);
+    // ---- the item's tiles but the last: a single-entry loop over the three rotations ----
+    int kt = c_kt0, exit_j;
+    const int kt_last = c_kt1 - 1;
+    for (;;) {
+      if (kt >= kt_last) { exit_j = 0; break; }
+      tile_s(I0{}, std::false_type{}, kt); ++kt;
+      if (kt >= kt_last) { exit_j = 1; break; }
+      tile_s(I1{}, std::false_type{}, kt); ++kt;
+      if (kt >= kt_last) { exit_j = 2; break; }
+      tile_s(I2{}, std::false_type{}, kt); ++kt;
+    }
+    // ---- the last tile (P.V only), the empty steps up to the rotation boundary, O out ----
+    const bool soft = have_next && (c_kt1 - c_kt0) >= 4;     // the look-ahead of a shorter item was issued before its successor was known
+    if (soft) load_queries(n_id);            // the Q registers are idle: the last tile computes no S(t+1)
+    if (exit_j == 0) {
+      tile_s(I0{}, std::true_type{}, kt);
+      if (soft) { empty_s(I1{}, std::true_type{}, kt + 1); empty_s(I2{}, std::false_type{}, kt + 2); }
+    } else if (exit_j == 1) {
+      tile_s(I1{}, std::true_type{}, kt);
+      if (soft) empty_s(I2{}, std::false_type{}, kt + 1);
+    } else {
+      tile_s(I2{}, std::true_type{}, kt);
+    }
+    TS_S(3);
+    store_out();
+    TS_S(4);
+#ifdef VC_ATTN_TIMESTAMPS
+    ++ts_seg;
+#endif
+    if (!have_next) break;
+    VC_SEG_ADVANCE;
+    hard = !soft;
+    if (hard) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's look-ahead pieces land before the ring restarts
+  }
 #ifdef VC_ATTN_TIMESTAMPS
   if (a.debug_ts && tid == 0) {
     a.debug_ts[blockIdx.x * 32 + 0] = ts0;
@@ -874,13 +1341,19 @@ int vc_attention64_launch(const VcAttention& A, bool tail_split, int n_cu, uint6
   if (done.need()) {
     e = hipFuncSetAttribute((const void*)attn64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn64s_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
     if (e != hipSuccess) { snprintf(err, errlen, "attention64 attribute: %s", hipGetErrorString(e)); return VC_ERR_HIP; }
     done.mark();
   }
   // logits bounded by the caller (|x| <= logit_bound in the log2 domain): 2^x, a row's sum over L keys and O stay far inside
   // f32 for bound <= 100, so the softmax needs no running max (kernel header)
   const bool bounded = A.logit_bound > 0.0f && A.logit_bound <= 100.0f;
-  void (*kern)(const Attn64Args) = bounded ? attn64_kernel<true> : attn64_kernel<false>;
+  // bounded logits + prescaled queries (the product's launches wherever this kernel runs): the stream form
+  // (its LDS-DMA addresses are kernel-argument base + 32-bit byte offset)
+  const bool fits32 = ((uint64_t)B * (uint64_t)A.bstride + (uint64_t)L * (uint64_t)A.ld + 3u * (uint64_t)H * 128u) * 2u < (1ull << 32) &&
+                      (uint64_t)B * (uint64_t)H * 128u * (uint64_t)A.Lpad * 2u < (1ull << 32) && L >= 16;
+  const bool stream = bounded && a.q_pre && !A.q_scale && fits32;
+  void (*kern)(const Attn64Args) = stream ? attn64s_kernel<0> : bounded ? attn64_kernel<true> : attn64_kernel<false>;
   const int G = n_cu;
   const int nkt = (L + KVB - 1) / KVB;
   // the tail split is scheduled per XCD (Sched64): cut where some XCD has tail items and cutting shortens its critical

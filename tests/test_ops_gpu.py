@@ -723,6 +723,48 @@ def test_attention_with_prescaled_queries(hip, variant, L, H, extra, kv_len, spl
         hip.attention(w2, vt, o2, L, H, variant=variant, B=B, q_prescaled=True, q_norm=(qs, qs2, split, rope))
 
 
+@pytest.mark.parametrize("L,H,B", [(3968, 24, 1), (4000, 24, 1), (3752, 24, 1), (6656, 24, 1), (2100, 24, 2), (1100, 24, 4),
+                                   (2700, 24, 1),      # 264 items: ONE tail item per XCD, cut into 32 pieces of 1-2 tiles (hard boundaries)
+                                   (2500, 24, 1)])     # 240 items < 256 workgroups: every item is a tail item, no whole item follows the pieces
+def test_attention_stream_form_tail_combined_in_launch(hip, L, H, B):
+    """The stream form of the one-wave-per-SIMD kernel (bounded logits + prescaled queries: the product's launches) with the
+    tail split at full head count: variant 12 (pieces combined by attn64_merge_kernel) and variant 28 (pieces made FIRST and
+    combined at the end of the same launch through flag words of the zero-initialised scratch - VcAttention.variant bit 16)
+    must be BIT-IDENTICAL, launch after launch (a launch leaves every flag word zero for the next one), and agree with the
+    unsplit kernel (variant 8: another f32 summation order for the tail rows) and with the f32 torch softmax on a sample of
+    heads.  Lengths off the 64-key tile and off the 256-query item included."""
+    ld = 3 * H * 128
+    qkv = rnd(B * L, ld, seed=21)
+    qs, ks = torch.ones(128, dtype=torch.bfloat16, device=DEV), torch.ones(128, dtype=torch.bfloat16, device=DEV)
+    rope = torch.stack([rope_table(L)] * B).contiguous() if B > 1 else rope_table(L)
+    Lpad = (L + 63) // 64 * 64
+    vt = torch.zeros((B, H, 128, Lpad), dtype=torch.bfloat16, device=DEV)
+    w = qkv.clone()
+    hip.qknorm_rope_vt(w, qs, ks, rope, vt, L, H, B=B, parts=hip.QKN_Q | hip.QKN_K | hip.QKN_VT | hip.QKN_QPRE)
+    outs = {}
+    for variant in (8, 12, 28, 28, 12, 28):
+        o = torch.full((B * L, H * 128), float("nan"), dtype=torch.bfloat16, device=DEV)
+        hip.attention(w, vt, o, L, H, variant=variant, B=B, q_prescaled=True, logit_bound=16.65)
+        torch.cuda.synchronize()
+        assert torch.isfinite(o.float()).all(), variant
+        if variant in outs and variant != 8:
+            assert torch.equal(o, outs[variant]), f"variant {variant} is not reproducible from launch to launch"
+        outs[variant] = o
+    assert torch.equal(outs[28], outs[12])                                  # same pieces, same order of combination
+    check(outs[12], outs[8].float(), tol=1e-2)
+    scr = hip.attention_scratch(torch.device(DEV))
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    off = 2 * n_cu * (4 * 2 * 16 * 64 * 8 + 4 * 2 * 64 * 8)                  # the pieces (two per workgroup), then the flag words
+    assert int(scr[off:off + n_cu * 16].to(torch.int32).sum()) == 0          # every flag word is zero again
+    # the f32 function on two heads of the first sample
+    x = qkv[:L]
+    qn, kn, _ = R.qknorm_rope_ref(x, qs, ks, rope[0] if B > 1 else rope, H)
+    v = x[:, 2 * H * 128: 3 * H * 128].float().reshape(L, H, 128)
+    for h in (0, H - 1):
+        ref = R.attention_ref(qn[:, h:h + 1], kn[:, h:h + 1], v[:, h:h + 1], None)
+        check(outs[28][:L, h * 128:(h + 1) * 128], ref)
+
+
 @pytest.mark.parametrize("variant", [0, 3, 8, 12])
 @pytest.mark.parametrize("L,lo,hi,kv", [(320, 0, 128, 320), (320, 0, 100, 300), (200, 0, 64, 200), (512, 0, 192, 470), (96, 0, 64, 96)])
 def test_attention_leading_keys_masked(hip, variant, L, lo, hi, kv):

@@ -15,7 +15,7 @@ for L in Ls:
     qkv = torch.randn(L, 3 * H * 128, device=dev).to(torch.bfloat16)
     vt = torch.randn(H, 128, Lp, device=dev).to(torch.bfloat16)
     o = torch.empty(L, H * 128, dtype=torch.bfloat16, device=dev)
-    for variant in (8, 12):
+    for variant in ([int(os.environ["VC_CLOCK_VARIANT"])] if "VC_CLOCK_VARIANT" in os.environ else [8, 12]):
         ts = torch.zeros(256, 32, dtype=torch.int64, device=dev)
         for _ in range(3):
             hip.attention(qkv, vt, o, L, H, variant=variant, **KW)

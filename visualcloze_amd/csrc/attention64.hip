@@ -65,6 +65,8 @@ struct Attn64Args {
   // optional in-kernel QKNorm + RoPE of the query rows (q_scale != nullptr): as vc_qknorm_rope_vt
   const bf16_t* q_scale; const bf16_t* q_scale2; const float* rope; int64_t rope_bstride; int32_t split;
   int32_t q_pre;        // the q columns hold normalised, rotated queries times 128^-0.5 * log2(e) (VcAttention.q_prescaled)
+  int32_t inmerge;      // stream form only: tail pieces FIRST, combined at the end of the same launch (flags below), no merge kernel
+  uint32_t* flags;      // [2 pieces per workgroup][2 query blocks]: 1 = piece complete and visible; zero before and after a launch
   uint64_t* debug_ts;   // profiling builds only (-DVC_ATTN_TIMESTAMPS): 32 words per workgroup (start, end, tiles, items; 8 per work item)
 };
 // BOUNDED (VcAttention.logit_bound): the caller guarantees |c q.k| <= bound (log2 domain) for every query / key pair - with
@@ -92,6 +94,20 @@ constexpr int PART64_O_BYTES = 4 * 2 * 16 * 64 * 8;
 constexpr int PART64_BYTES = PART64_O_BYTES + 4 * 2 * 64 * 8;
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 VC_DEV int chunk_begin64(int c, int units, int chunks) { return (int)(((long)c * units) / chunks); }
+// one piece folded into the running combination of a tail item: acc = acc * keep + w * O_p with w = l_p 2^(m_p - m), keep =
+// 2^(m_old - m).  ONE definition with explicit fused multiply-adds for the merge kernel and for the in-launch combine of the
+// stream form: left to the optimiser, the two loops contract differently and the two routes differ in the last bit.
+VC_DEV void merge_fold64(float (&acc)[16][4], float& wsum, float& m, const f16x4 (&v)[16], const f32x2 ml) {
+  const float m_new = fmaxf(m, ml[0]);
+  const float keep = __builtin_amdgcn_exp2f(m - m_new);          // 0 on the first piece (m = -inf), 1 while the maximum stands
+  const float w = ml[1] * __builtin_amdgcn_exp2f(ml[0] - m_new);
+  m = m_new;
+  wsum = __builtin_fmaf(wsum, keep, w);
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[i][e] = __builtin_fmaf(w, (float)v[i][e], acc[i][e] * keep);
+}
 
 // Work schedule of the persistent grid, PER XCD (grid % 8 == 0; block b runs on XCD b % 8 - observed placement, used for
 // speed only).  XCD x owns the contiguous logical items [start, start + n) that xcd_remap gives it: all query blocks of a
@@ -851,7 +867,9 @@ __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
   // fetch the next work item into the n_ set; false when the workgroup has none left
   auto next_seg = [&]() -> bool {
     int id, kt0 = 0, kt1 = -1, piece = -1;
-    if (rounds_left > 0) {
+    // a.inmerge: the workgroup's share of the tail comes FIRST, so that its pieces have long been published when the
+    // workgroups that combine them (at the very end of their own work) ask for them
+    if (rounds_left > 0 && !(a.inmerge && tu < tu_end)) {
       if (!split && id_full >= a.items) return false;
       id = split ? id_full : xcd_remap(id_full, a.items);
       id_full += id_step;
@@ -901,23 +919,32 @@ __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
   };
   const char* const k_base = (const char*)a.qkv;
   const char* const v_base = (const char*)a.vt;
-  auto dma_k = [&](auto SLOT, int n, int i) {
+  // scalar part of a tile's source offsets (computed ONCE per tile, at its head: the ~15 scalar instructions of the look-ahead
+  // mapping stay out of the MFMA gaps), then one piece = one v_add (+ v_min for K) and the asm statement
+  auto k_src = [&](int n, uint32_t& bound) -> uint32_t {
     bool fwd;
     const int kt = src_tile(n, fwd);
     const uint32_t so = fwd ? n_ko : c_ko;
-    const uint32_t tp = (uint32_t)kt * k_step + (uint32_t)i * k_piece;
-#ifndef VC_A64_NO_DMA      // analysis builds only (wrong results): the loop without one of its ingredients
-    glds16_m0(k_base, min(k_off0 + (tp + so), k_bound + so), wave_lds, decltype(SLOT)::value * K_TILE + i * 4096);
-#endif
+    bound = k_bound + so;
+    return (uint32_t)kt * k_step + so;
   };
-  auto dma_v = [&](auto SLOT, int n, int i) {
+  auto v_src = [&](int n) -> uint32_t {
     bool fwd;
     const int kt = src_tile(n, fwd);
-    const uint32_t so = fwd ? n_vo : c_vo;
-#ifndef VC_A64_NO_DMA
-    glds16_m0(v_base, v_off0 + (so + (uint32_t)kt * (KVB * 2) + (uint32_t)i * v_piece), wave_lds, V_RING0 + decltype(SLOT)::value * V_TILE + i * 4096);
+    return (fwd ? n_vo : c_vo) + (uint32_t)kt * (KVB * 2);
+  };
+  auto dma_k_at = [&](auto SLOT, uint32_t sc, uint32_t bound, int i) {
+#ifndef VC_A64_NO_DMA      // analysis builds only (wrong results): the loop without one of its ingredients
+    glds16_m0(k_base, min(k_off0 + (sc + (uint32_t)i * k_piece), bound), wave_lds, decltype(SLOT)::value * K_TILE + i * 4096);
 #endif
   };
+  auto dma_v_at = [&](auto SLOT, uint32_t sc, int i) {
+#ifndef VC_A64_NO_DMA
+    glds16_m0(v_base, v_off0 + (sc + (uint32_t)i * v_piece), wave_lds, V_RING0 + decltype(SLOT)::value * V_TILE + i * 4096);
+#endif
+  };
+  auto dma_k = [&](auto SLOT, int n, int i) { uint32_t bd; const uint32_t sc = k_src(n, bd); dma_k_at(SLOT, sc, bd, i); };
+  auto dma_v = [&](auto SLOT, int n, int i) { dma_v_at(SLOT, v_src(n), i); };
   // the 16 query fragments of item g -> a[128:191] (waited for with vmcnt by the caller)
   auto load_queries = [&](int g_id) {
     const int qb_i = g_id % a.qblocks;
@@ -942,6 +969,7 @@ __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
   for (int i = 0; i < a64s::V_REGS; ++i) asm volatile("" : "=v"(vf[i]));
   float l_acc[2] = {0.f, 0.f}, l_e[2] = {0.f, 0.f};
   float pe0[32], pe1[32];
+  int pub = -1;                       // a.inmerge: the piece whose flags are still to be set
 
   auto read_k = [&](auto SLOT, auto UT) {
     constexpr int ut = decltype(UT)::value, u = ut >> 3, t = ut & 7;
@@ -965,18 +993,17 @@ __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
   // ---- one filler token of the generated schedule (attention64_sched.h); LAST: the item's last tile, which has no S(t+1) -
   // no exponentials of it, no K fragments of the tile after it (the K registers keep K'(0) of the next item), and its counted
   // waits, sized for the full read stream, become lgkmcnt(0) ----
-  auto run_tok = [&](auto PH, auto TI, auto LASTc, auto RKc, auto SBASE, auto SLOT_V, auto SLOT_K2, auto SLOT_K4, int kt) {
+  auto run_tok = [&](auto PH, auto TI, auto LASTc, auto RKc, auto SBASE, auto SLOT_V, auto SLOT_K2, auto SLOT_K4, uint32_t v_sc, uint32_t k_sc, uint32_t k_bd) {
     constexpr a64s::Tok t = tok_at<decltype(PH)::value, decltype(TI)::value>();
     constexpr bool LAST = decltype(LASTc)::value, PB = decltype(PH)::value == 1, RK = decltype(RKc)::value;
     constexpr int k = t.a, pq = k >> 4, idx = k & 15, pu = idx >> 3, r0 = (idx & 7) * 2;
     constexpr int blk = (decltype(SBASE)::value + pq * 2 + pu) % 6;
     constexpr bool is_pair = t.kind <= a64s::T_CV;
-    constexpr bool is_lds = t.kind == a64s::T_RV || t.kind == a64s::T_RV2 || t.kind == a64s::T_RK || t.kind == a64s::T_WAIT;
 #ifdef VC_A64_NO_SOFTMAX      // analysis builds only (wrong results)
     if constexpr (is_pair) return;
 #endif
 #ifdef VC_A64_NO_LDS
-    if constexpr (is_lds) return;
+    if constexpr (t.kind == a64s::T_RV || t.kind == a64s::T_RV2 || t.kind == a64s::T_RK || t.kind == a64s::T_WAIT) return;
 #endif
     if constexpr (is_pair && PB && LAST) { }
     else if constexpr (t.kind == a64s::T_E0) { pe0[k & 31] = __builtin_amdgcn_exp2f(SBk[blk][r0 & 15]); PIN(pe0[k & 31]); }
@@ -997,8 +1024,8 @@ __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
     else if constexpr (t.kind == a64s::T_RK) { if constexpr (RK) read_k(SLOT_K2, std::integral_constant<int, t.a & 15>{}); }
     else if constexpr (t.kind == a64s::T_WAIT) { if constexpr (LAST) wait_lgkm<0>(); else wait_lgkm<t.a & 15>(); }
     else if constexpr (t.kind == a64s::T_DMA) {
-      if constexpr (t.a < 4) dma_v(SLOT_K2, kt + 2, t.a & 3);
-      else dma_k(SLOT_K4, kt + 4, t.a & 3);
+      if constexpr (t.a < 4) dma_v_at(SLOT_K2, v_sc, t.a & 3);
+      else dma_k_at(SLOT_K4, k_sc, k_bd, t.a & 3);
     }
   };
   // ---- one tile: J = (stream tile index) % 3 selects ring slots and S block roles (attn64_kernel's tile_b) ----
@@ -1020,6 +1047,8 @@ __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
     // allocation slack); the k_aug fragments are built at the head of the tile - an MFMA in an asm statement reads a register
     // the VALU has just written without the wait states hipcc inserts for its own instructions (masked_step pads them).
     const bool msk = !LAST && tile_masked(kt + 1);
+    uint32_t k_bd;
+    const uint32_t k_sc = k_src(kt + 4, k_bd), v_sc = v_src(kt + 2);     // the stream's look-ahead: V^T(kt+2), K(kt+4)
     SB();
     sfor<0, 32>([&](auto Gp) {
       constexpr int g = decltype(Gp)::value, c = g >> 3, t = g & 7;
@@ -1031,13 +1060,13 @@ __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
         l_acc[0] += l_e[0];
         l_acc[1] += l_e[1];
       }
-      sfor<a64s::A_FIRST[g], a64s::A_FIRST[g + 1]>([&](auto Ti) { run_tok(I0{}, Ti, LASTc, RKc{}, SA{}, SLOT_V{}, SLOT_K2{}, SLOT_K4{}, kt); });
+      sfor<a64s::A_FIRST[g], a64s::A_FIRST[g + 1]>([&](auto Ti) { run_tok(I0{}, Ti, LASTc, RKc{}, SA{}, SLOT_V{}, SLOT_K2{}, SLOT_K4{}, v_sc, k_sc, k_bd); });
       SB();
     });
     sfor<0, 32>([&](auto Gp) {
       constexpr int g = decltype(Gp)::value, s = g >> 3, dt = (g >> 1) & 3, qb = g & 1;
       mfma_pv<A_O + (qb * 4 + dt) * 16>(vf[a64s::PV_REG[g]], P[qb][s]);
-      sfor<a64s::B_FIRST[g], a64s::B_FIRST[g + 1]>([&](auto Ti) { run_tok(I1{}, Ti, LASTc, RKc{}, SB1{}, SLOT_V{}, SLOT_K2{}, SLOT_K4{}, kt); });
+      sfor<a64s::B_FIRST[g], a64s::B_FIRST[g + 1]>([&](auto Ti) { run_tok(I1{}, Ti, LASTc, RKc{}, SB1{}, SLOT_V{}, SLOT_K2{}, SLOT_K4{}, v_sc, k_sc, k_bd); });
       SB();
     });
 #ifndef VC_A64_NO_DMA
@@ -1114,15 +1143,23 @@ __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
         constexpr int qb = decltype(QBc)::value;
         const float l_tot = xsum32(l_acc[qb]);
         const float inv = 1.0f / l_tot;
+        // a.inmerge: another workgroup of THIS launch reads the piece - 8-byte agent-scope stores (write-through, `sc1`)
+        // here, agent-scope loads there, a flag in between (cdna_hip_programming.md Guideline 16, form R1); else plain stores
+        // for the merge kernel behind the launch boundary
         sfor<0, 16>([&](auto Gq) {
           constexpr int g = decltype(Gq)::value, A0 = A_O + (qb * 4 + (g >> 2)) * 16 + (g & 3) * 4;
           const f16x4 w = {(_Float16)(agpr_read<A0 + 0>() * inv), (_Float16)(agpr_read<A0 + 1>() * inv),
                            (_Float16)(agpr_read<A0 + 2>() * inv), (_Float16)(agpr_read<A0 + 3>() * inv)};
-          *(f16x4*)(pp + (((wave * 2 + qb) * 16 + g) * 64 + lane) * 8) = w;
+          char* dst = pp + (((wave * 2 + qb) * 16 + g) * 64 + lane) * 8;
+          if (a.inmerge) __hip_atomic_store((uint64_t*)dst, __builtin_bit_cast(uint64_t, w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else *(f16x4*)dst = w;
         });
         const f32x2 ml = {0.f, l_tot};                                // reference point 0: bounded logits
-        *(f32x2*)(pp + PART64_O_BYTES + ((wave * 2 + qb) * 64 + lane) * 8) = ml;
+        char* dml = pp + PART64_O_BYTES + ((wave * 2 + qb) * 64 + lane) * 8;
+        if (a.inmerge) __hip_atomic_store((uint64_t*)dml, __builtin_bit_cast(uint64_t, ml), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *(f32x2*)dml = ml;
       });
+      pub = c_piece;                                                  // (published one item later: see the item loop)
     } else {
       sfor<0, 2>([&](auto QBc) {
         constexpr int qb = decltype(QBc)::value;
@@ -1134,8 +1171,9 @@ __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
         // d = 16 m .. 16 m + 7 and the upper one 16 m + 8 .. 16 m + 15 - one 16-byte store per pair of groups
         sfor<0, 8>([&](auto Mq) {
           constexpr int m = decltype(Mq)::value, dt = m >> 1, A0 = A_O + (qb * 4 + dt) * 16 + (m & 1) * 8;
-          uint32_t x0 = pack2bf(agpr_read<A0 + 0>() * inv, agpr_read<A0 + 1>() * inv), x1 = pack2bf(agpr_read<A0 + 2>() * inv, agpr_read<A0 + 3>() * inv);
-          uint32_t y0 = pack2bf(agpr_read<A0 + 4>() * inv, agpr_read<A0 + 5>() * inv), y1 = pack2bf(agpr_read<A0 + 6>() * inv, agpr_read<A0 + 7>() * inv);
+          // (v_cvt_pk_bf16_f32: the same round-to-nearest-even as the two conversions of pack2bf, in one instruction)
+          uint32_t x0 = v_cvt_pk(agpr_read<A0 + 0>() * inv, agpr_read<A0 + 1>() * inv), x1 = v_cvt_pk(agpr_read<A0 + 2>() * inv, agpr_read<A0 + 3>() * inv);
+          uint32_t y0 = v_cvt_pk(agpr_read<A0 + 4>() * inv, agpr_read<A0 + 5>() * inv), y1 = v_cvt_pk(agpr_read<A0 + 6>() * inv, agpr_read<A0 + 7>() * inv);
           asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x0), "+v"(y0));
           asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x1), "+v"(y1));
           const u32x4 w = {x0, x1, y0, y1};
@@ -1145,6 +1183,15 @@ __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
     }
   };
 
+  // ---- a.inmerge: a piece is PUBLISHED (flag = 1 for both query blocks) once its stores are complete in every wave: not by
+  // draining the LDS-DMA stream behind store_out, but one item later - every step in between ended with a counted vmcnt
+  // that covers the (older) stores and a barrier ----
+  auto publish = [&](int piece) {
+    if (tid == 0) {
+      __hip_atomic_store(a.flags + piece * 2 + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.flags + piece * 2 + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
   // =================================================== the item loop ===================================================
 #ifdef VC_ATTN_TIMESTAMPS
 #define TS_S(k) do { if (a.debug_ts && tid == 0 && ts_seg < 3) a.debug_ts[blockIdx.x * 32 + 8 + ts_seg * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -1212,6 +1259,7 @@ __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
       tile_s(I2{}, std::true_type{}, kt);
     }
     TS_S(3);
+    if (pub >= 0) { publish(pub); pub = -1; }
     store_out();
     TS_S(4);
 #ifdef VC_ATTN_TIMESTAMPS
@@ -1221,6 +1269,92 @@ __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
     VC_SEG_ADVANCE;
     hard = !soft;
     if (hard) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's look-ahead pieces land before the ring restarts
+  }
+  // =================================== a.inmerge: the tail items' pieces are combined here ===================================
+  // task (tail item `it` of this XCD, query block qb) -> workgroup slot (2 it + qb) % W: out = sum_p l_p O_p / sum_p l_p over the
+  // item's pieces in chunk order - the arithmetic and the order of attn64_merge_kernel (merge_fold64: bit-identical), the pieces
+  // written by workgroups of this launch many tiles ago.  Every polled word is zero before a launch and zero again after it: a
+  // flag is consumed by exactly one task, which clears it.  (Requesting the first task's pieces before the workgroup's last O
+  // goes out - to run their round trips under those stores - was built: 136 more live registers across store_out, 924
+  // compiler-generated accumulator moves; not kept.)
+  if (a.inmerge) {
+    if (pub >= 0) {                    // this workgroup's last work was a piece: drain its stores, then publish
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      publish(pub);
+    }
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const Sched64 sc = sched64(xcd, G, a.items, nkt_all);
+    for (int T = slot; T < 2 * sc.tail; T += sc.W) {
+      const int it = T >> 1, qb = T & 1;
+      const int u0 = it * nkt_all, u1 = u0 + nkt_all;
+      int c = (int)(((long)u0 * sc.W) / sc.units);
+      while (c > 0 && chunk_begin64(c, sc.units, sc.W) > u0) --c;
+      while (c + 1 < sc.W && chunk_begin64(c + 1, sc.units, sc.W) <= u0) ++c;
+      if (chunk_begin64(c + 1, sc.units, sc.W) >= u1) continue;      // the whole item ran inside one chunk: already written
+      auto next_chunk = [&](int cc) {
+        while (cc < sc.W && chunk_begin64(cc, sc.units, sc.W) < u1 && chunk_begin64(cc + 1, sc.units, sc.W) == chunk_begin64(cc, sc.units, sc.W)) ++cc;
+        return (cc < sc.W && chunk_begin64(cc, sc.units, sc.W) < u1) ? cc : -1;
+      };
+      const long ml_off = PART64_O_BYTES + ((wave * 2 + qb) * 64 + lane) * 8;
+      const long o_off = ((long)(wave * 2 + qb) * 16 * 64 + lane) * 8;
+      float acc[16][4];
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][e] = 0.f;
+      float wsum = 0.f, m = -INFINITY;
+      // the item's pieces in chunk order, FOUR at a time (two or three in all at the product's geometries; up to W when an
+      // XCD has a single tail item): all flags of a batch first, then ALL its loads in flight together (a chain of memory
+      // round trips otherwise), then the folds in order
+      constexpr int MAXP = 4;
+      for (int cc = next_chunk(c); cc >= 0;) {
+        int pcs[MAXP], np = 0;
+        for (; cc >= 0 && np < MAXP; cc = next_chunk(cc + 1))
+          pcs[np++] = (cc * 8 + xcd) * 2 + (it - chunk_begin64(cc, sc.units, sc.W) / nkt_all);
+        for (int j = 0; j < np; ++j) {
+          uint32_t* fp = a.flags + pcs[j] * 2 + qb;
+          // ONE relaxed agent-scope poll per wave (the pieces were published ~60 tiles ago: it does not spin in practice);
+          // bounded - a piece that never arrives costs wrong rows, not a hung GPU
+          for (unsigned spins = 0; __hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u; ++spins) {
+            __builtin_amdgcn_s_sleep(16);
+            if (spins > (1u << 20)) break;
+          }
+        }
+        f16x4 v[MAXP][16];
+        f32x2 ml[MAXP];
+#pragma unroll
+        for (int j = 0; j < MAXP; ++j)
+          if (j < np) {
+            const char* pp = (const char*)a.part + (long)pcs[j] * PART64_BYTES;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+              v[j][i] = __builtin_bit_cast(f16x4, __hip_atomic_load((const uint64_t*)(pp + o_off + i * 512), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            ml[j] = __builtin_bit_cast(f32x2, __hip_atomic_load((const uint64_t*)(pp + ml_off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          }
+#pragma unroll
+        for (int j = 0; j < MAXP; ++j)
+          if (j < np) merge_fold64(acc, wsum, m, v[j], ml[j]);
+        __syncthreads();               // every wave has seen the flags and holds its part of the pieces
+        if (tid == 0)
+          for (int j = 0; j < np; ++j) __hip_atomic_store(a.flags + pcs[j] * 2 + qb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      const int id = sc.start + sc.rounds * sc.W + it;
+      const int qb_i = id % a.qblocks, bh = id / a.qblocks;
+      const int h = bh % a.H, b = bh / a.H;
+      const int q = qb_i * QB + wave * QW + qb * 32 + lq;
+      const float inv = 1.0f / wsum;
+      bf16_t* orow = a.out + (long)b * a.out_bstride + (long)min(q, L - 1) * a.ldo + h * 128 + hh * 8;
+#pragma unroll
+      for (int mm = 0; mm < 8; ++mm) {
+        uint32_t x0 = v_cvt_pk(acc[2 * mm][0] * inv, acc[2 * mm][1] * inv), x1 = v_cvt_pk(acc[2 * mm][2] * inv, acc[2 * mm][3] * inv);
+        uint32_t y0 = v_cvt_pk(acc[2 * mm + 1][0] * inv, acc[2 * mm + 1][1] * inv), y1 = v_cvt_pk(acc[2 * mm + 1][2] * inv, acc[2 * mm + 1][3] * inv);
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x0), "+v"(y0));
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x1), "+v"(y1));
+        const u32x4 wv = {x0, x1, y0, y1};
+        if (q < L) *(u32x4*)(orow + mm * 16) = wv;
+      }
+    }
   }
 #ifdef VC_ATTN_TIMESTAMPS
   if (a.debug_ts && tid == 0) {
@@ -1284,15 +1418,7 @@ __global__ __launch_bounds__(256) void attn64_merge_kernel(const Attn64Args a, i
       for (int i = 0; i < 16; ++i) vn[i] = *(const f16x4*)(pp + o_off + i * 512);
       mln = *(const f32x2*)(pp + ml_off);
     }
-    const float m_new = fmaxf(m, ml[0]);
-    const float keep = __builtin_amdgcn_exp2f(m - m_new);          // 0 on the first piece (m = -inf), 1 while the maximum stands
-    const float w = ml[1] * __builtin_amdgcn_exp2f(ml[0] - m_new);
-    m = m_new;
-    wsum = wsum * keep + w;
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc[i][e] = acc[i][e] * keep + w * (float)v[i][e];
+    merge_fold64(acc, wsum, m, v, ml);
     if (nx < 0) break;
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = vn[i];
@@ -1303,22 +1429,31 @@ __global__ __launch_bounds__(256) void attn64_merge_kernel(const Attn64Args a, i
   const int qb_i = id % a.qblocks, bh = id / a.qblocks;
   const int h = bh % a.H, b = bh / a.H;
   const int q = qb_i * QB + wave * QW + qb * 32 + lq;
-  if (q < a.L) {
+  {
+    // the writer's fragment layout: a lane holds d = 8 i + 4 hh + (0..3) of its query per group i.  The half-waves exchange
+    // (v_permlane32_swap) so that the lower one owns d = 16 m .. 16 m + 7 and the upper one the next eight: 8 stores of
+    // 16 bytes per lane instead of 16 of 8 (the tail of this kernel is store-issue bound, as every row-per-lane epilogue)
     const float inv = 1.0f / wsum;
-    bf16_t* orow = a.out + (long)b * a.out_bstride + (long)q * a.ldo + h * 128;
+    bf16_t* orow = a.out + (long)b * a.out_bstride + (long)min(q, a.L - 1) * a.ldo + h * 128 + hh * 8;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      u32x2 w;
-      w[0] = pack2bf(acc[i][0] * inv, acc[i][1] * inv);
-      w[1] = pack2bf(acc[i][2] * inv, acc[i][3] * inv);
-      *(u32x2*)(orow + (i >> 2) * 32 + (i & 3) * 8 + hh * 4) = w;
+    for (int m = 0; m < 8; ++m) {
+      uint32_t x0 = v_cvt_pk(acc[2 * m][0] * inv, acc[2 * m][1] * inv), x1 = v_cvt_pk(acc[2 * m][2] * inv, acc[2 * m][3] * inv);
+      uint32_t y0 = v_cvt_pk(acc[2 * m + 1][0] * inv, acc[2 * m + 1][1] * inv), y1 = v_cvt_pk(acc[2 * m + 1][2] * inv, acc[2 * m + 1][3] * inv);
+      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x0), "+v"(y0));
+      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x1), "+v"(y1));
+      const u32x4 w = {x0, x1, y0, y1};
+      if (q < a.L) *(u32x4*)(orow + m * 16) = w;
     }
   }
 }
 
 }  // namespace
 
-int64_t vc_attention64_scratch_bytes_impl(int n_cu) { return (int64_t)n_cu * 2 * PART64_BYTES; }
+// the pieces (two per workgroup), then the flag words of the in-launch combine (VcAttention.variant bit 16)
+static int64_t parts64_bytes(int n_cu) { return (int64_t)n_cu * 2 * PART64_BYTES; }
+int64_t vc_attention64_flags_offset_impl(int n_cu) { return parts64_bytes(n_cu); }
+int64_t vc_attention64_flags_bytes_impl(int n_cu) { return (int64_t)n_cu * 2 * 2 * 4; }
+int64_t vc_attention64_scratch_bytes_impl(int n_cu) { return parts64_bytes(n_cu) + ((vc_attention64_flags_bytes_impl(n_cu) + 255) & ~(int64_t)255); }
 
 int vc_attention64_launch(const VcAttention& A, bool tail_split, int n_cu, uint64_t* debug_ts, hipStream_t s, char* err, int errlen) {
   Attn64Args a;
@@ -1333,6 +1468,7 @@ int vc_attention64_launch(const VcAttention& A, bool tail_split, int n_cu, uint6
   a.q_scale = (const bf16_t*)A.q_scale; a.q_scale2 = (const bf16_t*)(A.q_scale2 ? A.q_scale2 : A.q_scale);
   a.rope = A.rope; a.rope_bstride = A.rope_bstride; a.split = A.q_scale2 ? A.split : L;
   a.q_pre = A.q_prescaled != 0;
+  a.inmerge = 0; a.flags = nullptr;
   a.qblocks = (L + QB - 1) / QB;
   a.items = a.qblocks * H * B;
   a.full_rounds = -1; a.tail_items = 0; a.tail_units = 0; a.part = (float*)scratch;
@@ -1368,11 +1504,17 @@ int vc_attention64_launch(const VcAttention& A, bool tail_split, int n_cu, uint6
     }
   if (tail_split && !kv_len && any_tail && scratch && scratch_bytes >= vc_attention64_scratch_bytes_impl(n_cu) && worst_split + 4 < nkt) {
     a.full_rounds = a.items / G; a.tail_items = a.items - a.full_rounds * G; a.tail_units = a.tail_items * nkt;
+    // variant bit 16 (stream form only): the pieces are combined inside the launch - the caller vouches that the flag words at
+    // the end of the scratch were zero once and that nothing but these launches, one at a time, touches the scratch
+    a.inmerge = stream && (A.variant & 16) ? 1 : 0;
+    a.flags = (uint32_t*)((char*)scratch + vc_attention64_flags_offset_impl(n_cu));
     hipLaunchKernelGGL(kern, dim3(G), dim3(256), LDS64, s, a);
-    // XCD x has (items / 8 [+ 1]) % (G / 8) tail items: 16 blocks (8 XCDs x 2 query blocks) per tail slot that any XCD fills
-    const int W = G >> 3, qn = a.items >> 3, rn = a.items & 7;
-    const int tail_slots = std::max(rn ? (qn + 1) % W : 0, qn % W);
-    hipLaunchKernelGGL(attn64_merge_kernel, dim3(16 * tail_slots), dim3(256), 0, s, a, G);
+    if (!a.inmerge) {
+      // XCD x has (items / 8 [+ 1]) % (G / 8) tail items: 16 blocks (8 XCDs x 2 query blocks) per tail slot that any XCD fills
+      const int W = G >> 3, qn = a.items >> 3, rn = a.items & 7;
+      const int tail_slots = std::max(rn ? (qn + 1) % W : 0, qn % W);
+      hipLaunchKernelGGL(attn64_merge_kernel, dim3(16 * tail_slots), dim3(256), 0, s, a, G);
+    }
   } else {
     hipLaunchKernelGGL(kern, dim3(std::min(a.items, G)), dim3(256), LDS64, s, a);
   }

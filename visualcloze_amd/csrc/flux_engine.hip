@@ -284,7 +284,10 @@ int ln1(Flux& f, const Ctx& c, int64_t mod, Err e) {                  // the joi
 
 int attention_variant(const Flux& f) {
   if (f.attn_variant >= 0) return f.attn_variant;
-  return ((f.L + 255) / 256) * f.H * f.B >= f.n_cu ? 12 : 3;
+  // 28 = 12 + 16: one wave per SIMD, tail split, and - where the stream form of the kernel runs - the tail pieces combined
+  // inside the launch (the flag words of ATT_SCRATCH are zeroed by vc_flux_prepare, and only this handle's launches, ordered on
+  // one stream, touch it)
+  return ((f.L + 255) / 256) * f.H * f.B >= f.n_cu ? 28 : 3;
 }
 
 // QKNorm + RoPE (+ V^T) and the joint attention over QKV -> CAT[:, :D] (layers.py:165-185 / 236-241)
@@ -668,6 +671,8 @@ int vc_flux_prepare_impl(void* handle, const VcFluxInputs* in, void* workspace, 
   TRY(stage_send(f, f.G32, g32, B * sizeof(float), s, e));
   TRY(stage_end(f, s, e));
   HIP(hipMemsetAsync(f.VT, 0, (size_t)B * f.H * 128 * f.Lp * 2, s), "hipMemsetAsync");
+  // the flag words of the attention kernel's in-launch combine: zero before the first launch (every launch leaves them zero)
+  HIP(hipMemsetAsync((char*)f.ATT_SCRATCH + vc_attention64_flags_offset_impl(f.n_cu), 0, (size_t)vc_attention64_flags_bytes_impl(f.n_cu), s), "hipMemsetAsync");
   // step-invariant projections
   TRY(lin(f, f.txt_in, in->txt, f.cfg.context_in_dim, f.TXT0, D, B * T, VC_EPI_BIAS, s, e));
   if (f.cfg.guidance_embed) {

@@ -342,7 +342,8 @@ class FluxEngine:
     def attention_variant(self, ws: Workspace) -> int:
         if self.attn_variant is not None:
             return self.attn_variant
-        return 12 if ((ws.L + 255) // 256) * self.H * ws.B >= self.n_cu else 3
+        # 28 = 12 + 16: tail pieces combined inside the launch where the stream form runs (hip.attention_scratch is zero-initialised)
+        return 28 if ((ws.L + 255) // 256) * self.H * ws.B >= self.n_cu else 3
 
     def _attention(self, c, scales, split):
         """QKNorm + RoPE (+ V^T) and the joint attention over ws.QKV -> CAT[:, :D] (layers.py:165-185 / 236-241).  With the

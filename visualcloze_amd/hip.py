@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VC_HIP_LIB") or os.path.join(_HERE, "lib", "libvcloze_hip.so")   # VC_HIP_LIB: profiling build
 CSRC = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 8                # VC_ABI_VERSION of include/vcloze_hip.h
+ABI_VERSION = 9                # VC_ABI_VERSION of include/vcloze_hip.h
 GEMM_MAX_PROBLEMS = 4          # VC_GEMM_MAX_PROBLEMS: grouped problems per vc_gemm launch
 EPI_BIAS, EPI_GELU, EPI_GATE_RES, EPI_SILU, EPI_QKV = 0, 1, 2, 3, 4
 GEMM_NO_SPLIT = 64             # VC_GEMM_NO_SPLIT: tile_cfg value that keeps an auto-tiled vc_gemm one launch
@@ -382,11 +382,12 @@ _attn_scratch = {}
 
 
 def attention_scratch(device) -> torch.Tensor:
-    """The partial-result buffer of the tail-split attention (variant 7), one per device; launches on one stream
-    serialise their use of it."""
+    """The partial-result buffer of the tail-split attention (variants 7 / 12 / 28), one per device; launches on one stream
+    serialise their use of it.  ZERO-initialised: variant 28 combines the pieces inside the launch through flag words at the
+    end of the buffer that are zero before and after every launch (VcAttention.variant bit 16)."""
     key = str(device)
     if key not in _attn_scratch:
-        _attn_scratch[key] = torch.empty(lib().vc_attention_scratch_bytes(), dtype=torch.uint8, device=device)
+        _attn_scratch[key] = torch.zeros(lib().vc_attention_scratch_bytes(), dtype=torch.uint8, device=device)
     return _attn_scratch[key]
 
 

@@ -1048,7 +1048,8 @@ __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
     // the VALU has just written without the wait states hipcc inserts for its own instructions (masked_step pads them).
     const bool msk = !LAST && tile_masked(kt + 1);
     uint32_t k_bd;
-    const uint32_t k_sc = k_src(kt + 4, k_bd), v_sc = v_src(kt + 2);     // the stream's look-ahead: V^T(kt+2), K(kt+4)
+    uint32_t k_sc = k_src(kt + 4, k_bd), v_sc = v_src(kt + 2);           // the stream's look-ahead: V^T(kt+2), K(kt+4)
+    asm volatile("" : "+s"(k_sc), "+s"(v_sc), "+s"(k_bd));                // (materialised HERE, not sunk into the gap of their first use)
     SB();
     sfor<0, 32>([&](auto Gp) {
       constexpr int g = decltype(Gp)::value, c = g >> 3, t = g & 7;

@@ -403,7 +403,8 @@ def roofline_attention(job, iters=3):
         e1.record(s)
         ms_iso = e0.elapsed_ms(e1) / (iters * 10)
     fl = 4.0 * ws.L * ws.L * eng.D * ws.B
-    return dict(kernel=(template + " + attn64_merge_kernel") if v & 8 else template, variant=v, logit_bound=round(bound, 3),
+    in_launch = bool(v & 16) and is_bounded and q_done          # VcAttention.variant bit 16: the tail pieces are combined inside the launch
+    return dict(kernel=(template + (" (tail pieces combined in the launch)" if in_launch else " + attn64_merge_kernel")) if v & 8 else template, variant=v, logit_bound=round(bound, 3),
                 query_norm="qkv GEMM epilogue (prescaled)" if q_done else ("attention prologue" if fused_q else "pre-pass"), timed="in situ: HIP events around each attention launch inside product-plan "
                 "evaluations", launches_timed=len(situ), avg_launch_us=round(ms * 1e3, 2),
                 median_launch_us=round(situ[len(situ) // 2] * 1e3, 2), isolated_us=round(ms_iso * 1e3, 2),

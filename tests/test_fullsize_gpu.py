@@ -151,7 +151,8 @@ def test_full_width_one_plus_one_blocks_vs_oracle(small_model, geom):
 
 @pytest.mark.parametrize("qmax,kmax,bounded", [(1.5, 1.5, True), (3.0, 3.0, False)])
 def test_full_width_non_unit_norm_scales_both_sides_of_the_logit_bound(qmax, kmax, bounded):
-    """Which attention instantiation runs is a property of the WEIGHTS: attn64_kernel<true> (no running max) while
+    """Which attention instantiation runs is a property of the WEIGHTS: the bounded-logit kernels (no running max; attn64s_kernel, the
+    stream form, with the queries finished by the qkv GEMM's epilogue) while
     16.65 * max|query_norm.scale| * max|key_norm.scale| <= 100 (model.prepare; every other full-size test and the bench use unit
     scales and therefore always take it), attn64_kernel<false> (running max) beyond - a real checkpoint may sit on either side.
     One full-width evaluation (cfg 2 geometry, 1 + 1 blocks) with NON-UNIT scales on each side of the switch against the oracle
@@ -172,7 +173,7 @@ def test_full_width_non_unit_norm_scales_both_sides_of_the_logit_bound(qmax, kma
     got = _call(m, inp, t)
     eng = m.engine()
     assert (0.0 < eng.W.logit_bound <= 100.0) == bounded, eng.W.logit_bound
-    assert eng.attention_variant(eng.workspace(T, inp["x"].shape[1], 1, 1)) == 12
+    assert eng.attention_variant(eng.workspace(T, inp["x"].shape[1], 1, 1)) == 28      # 12 + 16: tail pieces combined in the launch where the stream form runs
     want_bf16, want_fp32 = _oracle_pair(sd, O.FluxGeometry(depth=1, depth_single_blocks=1), inp, t)
     floor, e16, e32 = rel_l2(want_bf16, want_fp32), rel_l2(got, want_bf16), rel_l2(got, want_fp32)
     parity_log(f"[1+1 blocks, cfg2, norm scales up to {qmax} / {kmax}: logit bound {eng.W.logit_bound:.1f} -> attn64_kernel<{str(bounded).lower()}>] "
@@ -719,3 +720,16 @@ def test_race_screen_repeated_launches_are_bit_identical():
             hip.attention(qkv, vt, o8, L2, H, variant=8)                # the same kernel, no item cut: f32 summation order only
             torch.cuda.synchronize()
             assert rel_l2(o0, o8) < 4e-3 and not torch.equal(o0, o8)
+    # the stream form (bounded logits, prescaled queries: the product's launches), pieces combined by the merge kernel (12) and
+    # inside the launch (28): 40 launches each, bit-reproducible and equal to each other
+    outs = {}
+    for variant in (12, 28):
+        o0 = torch.empty(L2, D, dtype=torch.bfloat16, device=DEV)
+        o1 = torch.empty(L2, D, dtype=torch.bfloat16, device=DEV)
+        hip.attention(qkv, vt, o0, L2, H, variant=variant, q_prescaled=True, logit_bound=16.65)
+        for it in range(40):
+            hip.attention(qkv, vt, o1, L2, H, variant=variant, q_prescaled=True, logit_bound=16.65)
+        torch.cuda.synchronize()
+        assert torch.equal(o0, o1), f"stream-form attention, variant {variant}: not deterministic"
+        outs[variant] = o0
+    assert torch.equal(outs[12], outs[28])

@@ -200,10 +200,11 @@ int vc_qknorm_rope_vt(void* qkv, int64_t ld, int64_t bstride, const void* q_scal
  * +16 (28; ABI 9): NO second kernel - where the kernel's stream form runs (q_prescaled and logit_bound <= 100: the product's
  * launches) each workgroup does its share of the tail FIRST, publishes its pieces (agent-scope stores + one flag word per
  * piece and query block, at the end of `scratch`) and combines the pieces assigned to it at the very end of its own work -
- * same arithmetic and order as the merge kernel (bit-identical).  CONTRACT of bit 16: the last
- * vc_attention_scratch_bytes() - 2 * 66 KB * CUs bytes of `scratch` (the flag words) were ZERO before the first launch, and
- * nothing but these launches, one at a time, touches the scratch (every launch leaves the flag words zero); all workgroups of
- * the grid (one per CU) must be able to run concurrently.  Elsewhere the bit is ignored.  28 is the default of the host engines.
+ * same arithmetic and order as the merge kernel (bit-identical).  CONTRACT of bit 16: `scratch` is a whole
+ * vc_attention_scratch_bytes() buffer whose LAST 16 * CUs bytes (rounded up to 256: the flag words, behind the partials of
+ * every variant) were ZERO before the first launch; launches that use a scratch are ordered on one stream (every launch leaves
+ * the flag words zero); all workgroups of the grid (one per CU) must be able to run concurrently.  A smaller scratch, or any
+ * other kernel form, ignores the bit.  28 is the default of the host engines.
  * q_scale != NULL (variants 8, 12 only): the q columns of qkv hold the RAW projection output and QKNorm + RoPE
  * (layers.py:75-84, math.py:112-117) are applied to the 64 query rows a wave loads, with q_scale / q_scale2 / split /
  * rope / rope_bstride as in vc_qknorm_rope_vt (which is then called with parts = VC_QKN_K | VC_QKN_VT).

@@ -41,15 +41,22 @@ def gap_cycles(price):
     return max(32.0, 4.6 * (1.0 + price))
 
 
+# instructions a token turns into (what `make audit64` counts between two MFMAs): a DMA piece is offset add (+ clamp for K),
+# M0 add, wait state, load
+NINSN = {E0: 1, E1: 1, A0: 1, A1: 1, CV: 1, RV: 1, RV2: 1, RK: 1, DMA: 5, WAIT: 1}
+MAX_INSN = 6            # per gap, hard (MI355X_MICROARCH.md: <= 5 single-issue fillers hidden per 32x32x16 MFMA, placed)
+
+
 def deal(tokens, n_gaps=32):
     """tokens: dicts(kind, a, b, earliest, order).  The tokens keep their `order`; the sequence is cut into n_gaps contiguous
     groups (dynamic programme) so that the estimated cycles - sum over gaps of max(32, 4.6 (1 + price)) - are minimal, no
     token lands before its `earliest` gap, and among equal-cost cuts the prices are as even as possible."""
     toks = sorted(tokens, key=lambda t: t["order"])
     n = len(toks)
-    pre = [0.0]
+    pre, cnt = [0.0], [0]
     for t in toks:
         pre.append(pre[-1] + COST[t["kind"]])
+        cnt.append(cnt[-1] + NINSN[t["kind"]])
     INF = 1e18
     dp = [[INF] * (n + 1) for _ in range(n_gaps + 1)]
     arg = [[-1] * (n + 1) for _ in range(n_gaps + 1)]
@@ -62,6 +69,8 @@ def deal(tokens, n_gaps=32):
             while True:
                 price = pre[j] - pre[i]
                 c = dp[g][i] + gap_cycles(price) + 0.02 * price * price
+                if cnt[j] - cnt[i] > MAX_INSN and j > i + 1:       # (a single token may exceed the cap by itself)
+                    break
                 if c < dp[g + 1][j]:
                     dp[g + 1][j], arg[g + 1][j] = c, i
                 if j == n or toks[j]["earliest"] > g:
@@ -172,6 +181,14 @@ def add_waits(ga, gb):
         tok = next(t for g in ga + gb for t in g if t["kind"] in (RV, RV2) and t["a"] == code)
         where = (0, 31) if j == 0 else (1, j - 1)
         idx = next(i for i, r in enumerate(reads) if r[2] is tok)
+        if RING == 8 and p["dt"] == 0:
+            # ring of eight: all four fragments of a 16-key step are issued a whole step before its first MFMA - ONE wait per
+            # step, for the last of them (free by then), instead of one per fragment
+            grp = [next(i for i, r in enumerate(reads) if r[2] is t) for g in ga + gb for t in g
+                   if t["kind"] in (RV, RV2) and t["a"] // 4 == p["s"]]
+            issued_now = sum(1 for (ph, g, t) in reads if (ph, g) <= where)
+            if all(i < issued_now for i in grp):
+                idx = max(grp)
         issued = sum(1 for (ph, g, t) in reads if (ph, g) <= where)
         assert idx < issued, (j, idx, issued)
         if idx <= done:

@@ -386,8 +386,14 @@ extern "C" void vc_debug_set_attn_ts(void* p) { g_attn_debug_ts = (uint64_t*)p; 
 
 static int attn_cu_count() { return vc_cu_count(); }
 
+// [partials of whichever variant runs: the larger of the two layouts][flag words of attention64's in-launch combine, zero between
+// launches (VcAttention.variant bit 16): behind everything any other variant writes]
+int64_t vc_attention_flags_offset_impl() {
+  const int64_t parts = std::max((int64_t)2 * attn_cu_count() * 2 * PART_FLOATS * (int64_t)sizeof(float), vc_attention64_scratch_bytes_impl(attn_cu_count()));
+  return (parts + 255) & ~(int64_t)255;
+}
 int64_t vc_attention_scratch_bytes_impl() {
-  return std::max((int64_t)2 * attn_cu_count() * 2 * PART_FLOATS * (int64_t)sizeof(float), vc_attention64_scratch_bytes_impl(attn_cu_count()));
+  return vc_attention_flags_offset_impl() + ((vc_attention64_flags_bytes_impl(attn_cu_count()) + 255) & ~(int64_t)255);
 }
 
 int vc_attention_launch(const VcAttention& A, hipStream_t s, char* err, int errlen) {

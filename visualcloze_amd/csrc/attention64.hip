@@ -1313,15 +1313,19 @@ __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
         int pcs[MAXP], np = 0;
         for (; cc >= 0 && np < MAXP; cc = next_chunk(cc + 1))
           pcs[np++] = (cc * 8 + xcd) * 2 + (it - chunk_begin64(cc, sc.units, sc.W) / nkt_all);
-        for (int j = 0; j < np; ++j) {
-          uint32_t* fp = a.flags + pcs[j] * 2 + qb;
-          // ONE relaxed agent-scope poll per wave (the pieces were published ~60 tiles ago: it does not spin in practice);
-          // bounded - a piece that never arrives costs wrong rows, not a hung GPU
-          for (unsigned spins = 0; __hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u; ++spins) {
-            __builtin_amdgcn_s_sleep(16);
-            if (spins > (1u << 20)) break;
-          }
-        }
+        // ONE relaxed agent-scope read of every flag of the batch, all in flight together (the pieces were published ~60 tiles
+        // ago: nothing spins in practice); what is not there yet is polled, bounded - a piece that never arrives costs wrong
+        // rows, not a hung GPU
+        uint32_t fl[MAXP];
+#pragma unroll
+        for (int j = 0; j < MAXP; ++j) fl[j] = j < np ? __hip_atomic_load(a.flags + pcs[j] * 2 + qb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
+#pragma unroll
+        for (int j = 0; j < MAXP; ++j)
+          if (j < np && fl[j] != 1u)
+            for (unsigned spins = 0; __hip_atomic_load(a.flags + pcs[j] * 2 + qb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u; ++spins) {
+              __builtin_amdgcn_s_sleep(16);
+              if (spins > (1u << 20)) break;
+            }
         f16x4 v[MAXP][16];
         f32x2 ml[MAXP];
 #pragma unroll
@@ -1450,11 +1454,10 @@ __global__ __launch_bounds__(256) void attn64_merge_kernel(const Attn64Args a, i
 
 }  // namespace
 
-// the pieces (two per workgroup), then the flag words of the in-launch combine (VcAttention.variant bit 16)
-static int64_t parts64_bytes(int n_cu) { return (int64_t)n_cu * 2 * PART64_BYTES; }
-int64_t vc_attention64_flags_offset_impl(int n_cu) { return parts64_bytes(n_cu); }
+// the pieces (two per workgroup); the flag words of the in-launch combine (VcAttention.variant bit 16) sit at the END of the
+// whole attention scratch (vc_attention_flags_offset_impl, attention.hip), behind the partials of every other variant
+int64_t vc_attention64_scratch_bytes_impl(int n_cu) { return (int64_t)n_cu * 2 * PART64_BYTES; }
 int64_t vc_attention64_flags_bytes_impl(int n_cu) { return (int64_t)n_cu * 2 * 2 * 4; }
-int64_t vc_attention64_scratch_bytes_impl(int n_cu) { return parts64_bytes(n_cu) + ((vc_attention64_flags_bytes_impl(n_cu) + 255) & ~(int64_t)255); }
 
 int vc_attention64_launch(const VcAttention& A, bool tail_split, int n_cu, uint64_t* debug_ts, hipStream_t s, char* err, int errlen) {
   Attn64Args a;
@@ -1504,11 +1507,12 @@ int vc_attention64_launch(const VcAttention& A, bool tail_split, int n_cu, uint6
       worst_split = std::max(worst_split, (int)(((long)tail * nkt + W - 1) / W));
     }
   if (tail_split && !kv_len && any_tail && scratch && scratch_bytes >= vc_attention64_scratch_bytes_impl(n_cu) && worst_split + 4 < nkt) {
+    const bool has_flags = scratch_bytes >= vc_attention_scratch_bytes_impl();       // the whole buffer, flag words at its end
     a.full_rounds = a.items / G; a.tail_items = a.items - a.full_rounds * G; a.tail_units = a.tail_items * nkt;
     // variant bit 16 (stream form only): the pieces are combined inside the launch - the caller vouches that the flag words at
     // the end of the scratch were zero once and that nothing but these launches, one at a time, touches the scratch
-    a.inmerge = stream && (A.variant & 16) ? 1 : 0;
-    a.flags = (uint32_t*)((char*)scratch + vc_attention64_flags_offset_impl(n_cu));
+    a.inmerge = stream && (A.variant & 16) && has_flags ? 1 : 0;
+    a.flags = (uint32_t*)((char*)scratch + vc_attention_flags_offset_impl());
     hipLaunchKernelGGL(kern, dim3(G), dim3(256), LDS64, s, a);
     if (!a.inmerge) {
       // XCD x has (items / 8 [+ 1]) % (G / 8) tail items: 16 blocks (8 XCDs x 2 query blocks) per tail slot that any XCD fills

@@ -672,7 +672,7 @@ int vc_flux_prepare_impl(void* handle, const VcFluxInputs* in, void* workspace, 
   TRY(stage_end(f, s, e));
   HIP(hipMemsetAsync(f.VT, 0, (size_t)B * f.H * 128 * f.Lp * 2, s), "hipMemsetAsync");
   // the flag words of the attention kernel's in-launch combine: zero before the first launch (every launch leaves them zero)
-  HIP(hipMemsetAsync((char*)f.ATT_SCRATCH + vc_attention64_flags_offset_impl(f.n_cu), 0, (size_t)vc_attention64_flags_bytes_impl(f.n_cu), s), "hipMemsetAsync");
+  HIP(hipMemsetAsync((char*)f.ATT_SCRATCH + vc_attention_flags_offset_impl(), 0, (size_t)vc_attention64_flags_bytes_impl(f.n_cu), s), "hipMemsetAsync");
   // step-invariant projections
   TRY(lin(f, f.txt_in, in->txt, f.cfg.context_in_dim, f.TXT0, D, B * T, VC_EPI_BIAS, s, e));
   if (f.cfg.guidance_embed) {

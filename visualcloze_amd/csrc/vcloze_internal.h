@@ -30,7 +30,7 @@ int vc_gemm_launch(VcGemmArgs a, int tile_cfg, hipStream_t s, char* err, int err
 int vc_gemm_plan_impl(VcGemmArgs a, int tile_cfg, int32_t out[8], char* err, int errlen);
 int vc_attention_launch(const VcAttention& a, hipStream_t s, char* err, int errlen);
 int64_t vc_attention_scratch_bytes_impl();
-int64_t vc_attention64_flags_offset_impl(int n_cu);
+int64_t vc_attention_flags_offset_impl();
 int64_t vc_attention64_flags_bytes_impl(int n_cu);
 int vc_attention64_launch(const VcAttention& a, bool tail_split, int n_cu, uint64_t* debug_ts, hipStream_t s, char* err, int errlen);
 int64_t vc_attention64_scratch_bytes_impl(int n_cu);

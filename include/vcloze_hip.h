@@ -347,7 +347,9 @@ int vc_flux_destroy(void* handle);
  * which is within 1 ulp of torch's f32 exp);
  * or, optionally, "splitk_ws": ONE device scratch of rows * cols F32 values >= VC_GEMM_SPLITK_WS_BYTES for the split-K / stream
  * remainders of every geometry this handle runs (rows = 1, cols = the float count) - bound BEFORE vc_flux_workspace_bytes is
- * asked, it keeps those 100 MB out of each workspace (default: carved into every workspace).  Pointers must stay valid while bound. */
+ * asked, it keeps those 100 MB out of each workspace (default: carved into every workspace); a FIRST bind after
+ * vc_flux_workspace_bytes or vc_flux_prepare has answered is refused (VC_ERR_STATE: it would change the layout of workspaces the
+ * caller already holds); re-binding another buffer is allowed at any time.  Pointers must stay valid while bound. */
 int vc_flux_bind_weight(void* handle, const char* name, const void* w, const void* bias, int32_t rows, int32_t cols, int64_t ldw);
 int64_t vc_flux_mod_offset(void* handle, const char* module_name);
 /* knobs for tests and A/B runs: "attn_variant" (-1 = by size, the default), "tile_cfg" (0; flag bits such as

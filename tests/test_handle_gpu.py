@@ -160,6 +160,10 @@ def test_handle_error_behaviour(model):
         t = np.asarray([0.5], np.float32)
         assert L.vc_flux_forward(h, out.data_ptr(), fp(t), 0, out.data_ptr(), None) == -3        # not prepared
         assert L.vc_flux_set_option(h, b"no_such_knob", 1) == -1
+        # the optional split-K scratch changes the carve-up of every workspace: a first bind AFTER a workspace has been sized
+        # (vc_flux_workspace_bytes above) is refused, not silently applied (advisor r05)
+        skw = torch.empty(64, dtype=torch.float32, device=DEV)
+        assert L.vc_flux_bind_weight(h, b"splitk_ws", skw.data_ptr(), None, 1, 64, 64) == -3 and b"BEFORE" in L.vc_last_error()
         assert L.vc_flux_mod_offset(h, b"double_blocks.0.txt_mod.lin") == 6 * D
         assert L.vc_flux_mod_offset(h, b"nope") == -1
         bad = hip.FluxConfig(p.in_channels, p.out_channels, p.vec_in_dim, p.context_in_dim, D + 8, p.num_heads, p.depth,

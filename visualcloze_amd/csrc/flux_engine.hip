@@ -61,6 +61,7 @@ struct Flux : Buffers {
   int attn_variant = -1, tile_cfg = 0, fuse_qnorm = 2, fuse_vt = 1, qkv_heads = 0, fuse_knorm = 0, logit_bound_milli = 0, mlp_first = 0, splitk = 1, n_cu = 256;
   // prepared geometry + workspace carve-up
   bool prepared = false;
+  bool ws_sized = false;     // vc_flux_workspace_bytes / vc_flux_prepare have answered with the current carve-up
   int B = 0, T = 0, N = 0, L = 0, Lp = 0, S = 0;
   bool ragged = false, gapped = false;
   char* base = nullptr;
@@ -286,8 +287,12 @@ int attention_variant(const Flux& f) {
   if (f.attn_variant >= 0) return f.attn_variant;
   // 28 = 12 + 16: one wave per SIMD, tail split, and - where the stream form of the kernel runs - the tail pieces combined
   // inside the launch (the flag words of ATT_SCRATCH are zeroed by vc_flux_prepare, and only this handle's launches, ordered on
-  // one stream, touch it)
-  return ((f.L + 255) / 256) * f.H * f.B >= f.n_cu ? 28 : 3;
+  // one stream, touch it).  Fewer 256-query items than CUs (cfg 1: 168): the same kernel WITHOUT a split (8) - one item per
+  // workgroup beats the 32-queries-per-wave kernel down to half the CUs (round 6, cfg 1: 44.6-49.7 vs 56.3-59.4 us per launch
+  // in situ; per step +1.7 % on one box, +-0.1 % on another - the q / k norm moves from the pre-pass into the qkv GEMM's
+  // epilogue with it; cutting 168 items into 256 short pieces loses 1 %: profiles/r06o_ab_cfg1.log, r06q_ab_cfg1.log)
+  const int items = ((f.L + 255) / 256) * f.H * f.B;
+  return items >= f.n_cu ? 28 : 2 * items >= f.n_cu ? 8 : 3;
 }
 
 // QKNorm + RoPE (+ V^T) and the joint attention over QKV -> CAT[:, :D] (layers.py:165-185 / 236-241)
@@ -540,6 +545,11 @@ int vc_flux_bind_weight_impl(void* handle, const char* name, const void* w, cons
                              char* err, int errlen) {
   H(handle);
   if (!name || !w || rows <= 0 || cols <= 0 || ldw < cols) FAIL(VC_ERR_ARG, "flux_bind_weight: bad arguments for '%s'", name ? name : "?");
+  // the optional split-K scratch decides whether 100 MB are carved into EVERY workspace: binding it for the first time after a
+  // workspace has been sized would silently change the carve-up of buffers the caller already holds (advisor r05)
+  if (!strcmp(name, "splitk_ws") && f.ws_sized && f.bound.find("splitk_ws") == f.bound.end())
+    FAIL(VC_ERR_STATE, "flux_bind_weight: bind 'splitk_ws' BEFORE the first vc_flux_workspace_bytes / vc_flux_prepare (it changes the size and "
+                       "layout of every workspace)");
   Lin l;
   l.w = w; l.b = bias; l.N = rows; l.K = cols; l.ldw = ldw;
   f.bound[name] = l;
@@ -578,12 +588,14 @@ int vc_flux_set_option_impl(void* handle, const char* name, int32_t value, char*
 int64_t vc_flux_workspace_bytes_impl(void* handle, int32_t B, int32_t T, int32_t N, int32_t max_steps) {
   if (!handle || B <= 0 || T <= 0 || N <= 0 || max_steps <= 0) return -1;
   Buffers tmp;                    // carve into a scratch copy: the pointers of the live handle stay as they are
+  ((Flux*)handle)->ws_sized = true;
   return carve(tmp, *(Flux*)handle, nullptr, B, T, N, max_steps);
 }
 
 int vc_flux_prepare_impl(void* handle, const VcFluxInputs* in, void* workspace, int64_t workspace_bytes, hipStream_t s, char* err, int errlen) {
   H(handle);
   if (!in || !workspace) FAIL(VC_ERR_ARG, "flux_prepare: null argument");
+  f.ws_sized = true;
   const int B = in->B, T = in->T, N = in->N, S = in->max_steps;
   if (B <= 0 || T <= 0 || N <= 0 || S <= 0) FAIL(VC_ERR_ARG, "flux_prepare: B, T, N, max_steps must be positive");
   if (!in->txt || !in->y || !in->img_ids || !in->txt_ids) FAIL(VC_ERR_ARG, "flux_prepare: txt, y, img_ids, txt_ids are required");

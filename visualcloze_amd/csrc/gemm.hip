@@ -1462,7 +1462,9 @@ static GemmPlan plan_gemm(const VcGemmArgs& a, int tile_cfg) {
     for (int i = 1; i < a.nprob; ++i) same_k = same_k && a.p[i].K == a.p[0].K;
     const bool prefer = (tile_cfg_flags & VC_GEMM_PREFER_STREAMK) != 0, any_k = (tile_cfg_flags & VC_GEMM_STREAMK_ANY_K) != 0;
     if (R >= 1 && 2 * rem > n_cus && same_k && (a.p[0].K >= VC_GEMM_STREAMK_MIN_K || any_k) && (double)n_cus * 2 * cfg_bm[4] * cfg_bn[4] * 4 <= (double)a.splitk_ws_bytes) {
-      if (prefer || any_k || 10 * rem <= 7 * n_cus) return stream_plan();
+      // (advisor r05: only where the one-launch plan would have chosen the 256x192 tile itself - at N = 256 or 4096 a 192-wide
+      // tile wastes columns and another tile may cost far less than any remainder scheme on this one)
+      if (prefer || any_k || (10 * rem <= 7 * n_cus && whole.tile_cfg == 4)) return stream_plan();
     }
   }
   // Block-round quantisation: cut problem 0's rows where the 256x192 tiles above the cut are (nearly) whole rounds of the 256
@@ -1498,7 +1500,7 @@ static GemmPlan plan_gemm(const VcGemmArgs& a, int tile_cfg) {
       if (t1 + rp.cost < best) { best = t1 + rp.cost; cut = rows; rest_plan = rp; best_cut = best; }
     }
   }
-  if ((sk.sk_S > 1 || sk.sk_stream > 0) && (cut == 0 || sk_cost <= best_cut)) return sk;
+  if (sk.sk_S > 1 && (cut == 0 || sk_cost <= best_cut)) return sk;
   if (cut == 0) return GemmPlan{0, whole.tile_cfg, whole.pp, 0, 0};
   return GemmPlan{cut, 4, 2, rest_plan.tile_cfg, rest_plan.pp};
 }

@@ -342,8 +342,11 @@ class FluxEngine:
     def attention_variant(self, ws: Workspace) -> int:
         if self.attn_variant is not None:
             return self.attn_variant
-        # 28 = 12 + 16: tail pieces combined inside the launch where the stream form runs (hip.attention_scratch is zero-initialised)
-        return 28 if ((ws.L + 255) // 256) * self.H * ws.B >= self.n_cu else 3
+        # 28 = 12 + 16: tail pieces combined inside the launch where the stream form runs (hip.attention_scratch is zero-initialised);
+        # fewer 256-query items than CUs: the same kernel without a split (8) down to half the CUs (cfg 1), the
+        # 32-queries-per-wave kernel (3) below (csrc/flux_engine.hip attention_variant)
+        items = ((ws.L + 255) // 256) * self.H * ws.B
+        return 28 if items >= self.n_cu else 8 if 2 * items >= self.n_cu else 3
 
     def _attention(self, c, scales, split):
         """QKNorm + RoPE (+ V^T) and the joint attention over ws.QKV -> CAT[:, :D] (layers.py:165-185 / 236-241).  With the

@@ -363,8 +363,9 @@ def roofline_attention(job, iters=3):
     # attention64.hip runs attn64_kernel<true> (no running max) when the weights' norm scales bound the logits by <= 100
     # and, when the queries arrive finished from the qkv GEMM's epilogue as well, its stream form attn64s_kernel (round 6)
     is_bounded = 0.0 < bound <= 100.0
-    template = (("attn64s_kernel (bounded logits, prescaled queries: K / V^T stream across work items)" if q_done else
-                 "attn64_kernel<true> (bounded logits: no running max)") if is_bounded else "attn64_kernel<false> (running max)") if v & 8 else "attn_fwd_kernel"
+    template = (("attn64s_kernel<true> (bounded logits, prescaled queries: K / V^T stream across work items)" if q_done else
+                 "attn64_kernel<true> (bounded logits: no running max)") if is_bounded else
+                ("attn64s_kernel<false> (running max, stream form)" if q_done else "attn64_kernel<false> (running max)")) if v & 8 else "attn_fwd_kernel"
 
     def in_situ():
         eng.eval_once(ws, ws.STEP, euler=False, s=s)              # warm
@@ -411,8 +412,8 @@ def roofline_attention(job, iters=3):
                 achieved=round(fl / ms / 1e9, 1), unit="TFLOP/s", frac=round(fl / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4),
                 runmax_us=round(runmax_ms * 1e3, 2) if runmax_ms else None,
                 runmax_frac=round(fl / runmax_ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4) if runmax_ms else None,
-                runmax_note="attn64_kernel<false> (running max) in situ on the same operands: the template a checkpoint with "
-                            "large QK-norm scales would run")
+                runmax_note="the running-max template (attn64s_kernel<false> with prescaled queries) in situ on the same operands: what a "
+                            "checkpoint whose QK-norm scales break the logit bound would run")
 
 
 def cpu_baseline(T, N, wl):

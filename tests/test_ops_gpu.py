@@ -741,17 +741,22 @@ def test_attention_stream_form_tail_combined_in_launch(hip, L, H, B):
     vt = torch.zeros((B, H, 128, Lpad), dtype=torch.bfloat16, device=DEV)
     w = qkv.clone()
     hip.qknorm_rope_vt(w, qs, ks, rope, vt, L, H, B=B, parts=hip.QKN_Q | hip.QKN_K | hip.QKN_VT | hip.QKN_QPRE)
-    outs = {}
-    for variant in (8, 12, 28, 28, 12, 28):
-        o = torch.full((B * L, H * 128), float("nan"), dtype=torch.bfloat16, device=DEV)
-        hip.attention(w, vt, o, L, H, variant=variant, B=B, q_prescaled=True, logit_bound=16.65)
-        torch.cuda.synchronize()
-        assert torch.isfinite(o.float()).all(), variant
-        if variant in outs and variant != 8:
-            assert torch.equal(o, outs[variant]), f"variant {variant} is not reproducible from launch to launch"
-        outs[variant] = o
-    assert torch.equal(outs[28], outs[12])                                  # same pieces, same order of combination
-    check(outs[12], outs[8].float(), tol=1e-2)
+    both = {}
+    for lb in (16.65, 0.0):            # bounded logits (no running max) and the running-max form of the same stream skeleton
+        outs = {}
+        for variant in (8, 12, 28, 28, 12, 28):
+            o = torch.full((B * L, H * 128), float("nan"), dtype=torch.bfloat16, device=DEV)
+            hip.attention(w, vt, o, L, H, variant=variant, B=B, q_prescaled=True, logit_bound=lb)
+            torch.cuda.synchronize()
+            assert torch.isfinite(o.float()).all(), (variant, lb)
+            if variant in outs and variant != 8:
+                assert torch.equal(o, outs[variant]), f"variant {variant} (logit_bound {lb}) is not reproducible from launch to launch"
+            outs[variant] = o
+        assert torch.equal(outs[28], outs[12]), lb                              # same pieces, same order of combination
+        check(outs[12], outs[8].float(), tol=1e-2)
+        both[lb] = outs
+    outs = both[16.65]
+    check(both[0.0][28], outs[28].float(), tol=1e-2)                            # the same function with and without a running max
     scr = hip.attention_scratch(torch.device(DEV))
     n_cu = torch.cuda.get_device_properties(0).multi_processor_count
     nflag = (n_cu * 16 + 255) // 256 * 256                                    # the flag words: the END of the scratch, behind every variant's partials
@@ -763,6 +768,7 @@ def test_attention_stream_form_tail_combined_in_launch(hip, L, H, B):
     for h in (0, H - 1):
         ref = R.attention_ref(qn[:, h:h + 1], kn[:, h:h + 1], v[:, h:h + 1], None)
         check(outs[28][:L, h * 128:(h + 1) * 128], ref)
+        check(both[0.0][28][:L, h * 128:(h + 1) * 128], ref)
 
 
 @pytest.mark.parametrize("variant", [0, 3, 8, 12])

@@ -4,10 +4,14 @@ instruction mix of the kernel's largest loop.     python tools/audit_asm.py file
 import re, sys
 path, name = sys.argv[1], sys.argv[2]
 txt = open(path).read()
-m = re.search(r"^(_Z\w*%s\w*):[^\n]*\n(.*?)\n\s*s_endpgm" % name, txt, re.S | re.M)
-if not m:
+ms = re.search(r"\.amdhsa_kernel\s+(_Z\w*%s\w*)" % name, txt)
+if not ms:
     sys.exit(f"kernel *{name}* not found")
-sym, body = m.group(1), m.group(2)
+sym = ms.group(1)
+m = re.search(r"^%s:[^\n]*\n(.*?)\n\s*s_endpgm" % re.escape(sym), txt, re.S | re.M)
+if not m:
+    sys.exit(f"body of {sym} not found")
+body = m.group(1)
 meta = txt[txt.index(".amdhsa_kernel " + sym):]
 meta = meta[:meta.index(".end_amdhsa_kernel")]
 def field(k):

@@ -802,7 +802,7 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
 // per boundary - epilogue 10.8 k ticks, prologue 7.9 k (a full DMA round trip with the matrix pipe idle), first tile 2.5 k, and
 // the 32 MFMAs of an S(t+1) that does not exist - becomes ~2 k + ~2 k.  An item of fewer than 4 tiles ends in a HARD boundary
 // (drain, prologue as below): the look-ahead beyond it was issued before its successor was known.
-template <int UNUSED>
+template <bool BOUNDED>
 __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   asm volatile("" ::: "a0", "a15", "a31", "a47", "a63", "a79", "a95", "a111", "a127", "a143", "a159", "a175", "a191", "a207",
@@ -965,6 +965,9 @@ __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) asm volatile("" : "=v"(P[i >> 2][i & 3]));
   u32x4 vf[a64s::V_REGS];            // V^T fragment ring
+  u32x4 vfr[8];                      // (running-max form: its own ring of eight, dt-major P.V order)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) asm volatile("" : "=v"(vfr[i]));
 #pragma unroll
   for (int i = 0; i < a64s::V_REGS; ++i) asm volatile("" : "=v"(vf[i]));
   float l_acc[2] = {0.f, 0.f}, l_e[2] = {0.f, 0.f};
@@ -990,6 +993,132 @@ __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
   };
   auto tile_masked = [&](int n) { return n * KVB + KVB > c_kvlen || (n * KVB < c_gap_hi && n * KVB + KVB > c_gap_lo); };
 
+  // ---- running-max form (BOUNDED = false: weights whose QK-norm scales do not bound the logits): the row max m of a tile is
+  // subtracted BY THE MATRIX PIPE (9th k-step: q_aug = (-m, -29952), k_aug = (1, key masked)), m moves only when a row of the
+  // wave grows by more than 2^8 (deferred rescale), exactly as attn64_kernel<false> - same arithmetic, inside the stream
+  // skeleton (stream DMA across items, soft boundaries, in-launch combine) ----
+  // (scalars and two named vectors, not arrays: arrays captured by the nested lambdas ended up in scratch memory)
+  float m_run0 = 0.f, m_run1 = 0.f, alpha0 = 1.f, alpha1 = 1.f;
+  u32x4 qaug_r0 = {qaug_mask, 0u, 0u, 0u}, qaug_r1 = {qaug_mask, 0u, 0u, 0u};
+  int resc = 0;
+  float mxp0 = 0.f, mxp1 = 0.f, mxp2 = 0.f, mxp3 = 0.f, mq0 = 0.f, mq1 = 0.f;
+  auto max_step = [&](f32x16& Sx, float& mx, auto Jc) {     // 8 steps per chain: 16 values -> one
+    constexpr int j = decltype(Jc)::value;
+    if constexpr (j == 0) mx = v_max3(Sx[0], Sx[1], Sx[2]);
+    else if constexpr (j < 7) mx = v_max3(mx, Sx[2 * j + 1], Sx[2 * j + 2]);
+    else mx = v_max(mx, Sx[15]);
+  };
+  auto max_steps = [&](auto B0, auto Jc) {                  // step j of all four chains of the S tile whose first block is B0
+    constexpr int b0 = decltype(B0)::value;
+    max_step(SBk[(b0 + 0) % 6], mxp0, Jc);
+    max_step(SBk[(b0 + 1) % 6], mxp1, Jc);
+    max_step(SBk[(b0 + 2) % 6], mxp2, Jc);
+    max_step(SBk[(b0 + 3) % 6], mxp3, Jc);
+  };
+  auto decide0 = [&]() {
+    mq0 = v_max(mxp0, mxp1);
+    mq1 = v_max(mxp2, mxp3);
+  };
+  auto decide1 = [&](auto QBc) { if constexpr (decltype(QBc)::value == 0) mq0 = xmax32(mq0); else mq1 = xmax32(mq1); };
+  auto new_max = [&](float mq, float& m_run, float& alpha, u32x4& qa, f32x16& S0, f32x16& S1, bool first) {
+    const float want = first ? mq : m_run + fmaxf(mq, 0.f);
+    const bf16_t nb = f2bf(-want);
+    const float m_new = -bf2f(nb);
+    const float delta = m_new - m_run;
+    alpha = __builtin_amdgcn_exp2f(-delta);
+    m_run = m_new;
+    qa[0] = ((uint32_t)nb & aug_on) | qaug_mask;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { S0[r] -= delta; S1[r] -= delta; }
+  };
+  auto decide2 = [&](auto B0, bool first) {       // B0: index of the first block of the tile's S in SBk
+    constexpr int b0 = decltype(B0)::value;
+    resc = (first || !__all((mq0 <= 8.0f) && (mq1 <= 8.0f))) ? 1 : 0;
+    if (resc) {
+      new_max(mq0, m_run0, alpha0, qaug_r0, SBk[(b0 + 0) % 6], SBk[(b0 + 1) % 6], first);
+      new_max(mq1, m_run1, alpha1, qaug_r1, SBk[(b0 + 2) % 6], SBk[(b0 + 3) % 6], first);
+    }
+  };
+  // (always_inline: left to the inliner's size heuristics this body becomes a CALL, and everything it captures by reference
+  // - l, alpha, the flag - then lives in scratch memory, loaded and stored in every tile)
+  auto rescale_o = [&]() __attribute__((always_inline)) {      // the rare path: O *= alpha, l *= alpha (between two P.V phases)
+    if (resc) {
+      asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+      sfor<0, 64>([&](auto I) { constexpr int i = decltype(I)::value; agpr_write<A_O + i>(agpr_read<A_O + i>() * alpha0); });
+      sfor<64, 128>([&](auto I) { constexpr int i = decltype(I)::value; agpr_write<A_O + i>(agpr_read<A_O + i>() * alpha1); });
+      l_acc[0] *= alpha0;
+      l_acc[1] *= alpha1;
+      asm volatile("s_nop 7" ::: "memory");
+      resc = 0;
+    }
+  };
+  // one tile of the running-max form (attn64_kernel<false>'s tile_r: 36 + 32 MFMAs, every phase-A gap takes a pair, the row
+  // max of S(kt+1) fills the P.V phase); LAST / RK as tile_s below
+  auto tile_rs = [&](auto Jc, auto LASTc, int kt) {
+    constexpr int J = decltype(Jc)::value;
+    constexpr bool LAST = decltype(LASTc)::value, RK = !LAST || J == 1;
+    constexpr int BASE = (4 * J) % 6;
+    using SLOT_V = std::integral_constant<int, J>;
+    using SLOT_K2 = std::integral_constant<int, (J + 2) % 3>;
+    using SLOT_K4 = std::integral_constant<int, (J + 1) % 3>;
+    rescale_o();
+    const u32x4 ka0 = make_kaug(kt + 1, 0), ka1 = make_kaug(kt + 1, 1);
+    uint32_t k_bd;
+    uint32_t k_sc = k_src(kt + 4, k_bd), v_sc = v_src(kt + 2);
+    asm volatile("" : "+s"(k_sc), "+s"(v_sc), "+s"(k_bd));
+    SB();
+    float pe0r = 0.f, pe1r = 0.f;
+    sfor<0, 36>([&](auto Gp) {
+      constexpr int g = decltype(Gp)::value, c = g / 9, t = g % 9, qb = c >> 1, u = c & 1;
+      if constexpr (!LAST) {
+        if constexpr (t < 8) mfma_qk<A_K + (u * 8 + t) * 4, A_Q + (qb * 8 + t) * 4, t == 0>(SBk[(BASE + 4 + c) % 6]);
+        else mfma_aug(SBk[(BASE + 4 + c) % 6], u == 0 ? ka0 : ka1, qb == 0 ? qaug_r0 : qaug_r1);
+      }
+      if constexpr (g > 0 && g <= 32) {   // pair g-1: row sum and bf16 pack of the two probabilities exponentiated one gap earlier
+        constexpr int k = g - 1, pq = k >> 4, idx = k & 15, pu = idx >> 3, r0 = (idx & 7) * 2;
+        l_acc[pq] += pe0r;
+        l_acc[pq] += pe1r;
+        PIN(l_acc[pq]);
+        P[pq][pu * 2 + (r0 >> 3)][(r0 & 7) >> 1] = v_cvt_pk(pe0r, pe1r);
+      }
+      if constexpr (g < 32) {
+        constexpr int k = g, pq = k >> 4, idx = k & 15, pu = idx >> 3, r0 = (idx & 7) * 2;
+        pe0r = __builtin_amdgcn_exp2f(SBk[(BASE + pq * 2 + pu) % 6][r0]);
+        pe1r = __builtin_amdgcn_exp2f(SBk[(BASE + pq * 2 + pu) % 6][r0 + 1]);
+      }
+      if constexpr (g >= 32) {            // the four thin gaps at the end take the first eight V^T fragments
+        constexpr int f = (g - 32) * 2;   // fragment (dt = f >> 2, s = f & 3)
+        lds_v<SLOT_V::value * V_TILE + (f >> 2) * 4096>(vfr[f], v_rd[f & 3]);
+        lds_v<SLOT_V::value * V_TILE + ((f + 1) >> 2) * 4096>(vfr[f + 1], v_rd[(f + 1) & 3]);
+      }
+      if constexpr (g == 35) wait_lgkm<0>();
+      SB();
+    });
+    sfor<0, 32>([&](auto Gp) {
+      constexpr int g = decltype(Gp)::value, dt = g >> 3, s = (g >> 1) & 3, qb = g & 1;
+      if constexpr (g == 16) wait_lgkm<0>();      // V^T fragments 8..15 (and the K fragments issued so far)
+      mfma_pv<A_O + (qb * 4 + dt) * 16>(vfr[(dt & 1) * 4 + s], P[qb][s]);
+      if constexpr (!LAST) {                      // S(kt+1) was completed by the last MFMAs of phase A: first VALU read two gaps later
+        if constexpr (g >= 2 && g <= 9) max_steps(std::integral_constant<int, (BASE + 4) % 6>{}, std::integral_constant<int, g - 2>{});
+        if constexpr (g == 10) decide0();
+        if constexpr (g == 11) decide1(I0{});
+        if constexpr (g == 12) decide1(I1{});
+        if constexpr (g == 13) decide2(std::integral_constant<int, (BASE + 4) % 6>{}, false);
+      }
+      if constexpr ((g & 1) && g < 16) lds_v<SLOT_V::value * V_TILE + (dt + 2) * 4096>(vfr[(dt & 1) * 4 + s], v_rd[s]);
+      if constexpr (RK && g >= 14 && g < 30) read_k(SLOT_K2{}, std::integral_constant<int, g - 14>{});
+      if constexpr (g < 2 || (g >= 18 && g < 30 && (g & 1) == 0)) {    // LDS-DMA pieces: gaps 0, 1, 18, 20, ... 28
+        constexpr int i = g < 2 ? g : (g - 18) / 2 + 2;
+        if constexpr (i < 4) dma_v_at(SLOT_K2{}, v_sc, i);
+        else dma_k_at(SLOT_K4{}, k_sc, k_bd, i - 4);
+      }
+      SB();
+    });
+    wait_vm<8>();
+    wait_lgkm<0>();
+    __builtin_amdgcn_s_barrier();
+    SB();
+  };
   // ---- one filler token of the generated schedule (attention64_sched.h); LAST: the item's last tile, which has no S(t+1) -
   // no exponentials of it, no K fragments of the tile after it (the K registers keep K'(0) of the next item), and its counted
   // waits, sized for the full read stream, become lgkmcnt(0) ----
@@ -1079,6 +1208,10 @@ __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
 #endif
     SB();
   };
+  auto tile_any = [&](auto Jc, auto LASTc, int kt) {
+    if constexpr (BOUNDED) tile_s(Jc, LASTc, kt);
+    else tile_rs(Jc, LASTc, kt);
+  };
   // ---- an EMPTY step of rotation J at stream position n (between an item's last tile and the rotation boundary): only the
   // stream's LDS-DMA (V^T(n+2), K(n+4): the next item's first tiles) and the step's waits; READ_K: the K'(0) fragments ----
   auto empty_s = [&](auto Jc, auto RKc, int n) {
@@ -1105,7 +1238,7 @@ __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
       constexpr int g = decltype(Gp)::value, c = g >> 3, t = g & 7;
       mfma_qk<A_K + ((c & 1) * 8 + t) * 4, A_Q + ((c >> 1) * 8 + t) * 4, t == 0>(SBk[c]);
       if constexpr (t == 7) {
-        if (__builtin_expect(msk0, 0)) masked_step(SBk[c], c_kt0, c & 1);
+        if (__builtin_expect(msk0, 0)) masked_step(SBk[c], c_kt0, c & 1);      // (reference point 0 on an item's first tile in both forms)
       }
       sfor<0, 4>([&](auto Zc) { agpr_write<A_O + g * 4 + decltype(Zc)::value>(0.f); });
       SB();
@@ -1119,7 +1252,17 @@ __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
     SB();
     l_acc[0] = l_acc[1] = 0.f;
     l_e[0] = l_e[1] = 0.f;
-    sfor<0, a64s::N_EARLY>([&](auto Ic) {
+    if constexpr (!BOUNDED) {             // the item's first reference point: the row max of its first tile
+      m_run0 = m_run1 = 0.f;
+      qaug_r0[0] = qaug_mask; qaug_r1[0] = qaug_mask;
+      sfor<0, 8>([&](auto Jc) { max_steps(I0{}, Jc); });
+      decide0();
+      decide1(I0{});
+      decide1(I1{});
+      decide2(I0{}, true);
+      resc = 0;                           // O = 0, l = 0: nothing to rescale
+    }
+    if constexpr (BOUNDED) sfor<0, a64s::N_EARLY>([&](auto Ic) {
       constexpr int k = a64s::EARLY_PAIR[decltype(Ic)::value], pq = k >> 4, idx = k & 15, pu = idx >> 3, r0 = (idx & 7) * 2;
       const float e0 = __builtin_amdgcn_exp2f(SBk[pq * 2 + pu][r0]), e1 = __builtin_amdgcn_exp2f(SBk[pq * 2 + pu][r0 + 1]);
       l_e[pq] += e0;
@@ -1155,7 +1298,7 @@ __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
           if (a.inmerge) __hip_atomic_store((uint64_t*)dst, __builtin_bit_cast(uint64_t, w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           else *(f16x4*)dst = w;
         });
-        const f32x2 ml = {0.f, l_tot};                                // reference point 0: bounded logits
+        const f32x2 ml = {BOUNDED ? 0.f : (qb == 0 ? m_run0 : m_run1), l_tot};          // (reference point 0 with bounded logits)
         char* dml = pp + PART64_O_BYTES + ((wave * 2 + qb) * 64 + lane) * 8;
         if (a.inmerge) __hip_atomic_store((uint64_t*)dml, __builtin_bit_cast(uint64_t, ml), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else *(f32x2*)dml = ml;
@@ -1241,23 +1384,23 @@ __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
     const int kt_last = c_kt1 - 1;
     for (;;) {
       if (kt >= kt_last) { exit_j = 0; break; }
-      tile_s(I0{}, std::false_type{}, kt); ++kt;
+      tile_any(I0{}, std::false_type{}, kt); ++kt;
       if (kt >= kt_last) { exit_j = 1; break; }
-      tile_s(I1{}, std::false_type{}, kt); ++kt;
+      tile_any(I1{}, std::false_type{}, kt); ++kt;
       if (kt >= kt_last) { exit_j = 2; break; }
-      tile_s(I2{}, std::false_type{}, kt); ++kt;
+      tile_any(I2{}, std::false_type{}, kt); ++kt;
     }
     // ---- the last tile (P.V only), the empty steps up to the rotation boundary, O out ----
     const bool soft = have_next && (c_kt1 - c_kt0) >= 4;     // the look-ahead of a shorter item was issued before its successor was known
     if (soft) load_queries(n_id);            // the Q registers are idle: the last tile computes no S(t+1)
     if (exit_j == 0) {
-      tile_s(I0{}, std::true_type{}, kt);
+      tile_any(I0{}, std::true_type{}, kt);
       if (soft) { empty_s(I1{}, std::true_type{}, kt + 1); empty_s(I2{}, std::false_type{}, kt + 2); }
     } else if (exit_j == 1) {
-      tile_s(I1{}, std::true_type{}, kt);
+      tile_any(I1{}, std::true_type{}, kt);
       if (soft) empty_s(I2{}, std::false_type{}, kt + 1);
     } else {
-      tile_s(I2{}, std::true_type{}, kt);
+      tile_any(I2{}, std::true_type{}, kt);
     }
     TS_S(3);
     if (pub >= 0) { publish(pub); pub = -1; }
@@ -1481,7 +1624,8 @@ int vc_attention64_launch(const VcAttention& A, bool tail_split, int n_cu, uint6
   if (done.need()) {
     e = hipFuncSetAttribute((const void*)attn64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn64s_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn64s_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn64s_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
     if (e != hipSuccess) { snprintf(err, errlen, "attention64 attribute: %s", hipGetErrorString(e)); return VC_ERR_HIP; }
     done.mark();
   }
@@ -1492,8 +1636,8 @@ int vc_attention64_launch(const VcAttention& A, bool tail_split, int n_cu, uint6
   // (its LDS-DMA addresses are kernel-argument base + 32-bit byte offset)
   const bool fits32 = ((uint64_t)B * (uint64_t)A.bstride + (uint64_t)L * (uint64_t)A.ld + 3u * (uint64_t)H * 128u) * 2u < (1ull << 32) &&
                       (uint64_t)B * (uint64_t)H * 128u * (uint64_t)A.Lpad * 2u < (1ull << 32) && L >= 16;
-  const bool stream = bounded && a.q_pre && !A.q_scale && fits32;
-  void (*kern)(const Attn64Args) = stream ? attn64s_kernel<0> : bounded ? attn64_kernel<true> : attn64_kernel<false>;
+  const bool stream = a.q_pre && !A.q_scale && fits32;
+  void (*kern)(const Attn64Args) = stream ? (bounded ? attn64s_kernel<true> : attn64s_kernel<false>) : bounded ? attn64_kernel<true> : attn64_kernel<false>;
   const int G = n_cu;
   const int nkt = (L + KVB - 1) / KVB;
   // the tail split is scheduled per XCD (Sched64): cut where some XCD has tail items and cutting shortens its critical

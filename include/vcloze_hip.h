@@ -21,13 +21,13 @@ extern "C" {
 #define VC_ERR_HIP (-2)
 #define VC_ERR_STATE (-3)
 
-#define VC_ABI_VERSION 9
+#define VC_ABI_VERSION 10
 int vc_abi_version(void);
 const char* vc_last_error(void);
 /* sizeof(VcGemmProblem), sizeof(VcGemmArgs), sizeof(VcLnStream), sizeof(VcAttention), sizeof(VcFluxConfig),
- * sizeof(VcFluxInputs) as this library was compiled: a binding checks them against its own mirrors at load time, so a
- * stale .so cannot silently disagree with the caller. */
-void vc_struct_sizes(int32_t out[6]);
+ * sizeof(VcFluxInputs), sizeof(VcFluxLaunchClass) (ABI 10: SEVEN entries) as this library was compiled: a binding checks them
+ * against its own mirrors at load time, so a stale .so cannot silently disagree with the caller. */
+void vc_struct_sizes(int32_t out[7]);
 /* number of visible devices / name of device 0 ("" when none) — fails loudly, never falls back */
 int vc_device_count(void);
 int vc_device_info(int dev, char* name, int namelen, int* cu_count, int64_t* hbm_bytes);
@@ -398,6 +398,29 @@ int vc_flux_sample_begin(void* handle, const void* x, const void* cond, const fl
                          int32_t state_is_bf16, void* stream);
 int vc_flux_sample_steps(void* handle, int32_t n_steps, void* trajectory, void* stream);
 int vc_flux_sample_end(void* handle, void* x_out, void* stream);
+
+/* ---- the plan's own stopwatch (ABI 10): HIP-event times of the launches of whole evaluations, class by class ----
+ * What bench.py's `roofline` leg reports.  With a sample in flight (vc_flux_sample_begin), `evaluations` more evaluations of
+ * Flux.forward at the trajectory's CURRENT step are issued on `stream` by the same code the step graph was captured from - not
+ * captured, no Euler update: the state, the step counter and the graph stay as they are - with an event in front of and behind
+ * every GEMM, attention and LayerNorm-modulate launch (one warm evaluation first).  Every launch therefore finds the caches as
+ * its predecessor in the step leaves them.  Synchronises `stream`; entries come in order of first appearance.
+ * Reference: there is none (the reference times whole pipelines, visualcloze.py); replaces the Python-ordered twin of the plan
+ * (visualcloze_amd/engine.py) as the thing bench.py times. */
+enum { VC_LAUNCH_GEMM = 1, VC_LAUNCH_ATTENTION = 2, VC_LAUNCH_LN_MODULATE = 3 };
+typedef struct VcFluxLaunchClass {
+  int32_t kind;        /* VC_LAUNCH_* */
+  int32_t epi;         /* GEMM: the VC_EPI_* of the launch; attention: the VcAttention.variant that ran; else 0 */
+  int32_t n, k;        /* GEMM: N and K of the launch's first problem (a grouped launch: its img stream); else 0 */
+  int32_t launches;    /* launches of this class in the timed evaluations */
+  int32_t reserved;
+  double flops;        /* their arithmetic: 2 M N K over all problems (GEMM), 4 L^2 D B (attention: masked keys included), else 0 */
+  double bytes;        /* LayerNorm-modulate: rows read + rows written; else 0 */
+  float total_us;      /* sum of the launches' event times (an attention launch: the kernel and, where one runs, its merge kernel) */
+  float min_us, max_us;
+  float reserved2;
+} VcFluxLaunchClass;
+int vc_flux_profile(void* handle, int32_t evaluations, VcFluxLaunchClass* out, int32_t capacity, int32_t* count, void* stream);
 
 /* ---- hipGraph helpers: capture the launches issued on `stream` between begin/end ---- */
 int vc_stream_create(void** stream);

@@ -72,7 +72,7 @@ static void bind_scale(const char* name) {
 
 int main(int argc, char** argv) {
   if (argc < 2) { fprintf(stderr, "usage: %s out.bin\n", argv[0]); return 1; }
-  int32_t sizes[6];
+  int32_t sizes[7];
   vc_struct_sizes(sizes);
   if (vc_abi_version() != VC_ABI_VERSION || sizes[4] != (int32_t)sizeof(VcFluxConfig) || sizes[5] != (int32_t)sizeof(VcFluxInputs)) {
     fprintf(stderr, "library / header mismatch\n");

@@ -133,6 +133,51 @@ def test_sampler_trajectory_and_piecewise_steps(model):
         h.sample_steps(1, st.cuda_stream)
 
 
+def test_profile_times_the_plans_own_launches_and_leaves_the_trajectory_alone(model):
+    """vc_flux_profile (ABI 10, bench.py's roofline leg): the launch classes of whole evaluations issued by the handle's own
+    plan - the counts and the arithmetic are the plan's, every class has a positive time, and a trajectory with a profile in
+    its middle ends in the same bits as one without."""
+    from tests.procedural import tiny_inputs
+    from visualcloze_amd import hip
+    from visualcloze_amd.transport import solver_time_grid
+    m, _ = model
+    inp = tiny_inputs(B=2)
+    h = m.handle()
+    kw = _kw(inp)
+    S, E = 3, 2
+    t = solver_time_grid(S + 1, inp["x"].shape[1], 0.0, 1, True, 1)
+    st = m.engine().stream
+    g = m.engine().g
+    B, N, T = inp["x"].shape[0], inp["x"].shape[1], inp["txt"].shape[1]
+    L, D, mlp = N + T, g.hidden_size, int(g.hidden_size * g.mlp_ratio)
+    with torch.cuda.stream(st):
+        s = st.cuda_stream
+        h.prepare(kw["txt"], kw["y"], kw["guidance"], False, kw["img_ids"], kw["txt_ids"], S, stream=s)
+        with pytest.raises(Exception, match="sample_begin"):
+            h.profile(1, s)                                   # no sample in flight
+        x1 = inp["x"].to(DEV, torch.bfloat16).clone()
+        h.sample_euler(x1, kw["cond"], t, True, s)
+        x2 = inp["x"].to(DEV, torch.bfloat16).clone()
+        h.sample_begin(x2, kw["cond"], t, True, s)
+        h.sample_steps(1, s)
+        recs = h.profile(E, s)
+        h.sample_steps(S - 1, s)
+        out = torch.empty_like(x2)
+        h.sample_end(out, s)
+    torch.cuda.synchronize()
+    assert torch.equal(out, x1)
+    att = [r for r in recs if r["kind"] == hip.LAUNCH_ATTENTION]
+    assert len(att) == 1 and att[0]["launches"] == E * (g.depth + g.depth_single_blocks)
+    assert att[0]["flops"] == pytest.approx(att[0]["launches"] * 4.0 * L * L * D * B)
+    gate = [r for r in recs if r["kind"] == hip.LAUNCH_GEMM and r["epi"] == hip.EPI_GATE_RES]
+    assert sum(r["launches"] for r in gate) == E * (2 * g.depth + g.depth_single_blocks)
+    assert sum(r["flops"] for r in gate) == pytest.approx(E * B * (g.depth * (2.0 * L * D * D + 2.0 * L * D * mlp) + g.depth_single_blocks * 2.0 * L * D * (D + mlp)))
+    ln = [r for r in recs if r["kind"] == hip.LAUNCH_LN_MODULATE]
+    assert sum(r["launches"] for r in ln) == E * (2 * g.depth + g.depth_single_blocks + 1)
+    for r in recs:
+        assert r["launches"] > 0 and 0 < r["min_us"] <= r["total_us"] / r["launches"] <= r["max_us"] < 1e5, r
+
+
 def test_handle_error_behaviour(model):
     from tests.procedural import TINY, tiny_inputs
     from visualcloze_amd import hip

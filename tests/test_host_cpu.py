@@ -34,10 +34,11 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(hip.FluxConfig) == 14 * 4
     assert ctypes.sizeof(hip.FluxInputs) == 4 * 4 + 7 * 8 + 2 * 4
     # the library reports the same sizes (and hip.lib() refuses to load one that does not)
-    sizes = (ctypes.c_int32 * 6)()
+    assert ctypes.sizeof(hip.FluxLaunchClass) == 6 * 4 + 2 * 8 + 4 * 4           # vc_flux_profile (ABI 10)
+    sizes = (ctypes.c_int32 * 7)()
     hip.lib().vc_struct_sizes(sizes)
     assert list(sizes) == [ctypes.sizeof(c) for c in (hip.GemmProblem, hip.GemmArgs, hip.LnStream, hip.Attention, hip.FluxConfig,
-                                                       hip.FluxInputs)]
+                                                       hip.FluxInputs, hip.FluxLaunchClass)]
 
 
 def test_no_gpu_fails_loudly():

@@ -27,11 +27,14 @@ def load(name):
     path = hip.LIB_PATH if name == "main" else os.path.join(os.path.dirname(hip.LIB_PATH), f"libvcloze_hip_{name}.so")
     l = C.CDLL(path)
     for sym, (res, args) in hip.SYMBOLS.items():
+        if sym == "vc_flux_profile" and not hasattr(l, sym):      # an older library in the A/B
+            continue
         fn = getattr(l, sym)
         fn.restype, fn.argtypes = res, args
     # ABI 9 added a bit of VcAttention.variant (28 = 12 + 16, ignored by an ABI-8 library): same struct layouts, so a round-5
     # library can still stand in an A/B
-    assert l.vc_abi_version() in (hip.ABI_VERSION, 8), (name, l.vc_abi_version())
+    # (ABI 10 added vc_flux_profile, which these A/Bs do not call: libraries back to ABI 8 can still stand in)
+    assert l.vc_abi_version() in (hip.ABI_VERSION, 9, 8), (name, l.vc_abi_version())
     return l
 
 
@@ -107,7 +110,7 @@ def main():
             hip._lib = libs[alias]
             for k, v in o.items():
                 setattr(eng, k, v)
-            out[alias]["attention"] = {k: v for k, v in bench.roofline_attention(job, iters=2).items()
+            out[alias]["attention"] = {k: v for k, v in bench.roofline_attention(job, iters=2, via="python").items()
                                        if k in ("avg_launch_us", "median_launch_us", "isolated_us", "frac", "variant")}
     base = out[builds[0][1]]["median_ms"]
     for _, alias in builds:

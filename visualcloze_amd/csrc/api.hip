@@ -15,9 +15,10 @@ extern "C" {
 
 int vc_abi_version(void) { return VC_ABI_VERSION; }
 const char* vc_last_error(void) { return g_err; }
-void vc_struct_sizes(int32_t out[6]) {
+void vc_struct_sizes(int32_t out[7]) {
   out[0] = (int32_t)sizeof(VcGemmProblem); out[1] = (int32_t)sizeof(VcGemmArgs); out[2] = (int32_t)sizeof(VcLnStream);
   out[3] = (int32_t)sizeof(VcAttention); out[4] = (int32_t)sizeof(VcFluxConfig); out[5] = (int32_t)sizeof(VcFluxInputs);
+  out[6] = (int32_t)sizeof(VcFluxLaunchClass);
 }
 
 int vc_device_count(void) {
@@ -171,6 +172,9 @@ int vc_flux_sample_begin(void* handle, const void* x, const void* cond, const fl
 }
 int vc_flux_sample_steps(void* handle, int32_t n_steps, void* trajectory, void* stream) {
   return vc_flux_sample_steps_impl(handle, n_steps, trajectory, S(stream), ERRBUF);
+}
+int vc_flux_profile(void* handle, int32_t evaluations, VcFluxLaunchClass* out, int32_t capacity, int32_t* count, void* stream) {
+  return vc_flux_profile_impl(handle, evaluations, out, capacity, count, S(stream), ERRBUF);
 }
 int vc_flux_sample_end(void* handle, void* x_out, void* stream) { return vc_flux_sample_end_impl(handle, x_out, S(stream), ERRBUF); }
 int vc_flux_sample_euler(void* handle, void* x, const void* cond, const float* t_grid, int32_t n_points, int32_t state_is_bf16,

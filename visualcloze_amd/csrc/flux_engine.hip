@@ -84,6 +84,12 @@ struct Flux : Buffers {
   size_t pinned_bytes = 0, pinned_used = 0;
   hipEvent_t staged = nullptr;
   bool staged_pending = false;
+  // vc_flux_profile: HIP-event pairs around the launches of one evaluation (off outside that call)
+  struct ProfRec { int kind, epi, n, k; double flops, bytes; size_t e0; };
+  bool prof_on = false;
+  std::vector<hipEvent_t> prof_ev;
+  size_t prof_used = 0;
+  std::vector<ProfRec> prof_recs;
 };
 
 #define FAIL(code, ...)                         \
@@ -253,13 +259,34 @@ VcGemmProblem prob(const void* A, int64_t lda, const Lin& w, void* C, int64_t ld
   p.rows_per_batch = M;
   return p;
 }
+// vc_flux_profile: an event in front of and behind a launch of the plan (one pair per launch, taken from a pool that grows on demand)
+int prof_event(Flux& f, hipStream_t s, Err e) {
+  if (f.prof_used == f.prof_ev.size()) {
+    hipEvent_t ev;
+    HIP(hipEventCreate(&ev), "hipEventCreate");
+    f.prof_ev.push_back(ev);
+  }
+  HIP(hipEventRecord(f.prof_ev[f.prof_used++], s), "hipEventRecord");
+  return VC_OK;
+}
+int prof_open(Flux& f, hipStream_t s, int kind, int epi, int n, int k, double flops, double bytes, Err e) {
+  if (!f.prof_on) return VC_OK;
+  f.prof_recs.push_back(Flux::ProfRec{kind, epi, n, k, flops, bytes, f.prof_used});
+  return prof_event(f, s, e);
+}
+int prof_close(Flux& f, hipStream_t s, Err e) { return f.prof_on ? prof_event(f, s, e) : VC_OK; }
+
 int gemm(Flux& f, const VcGemmProblem* ps, int n, int epi, const int32_t* step_ptr, int64_t gate_step_stride, hipStream_t s, Err e) {
   VcGemmArgs a;
   memset(&a, 0, sizeof(a));
   for (int i = 0; i < n; ++i) a.p[i] = ps[i];
   a.nprob = n; a.epi = epi; a.step_ptr = step_ptr; a.gate_step_stride = gate_step_stride;
   if (f.splitk) { a.splitk_ws = f.SK_WS; a.splitk_ws_bytes = f.sk_ws_bytes; }   // the launcher's cost model decides
-  return vc_gemm_launch(a, f.tile_cfg, s, e.buf, e.len);
+  double flops = 0;
+  for (int i = 0; i < n; ++i) flops += 2.0 * ps[i].M * ps[i].N * ps[i].K;
+  TRY(prof_open(f, s, VC_LAUNCH_GEMM, epi, ps[0].N, ps[0].K, flops, 0, e));
+  TRY(vc_gemm_launch(a, f.tile_cfg, s, e.buf, e.len));
+  return prof_close(f, s, e);
 }
 int lin(Flux& f, const Lin& w, const void* A, int64_t lda, void* C, int64_t ldc, int M, int epi, hipStream_t s, Err e) {
   VcGemmProblem p = prob(A, lda, w, C, ldc, M);
@@ -276,11 +303,15 @@ inline const bf16_t* modp(Flux& f, int64_t off, int idx) { return f.MOD + off + 
 int ln2(Flux& f, const Ctx& c, const DoubleW& w, int idx, Err e) {   // img + txt streams in one launch
   VcLnStream a{f.XI, f.D, f.XH, f.D, modp(f, w.mod[0], idx), modp(f, w.mod[0], idx + 1), f.B * f.N, f.N};
   VcLnStream b{f.XT, f.D, f.XH + (int64_t)f.B * f.N * f.D, f.D, modp(f, w.mod[1], idx), modp(f, w.mod[1], idx + 1), f.B * f.T, f.T};
-  return vc_ln_modulate2_launch(&a, &b, f.n_mod, f.D, c.step_ptr, c.mss, c.s, e.buf, e.len);
+  TRY(prof_open(f, c.s, VC_LAUNCH_LN_MODULATE, 0, 0, 0, 0, 4.0 * f.B * f.L * f.D, e));      // rows read + written, bf16
+  TRY(vc_ln_modulate2_launch(&a, &b, f.n_mod, f.D, c.step_ptr, c.mss, c.s, e.buf, e.len));
+  return prof_close(f, c.s, e);
 }
 int ln1(Flux& f, const Ctx& c, int64_t mod, Err e) {                  // the joint stream X -> XH
-  return vc_ln_modulate_launch(f.X, f.D, f.XH, f.D, modp(f, mod, 0), modp(f, mod, 1), f.n_mod, f.B * f.L, f.D, f.L, c.step_ptr, c.mss,
-                               c.s, e.buf, e.len);
+  TRY(prof_open(f, c.s, VC_LAUNCH_LN_MODULATE, 0, 0, 0, 0, 4.0 * f.B * f.L * f.D, e));
+  TRY(vc_ln_modulate_launch(f.X, f.D, f.XH, f.D, modp(f, mod, 0), modp(f, mod, 1), f.n_mod, f.B * f.L, f.D, f.L, c.step_ptr, c.mss,
+                            c.s, e.buf, e.len));
+  return prof_close(f, c.s, e);
 }
 
 int attention_variant(const Flux& f) {
@@ -315,7 +346,9 @@ int attention(Flux& f, const Ctx& c, const void* q1, const void* k1, const void*
   if (q_done) a.q_prescaled = 1;
   else if (fused_q) { a.q_scale = q1; a.q_scale2 = q2; a.split = split; a.rope = f.ROPE; a.rope_bstride = (int64_t)f.L * 128; }
   a.logit_bound = (float)f.logit_bound_milli * 1e-3f;
-  return vc_attention_launch(a, c.s, e.buf, e.len);
+  TRY(prof_open(f, c.s, VC_LAUNCH_ATTENTION, variant, 0, 0, 4.0 * f.L * f.L * f.D * f.B, 0, e));     // the attention launch(es) alone
+  TRY(vc_attention_launch(a, c.s, e.buf, e.len));
+  return prof_close(f, c.s, e);
 }
 
 // DoubleStreamBlock (layers.py:158-196) on XI / XT, in place
@@ -462,6 +495,10 @@ int time_precompute(Flux& f, int S, int timesteps_is_bf16, hipStream_t s, Err e)
 }
 
 constexpr size_t MAX_GRAPHS = 4;
+void drop_prof(Flux& f) {
+  for (auto ev : f.prof_ev) (void)hipEventDestroy(ev);
+  f.prof_ev.clear();
+}
 void drop_graph(Flux& f) {
   for (auto& g : f.graphs) (void)hipGraphExecDestroy(g.second);
   f.graphs.clear();
@@ -535,6 +572,7 @@ int vc_flux_destroy_impl(void* handle, char* err, int errlen) {
   H(handle);
   if (f.staged_pending) (void)hipEventSynchronize(f.staged);
   drop_graph(f);
+  drop_prof(f);
   if (f.pinned) (void)hipHostFree(f.pinned);
   if (f.staged) (void)hipEventDestroy(f.staged);
   delete &f;
@@ -772,4 +810,46 @@ int vc_flux_sample_end_impl(void* handle, void* x_out, hipStream_t s, char* err,
   if (!x_out) FAIL(VC_ERR_ARG, "flux_sample_end: null output");
   if (f.state_f32) return d2d(x_out, f.XS32, (int64_t)f.B * f.N * f.cfg.out_channels * 4, s, e);
   return d2d(x_out, f.XS, (int64_t)f.B * f.N * f.cfg.out_channels * 2, s, e);
+}
+
+// HIP-event times of the launches of the product's plan, class by class (vcloze_hip.h): `evaluations` evaluations of the sample in
+// flight at its current step, issued un-captured on `s` by the same code that the step graph was captured from, no Euler update
+// (the trajectory's state, its step counter and its graph are left as they are).
+int vc_flux_profile_impl(void* handle, int32_t evaluations, VcFluxLaunchClass* out, int32_t capacity, int32_t* count, hipStream_t s,
+                         char* err, int errlen) {
+  H(handle);
+  if (!f.prepared || f.steps_total == 0) FAIL(VC_ERR_STATE, "flux_profile: call vc_flux_sample_begin first");
+  if (!out || !count || capacity <= 0 || evaluations <= 0) FAIL(VC_ERR_ARG, "flux_profile: bad argument");
+  TRY(evaluate(f, f.STEP, true, nullptr, nullptr, false, s, e));       // warm: caches and clocks as inside a trajectory
+  f.prof_recs.clear();
+  f.prof_used = 0;
+  f.prof_on = true;
+  int rc = VC_OK;
+  for (int i = 0; i < evaluations && rc == VC_OK; ++i) rc = evaluate(f, f.STEP, true, nullptr, nullptr, false, s, e);
+  f.prof_on = false;
+  if (rc != VC_OK) return rc;
+  HIP(hipStreamSynchronize(s), "hipStreamSynchronize");
+  int n = 0;
+  for (const auto& r : f.prof_recs) {
+    float ms = 0.f;
+    HIP(hipEventElapsedTime(&ms, f.prof_ev[r.e0], f.prof_ev[r.e0 + 1]), "hipEventElapsedTime");
+    const float us = ms * 1e3f;
+    int j = 0;
+    while (j < n && !(out[j].kind == r.kind && out[j].epi == r.epi && out[j].n == r.n && out[j].k == r.k)) ++j;
+    if (j == n) {
+      if (n == capacity) FAIL(VC_ERR_ARG, "flux_profile: more than %d launch classes", capacity);
+      memset(&out[n], 0, sizeof(out[n]));
+      out[n].kind = r.kind; out[n].epi = r.epi; out[n].n = r.n; out[n].k = r.k;
+      out[n].min_us = us; out[n].max_us = us;
+      ++n;
+    }
+    out[j].launches += 1;
+    out[j].flops += r.flops;
+    out[j].bytes += r.bytes;
+    out[j].total_us += us;
+    if (us < out[j].min_us) out[j].min_us = us;
+    if (us > out[j].max_us) out[j].max_us = us;
+  }
+  *count = n;
+  return VC_OK;
 }

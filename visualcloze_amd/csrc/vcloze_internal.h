@@ -89,4 +89,6 @@ int vc_flux_forward_impl(void* handle, const void* img, const float* timesteps, 
 int vc_flux_sample_begin_impl(void* handle, const void* x, const void* cond, const float* t_grid, int32_t n_points, int32_t state_is_bf16,
                               hipStream_t s, char* err, int errlen);
 int vc_flux_sample_steps_impl(void* handle, int32_t n_steps, void* trajectory, hipStream_t s, char* err, int errlen);
+int vc_flux_profile_impl(void* handle, int32_t evaluations, VcFluxLaunchClass* out, int32_t capacity, int32_t* count, hipStream_t s,
+                         char* err, int errlen);
 int vc_flux_sample_end_impl(void* handle, void* x_out, hipStream_t s, char* err, int errlen);

@@ -203,6 +203,16 @@ class FluxHandle:
     def sample_steps(self, n: int, stream, trajectory=None) -> None:
         hip._check(hip.lib().vc_flux_sample_steps(self.h, n, hip._p(trajectory), stream), "vc_flux_sample_steps")
 
+    def profile(self, evaluations: int, stream) -> list:
+        """vc_flux_profile: HIP-event times of the launches of `evaluations` evaluations at the current step of the sample in
+        flight, class by class - a list of dicts (kind, epi, n, k, launches, flops, bytes, total_us, min_us, max_us)."""
+        import ctypes as C
+        cap = 32
+        out = (hip.FluxLaunchClass * cap)()
+        n = C.c_int32(0)
+        hip._check(hip.lib().vc_flux_profile(self.h, int(evaluations), out, cap, C.byref(n), stream), "vc_flux_profile")
+        return [{k: getattr(out[i], k) for k, _ in hip.FluxLaunchClass._fields_ if not k.startswith("reserved")} for i in range(n.value)]
+
     def sample_end(self, x_out, stream) -> None:
         hip._check(hip.lib().vc_flux_sample_end(self.h, x_out.data_ptr(), stream), "vc_flux_sample_end")
 

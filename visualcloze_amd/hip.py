@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VC_HIP_LIB") or os.path.join(_HERE, "lib", "libvcloze_hip.so")   # VC_HIP_LIB: profiling build
 CSRC = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 9                # VC_ABI_VERSION of include/vcloze_hip.h
+ABI_VERSION = 10               # VC_ABI_VERSION of include/vcloze_hip.h
 GEMM_MAX_PROBLEMS = 4          # VC_GEMM_MAX_PROBLEMS: grouped problems per vc_gemm launch
 EPI_BIAS, EPI_GELU, EPI_GATE_RES, EPI_SILU, EPI_QKV = 0, 1, 2, 3, 4
 GEMM_NO_SPLIT = 64             # VC_GEMM_NO_SPLIT: tile_cfg value that keeps an auto-tiled vc_gemm one launch
@@ -97,6 +97,14 @@ class FluxInputs(C.Structure):
 
 # every symbol include/vcloze_hip.h declares: name -> (restype, argtypes)
 _vp, _i32, _i64 = C.c_void_p, C.c_int32, C.c_int64
+class FluxLaunchClass(C.Structure):          # VcFluxLaunchClass (vc_flux_profile)
+    _fields_ = [("kind", C.c_int32), ("epi", C.c_int32), ("n", C.c_int32), ("k", C.c_int32), ("launches", C.c_int32), ("reserved", C.c_int32),
+                ("flops", C.c_double), ("bytes", C.c_double), ("total_us", C.c_float), ("min_us", C.c_float), ("max_us", C.c_float),
+                ("reserved2", C.c_float)]
+
+
+LAUNCH_GEMM, LAUNCH_ATTENTION, LAUNCH_LN_MODULATE = 1, 2, 3
+
 SYMBOLS = {
     "vc_abi_version": (C.c_int, []),
     "vc_last_error": (C.c_char_p, []),
@@ -150,6 +158,7 @@ SYMBOLS = {
     "vc_flux_sample_begin": (C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_float), _i32, _i32, _vp]),
     "vc_flux_sample_steps": (C.c_int, [_vp, _i32, _vp, _vp]),
     "vc_flux_sample_end": (C.c_int, [_vp, _vp, _vp]),
+    "vc_flux_profile": (C.c_int, [_vp, _i32, C.POINTER(FluxLaunchClass), _i32, C.POINTER(_i32), _vp]),
     "vc_stream_create": (C.c_int, [C.POINTER(_vp)]),
     "vc_stream_destroy": (C.c_int, [_vp]),
     "vc_stream_sync": (C.c_int, [_vp]),
@@ -190,10 +199,10 @@ def lib() -> C.CDLL:
             fn.restype, fn.argtypes = res, args
         if l.vc_abi_version() != ABI_VERSION:
             raise VclozeHipError(f"libvcloze_hip.so ABI version {l.vc_abi_version()} != {ABI_VERSION} expected by hip.py - rebuild")
-        sizes = (C.c_int32 * 6)()
+        sizes = (C.c_int32 * 7)()
         l.vc_struct_sizes(sizes)          # a stale library whose structs disagree with these ctypes mirrors must not run
         if list(sizes) != [C.sizeof(GemmProblem), C.sizeof(GemmArgs), C.sizeof(LnStream), C.sizeof(Attention),
-                           C.sizeof(FluxConfig), C.sizeof(FluxInputs)]:
+                           C.sizeof(FluxConfig), C.sizeof(FluxInputs), C.sizeof(FluxLaunchClass)]:
             raise VclozeHipError(f"libvcloze_hip.so struct sizes {list(sizes)} differ from the ctypes mirrors - rebuild")
         _lib = l
     return _lib

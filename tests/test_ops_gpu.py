@@ -771,6 +771,81 @@ def test_attention_stream_form_tail_combined_in_launch(hip, L, H, B):
         check(both[0.0][28][:L, h * 128:(h + 1) * 128], ref)
 
 
+def test_attention_stream_form_masks_randomised(hip):
+    """The PRODUCT's attention launches (stream form: prescaled queries, variants 8 / 12 / 28, bounded logits and the running-max
+    template) under per-sample key padding and per-sample masked gaps - gaps that start at key 0, end at kv_len, cover whole
+    64-key tiles, sit inside one tile or straddle two, samples whose last tile is partly padding, items cut into tail pieces -
+    against the f32 softmax over the live keys (math.py:9-60: masked keys get no weight, masked query rows come back as
+    zeros).  Variant 28 must equal variant 12 bit for bit under every mask (same pieces, same order of combination)."""
+    g = torch.Generator().manual_seed(4242)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))  # noqa: E731
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    for it in range(12):
+        if it % 3 == 0:                          # enough 256-query items for a tail: H = 24 heads
+            L, H, B = ri(1500, 2700), 24, 1 + it % 2
+        else:
+            L, H, B = ri(65, 1400), ri(1, 4), ri(1, 3)
+        ld = 3 * H * 128
+        qkv = rnd(B * L, ld, seed=900 + it)
+        ones = torch.ones(128, dtype=torch.bfloat16, device=DEV)
+        rope1 = rope_table(L)
+        rope = torch.stack([rope1] * B).contiguous() if B > 1 else rope1
+        Lpad = (L + 63) // 64 * 64
+        vt = torch.zeros((B, H, 128, Lpad), dtype=torch.bfloat16, device=DEV)
+        w = qkv.clone()
+        hip.qknorm_rope_vt(w, ones, ones, rope, vt, L, H, B=B, parts=hip.QKN_Q | hip.QKN_K | hip.QKN_VT | hip.QKN_QPRE)
+        kv, gaps = [], []
+        live = torch.ones(B, L, dtype=torch.bool, device=DEV)
+        for b in range(B):
+            k = L if ri(0, 3) == 0 else ri(max(1, L // 2), L)
+            mode = ri(0, 4)
+            if mode == 0:
+                lo, hi = 0, 0                                        # no gap
+            elif mode == 1:
+                lo, hi = 0, min(k - 1, 64 * ri(1, 3))                 # starts at key 0, whole tiles
+            elif mode == 2:
+                lo = ri(0, k - 1); hi = k                             # ends at kv_len
+            elif mode == 3:
+                lo = ri(0, k - 1); hi = min(k, lo + ri(1, 40))        # inside one tile or straddling two
+            else:
+                lo = ri(0, k - 1); hi = min(k, lo + ri(64, 400))      # several tiles
+            if hi - lo >= k:
+                lo, hi = 0, 0
+            kv.append(k); gaps.append([lo, hi])
+            live[b, k:] = False
+            live[b, lo:hi] = False
+        kvl = torch.tensor(kv, dtype=torch.int32, device=DEV)
+        gp = torch.tensor(gaps, dtype=torch.int32, device=DEV)
+        heads = sorted({0, H - 1, ri(0, H - 1)})
+        refs = []
+        for b in range(B):
+            qn, kn, _ = R.qknorm_rope_ref(qkv[b * L:(b + 1) * L], ones, ones, rope1, H)
+            v = qkv[b * L:(b + 1) * L, 2 * H * 128: 3 * H * 128].float().reshape(L, H, 128)
+            sc = torch.einsum("qhd,khd->hqk", qn[:, heads], kn[:, heads]) * 128 ** -0.5
+            sc = sc.masked_fill(~live[b][None, None, :], float("-inf"))
+            o = torch.einsum("hqk,khd->qhd", torch.softmax(sc, -1), v[:, heads]) * live[b][:, None, None]
+            refs.append(o)
+        outs = {}
+        for lb in (16.65, 0.0):
+            for variant in (8, 12, 28):
+                o = torch.full((B * L, H * 128), float("nan"), dtype=torch.bfloat16, device=DEV)
+                hip.attention(w, vt, o, L, H, variant=variant, B=B, kv_len=kvl, kv_gap=gp, q_prescaled=True, logit_bound=lb)
+                torch.cuda.synchronize()
+                tag = (it, L, H, B, kv, gaps, variant, lb)
+                assert torch.isfinite(o.float()).all(), tag
+                ob = o.reshape(B, L, H, 128)
+                assert float(ob[~live].float().abs().sum()) == 0.0, tag
+                for b in range(B):
+                    got = ob[b][:, heads].float()
+                    err = ((got - refs[b]).norm() / refs[b].norm()).item()
+                    assert err < 1e-2, tag + (b, err)
+                outs[(variant, lb)] = o
+            assert torch.equal(outs[(28, lb)], outs[(12, lb)]), (it, L, H, B, kv, gaps, lb)
+    scr = hip.attention_scratch(torch.device(DEV))
+    nflag = (n_cu * 16 + 255) // 256 * 256
+    assert int(scr[-nflag:].to(torch.int32).sum()) == 0
+
+
 @pytest.mark.parametrize("variant", [0, 3, 8, 12])
 @pytest.mark.parametrize("L,lo,hi,kv", [(320, 0, 128, 320), (320, 0, 100, 300), (200, 0, 64, 200), (512, 0, 192, 470), (96, 0, 64, 96)])
 def test_attention_leading_keys_masked(hip, variant, L, lo, hi, kv):

@@ -325,6 +325,9 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const Attn64Args a) {
     // M0 values - and their spills - cost more than one s_add each)
     // (VC_WL_PIN re-derives the base from one SGPR per use; the bounded tile, whose pieces sit in both phases, hits
     // "illegal VGPR to SGPR copy" in hipcc's backend with the pin and compiles to the same per-use s_add without it)
+// (vector-register pins: with the per-wave `dead` branch around the tile bodies hipcc keeps these wave-uniform values in
+// VECTOR registers - "illegal VGPR to SGPR copy" for a scalar pin; the DMA statements take lane offsets anyway)
+#define VC_STREAM_PIN(a_, b_, c_) asm volatile("" : "+s"(a_), "+s"(b_), "+s"(c_))
 #define VC_WL_PIN do { if constexpr (!BOUNDED) asm volatile("" : "+s"(wave_lds)); } while (0)
     int wave_lds = wave * 1024;
     auto dma_k = [&](auto SLOT, int n, int i) {
@@ -865,7 +868,7 @@ __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
   VC_SEG(n_);
   bool have_next = false;
   // fetch the next work item into the n_ set; false when the workgroup has none left
-  auto next_seg = [&]() -> bool {
+  auto next_seg = [&]() __attribute__((always_inline)) -> bool {
     int id, kt0 = 0, kt1 = -1, piece = -1;
     // a.inmerge: the workgroup's share of the tail comes FIRST, so that its pieces have long been published when the
     // workgroups that combine them (at the very end of their own work) ask for them
@@ -913,7 +916,7 @@ __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
   // n in [kt1, pad1): an empty step, nothing to fetch (the item's last tile is fetched again: never read); n >= pad1: tile
   // n - pad1 of the NEXT item, if one is known.
   int pad1 = 0;          // c_kt0 + 3 * ceil((c_kt1 - c_kt0) / 3), set per item
-  auto src_tile = [&](int n, bool& fwd) -> int {
+  auto src_tile = [&](int n, bool& fwd) __attribute__((always_inline)) -> int {
     fwd = n >= pad1 && have_next;
     return fwd ? min(n_kt0 + (n - pad1), n_kt1 - 1) : min(n, c_kt1 - 1);
   };
@@ -921,32 +924,32 @@ __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
   const char* const v_base = (const char*)a.vt;
   // scalar part of a tile's source offsets (computed ONCE per tile, at its head: the ~15 scalar instructions of the look-ahead
   // mapping stay out of the MFMA gaps), then one piece = one v_add (+ v_min for K) and the asm statement
-  auto k_src = [&](int n, uint32_t& bound) -> uint32_t {
+  auto k_src = [&](int n, uint32_t& bound) __attribute__((always_inline)) -> uint32_t {
     bool fwd;
     const int kt = src_tile(n, fwd);
     const uint32_t so = fwd ? n_ko : c_ko;
     bound = k_bound + so;
     return (uint32_t)kt * k_step + so;
   };
-  auto v_src = [&](int n) -> uint32_t {
+  auto v_src = [&](int n) __attribute__((always_inline)) -> uint32_t {
     bool fwd;
     const int kt = src_tile(n, fwd);
     return (fwd ? n_vo : c_vo) + (uint32_t)kt * (KVB * 2);
   };
-  auto dma_k_at = [&](auto SLOT, uint32_t sc, uint32_t bound, int i) {
+  auto dma_k_at = [&](auto SLOT, uint32_t sc, uint32_t bound, int i) __attribute__((always_inline)) {
 #ifndef VC_A64_NO_DMA      // analysis builds only (wrong results): the loop without one of its ingredients
     glds16_m0(k_base, min(k_off0 + (sc + (uint32_t)i * k_piece), bound), wave_lds, decltype(SLOT)::value * K_TILE + i * 4096);
 #endif
   };
-  auto dma_v_at = [&](auto SLOT, uint32_t sc, int i) {
+  auto dma_v_at = [&](auto SLOT, uint32_t sc, int i) __attribute__((always_inline)) {
 #ifndef VC_A64_NO_DMA
     glds16_m0(v_base, v_off0 + (sc + (uint32_t)i * v_piece), wave_lds, V_RING0 + decltype(SLOT)::value * V_TILE + i * 4096);
 #endif
   };
-  auto dma_k = [&](auto SLOT, int n, int i) { uint32_t bd; const uint32_t sc = k_src(n, bd); dma_k_at(SLOT, sc, bd, i); };
-  auto dma_v = [&](auto SLOT, int n, int i) { dma_v_at(SLOT, v_src(n), i); };
+  auto dma_k = [&](auto SLOT, int n, int i) __attribute__((always_inline)) { uint32_t bd; const uint32_t sc = k_src(n, bd); dma_k_at(SLOT, sc, bd, i); };
+  auto dma_v = [&](auto SLOT, int n, int i) __attribute__((always_inline)) { dma_v_at(SLOT, v_src(n), i); };
   // the 16 query fragments of item g -> a[128:191] (waited for with vmcnt by the caller)
-  auto load_queries = [&](int g_id) {
+  auto load_queries = [&](int g_id) __attribute__((always_inline)) {
     const int qb_i = g_id % a.qblocks;
     const int bh = g_id / a.qblocks;
     const int h = bh % a.H, b = bh / a.H;
@@ -973,12 +976,23 @@ __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
   float l_acc[2] = {0.f, 0.f}, l_e[2] = {0.f, 0.f};
   float pe0[32], pe1[32];
   int pub = -1;                       // a.inmerge: the piece whose flags are still to be set
+  // A wave whose 64 queries all lie past row L - 1 (the last 256-query item of a sequence whose length is no multiple of 256: two
+  // of four waves at L = 3968) has no row to write.  It keeps its part in the workgroup's K / V^T stream - its LDS-DMA pieces,
+  // the counted waits, every barrier, the K'(0) fragment reads that belong to the NEXT item - and skips the item's MFMAs,
+  // exponentials and fragment reads: 3 % of the launch's arithmetic at cfg 2, on a board that runs at its power cap.
+  bool dead = false;
+#ifdef VC_A64_NO_DEAD_WAVES      // A/B builds: every wave computes its padded rows (rounds 2-6)
+#define VC_DEAD_OF(id) false
+#else
+#define VC_DEAD_OF(id) (BOUNDED && __builtin_amdgcn_readfirstlane((int)(((id) % a.qblocks) * QB + wave * QW >= L)) != 0)   /* (the running-max
+     template has no registers left for the second item skeleton: 44 accumulator spills) */
+#endif
 
-  auto read_k = [&](auto SLOT, auto UT) {
+  auto read_k = [&](auto SLOT, auto UT) __attribute__((always_inline)) {
     constexpr int ut = decltype(UT)::value, u = ut >> 3, t = ut & 7;
     lds_k<A_K + ut * 4, decltype(SLOT)::value * K_TILE + u * 8192>(k_rd[t]);
   };
-  auto make_kaug = [&](int n, int u) -> u32x4 {
+  auto make_kaug = [&](int n, int u) __attribute__((always_inline)) -> u32x4 {
     const int key = n * KVB + u * 32 + krow;
     const uint32_t m = (key >= c_kvlen || (key >= c_gap_lo && key < c_gap_hi)) ? (0x3f800000u & aug_on) : 0u;
     return u32x4{kaug_one | m, 0u, 0u, 0u};
@@ -986,12 +1000,12 @@ __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
   // the 9th k-step of an S chain over a tile with masked keys: S^T += k_aug . q_aug = -29952 on the masked keys (reference
   // point 0: bounded logits).  Cold path - both fragments are built here, with the wait states between a VALU write and an
   // MFMA read that hipcc inserts for its own instructions and an asm statement has to bring along
-  auto masked_step = [&](f32x16& Sx, int n, int u) {
+  auto masked_step = [&](f32x16& Sx, int n, int u) __attribute__((always_inline)) {
     u32x4 ka = make_kaug(n, u);
     u32x4 qa = {qaug_mask, 0u, 0u, 0u};
     asm volatile("s_nop 7\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(Sx) : "v"(ka), "v"(qa));
   };
-  auto tile_masked = [&](int n) { return n * KVB + KVB > c_kvlen || (n * KVB < c_gap_hi && n * KVB + KVB > c_gap_lo); };
+  auto tile_masked = [&](int n) __attribute__((always_inline)) { return n * KVB + KVB > c_kvlen || (n * KVB < c_gap_hi && n * KVB + KVB > c_gap_lo); };
 
   // ---- running-max form (BOUNDED = false: weights whose QK-norm scales do not bound the logits): the row max m of a tile is
   // subtracted BY THE MATRIX PIPE (9th k-step: q_aug = (-m, -29952), k_aug = (1, key masked)), m moves only when a row of the
@@ -1002,25 +1016,25 @@ __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
   u32x4 qaug_r0 = {qaug_mask, 0u, 0u, 0u}, qaug_r1 = {qaug_mask, 0u, 0u, 0u};
   int resc = 0;
   float mxp0 = 0.f, mxp1 = 0.f, mxp2 = 0.f, mxp3 = 0.f, mq0 = 0.f, mq1 = 0.f;
-  auto max_step = [&](f32x16& Sx, float& mx, auto Jc) {     // 8 steps per chain: 16 values -> one
+  auto max_step = [&](f32x16& Sx, float& mx, auto Jc) __attribute__((always_inline)) {     // 8 steps per chain: 16 values -> one
     constexpr int j = decltype(Jc)::value;
     if constexpr (j == 0) mx = v_max3(Sx[0], Sx[1], Sx[2]);
     else if constexpr (j < 7) mx = v_max3(mx, Sx[2 * j + 1], Sx[2 * j + 2]);
     else mx = v_max(mx, Sx[15]);
   };
-  auto max_steps = [&](auto B0, auto Jc) {                  // step j of all four chains of the S tile whose first block is B0
+  auto max_steps = [&](auto B0, auto Jc) __attribute__((always_inline)) {                  // step j of all four chains of the S tile whose first block is B0
     constexpr int b0 = decltype(B0)::value;
     max_step(SBk[(b0 + 0) % 6], mxp0, Jc);
     max_step(SBk[(b0 + 1) % 6], mxp1, Jc);
     max_step(SBk[(b0 + 2) % 6], mxp2, Jc);
     max_step(SBk[(b0 + 3) % 6], mxp3, Jc);
   };
-  auto decide0 = [&]() {
+  auto decide0 = [&]() __attribute__((always_inline)) {
     mq0 = v_max(mxp0, mxp1);
     mq1 = v_max(mxp2, mxp3);
   };
-  auto decide1 = [&](auto QBc) { if constexpr (decltype(QBc)::value == 0) mq0 = xmax32(mq0); else mq1 = xmax32(mq1); };
-  auto new_max = [&](float mq, float& m_run, float& alpha, u32x4& qa, f32x16& S0, f32x16& S1, bool first) {
+  auto decide1 = [&](auto QBc) __attribute__((always_inline)) { if constexpr (decltype(QBc)::value == 0) mq0 = xmax32(mq0); else mq1 = xmax32(mq1); };
+  auto new_max = [&](float mq, float& m_run, float& alpha, u32x4& qa, f32x16& S0, f32x16& S1, bool first) __attribute__((always_inline)) {
     const float want = first ? mq : m_run + fmaxf(mq, 0.f);
     const bf16_t nb = f2bf(-want);
     const float m_new = -bf2f(nb);
@@ -1031,7 +1045,7 @@ __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { S0[r] -= delta; S1[r] -= delta; }
   };
-  auto decide2 = [&](auto B0, bool first) {       // B0: index of the first block of the tile's S in SBk
+  auto decide2 = [&](auto B0, bool first) __attribute__((always_inline)) {       // B0: index of the first block of the tile's S in SBk
     constexpr int b0 = decltype(B0)::value;
     resc = (first || !__all((mq0 <= 8.0f) && (mq1 <= 8.0f))) ? 1 : 0;
     if (resc) {
@@ -1054,7 +1068,7 @@ __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
   };
   // one tile of the running-max form (attn64_kernel<false>'s tile_r: 36 + 32 MFMAs, every phase-A gap takes a pair, the row
   // max of S(kt+1) fills the P.V phase); LAST / RK as tile_s below
-  auto tile_rs = [&](auto Jc, auto LASTc, int kt) {
+  auto tile_rs = [&](auto Jc, auto LASTc, int kt) __attribute__((always_inline)) {
     constexpr int J = decltype(Jc)::value;
     constexpr bool LAST = decltype(LASTc)::value, RK = !LAST || J == 1;
     constexpr int BASE = (4 * J) % 6;
@@ -1065,7 +1079,7 @@ __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
     const u32x4 ka0 = make_kaug(kt + 1, 0), ka1 = make_kaug(kt + 1, 1);
     uint32_t k_bd;
     uint32_t k_sc = k_src(kt + 4, k_bd), v_sc = v_src(kt + 2);
-    asm volatile("" : "+s"(k_sc), "+s"(v_sc), "+s"(k_bd));
+    VC_STREAM_PIN(k_sc, v_sc, k_bd);
     SB();
     float pe0r = 0.f, pe1r = 0.f;
     sfor<0, 36>([&](auto Gp) {
@@ -1122,7 +1136,7 @@ __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
   // ---- one filler token of the generated schedule (attention64_sched.h); LAST: the item's last tile, which has no S(t+1) -
   // no exponentials of it, no K fragments of the tile after it (the K registers keep K'(0) of the next item), and its counted
   // waits, sized for the full read stream, become lgkmcnt(0) ----
-  auto run_tok = [&](auto PH, auto TI, auto LASTc, auto RKc, auto SBASE, auto SLOT_V, auto SLOT_K2, auto SLOT_K4, uint32_t v_sc, uint32_t k_sc, uint32_t k_bd) {
+  auto run_tok = [&](auto PH, auto TI, auto LASTc, auto RKc, auto SBASE, auto SLOT_V, auto SLOT_K2, auto SLOT_K4, uint32_t v_sc, uint32_t k_sc, uint32_t k_bd) __attribute__((always_inline)) {
     constexpr a64s::Tok t = tok_at<decltype(PH)::value, decltype(TI)::value>();
     constexpr bool LAST = decltype(LASTc)::value, PB = decltype(PH)::value == 1, RK = decltype(RKc)::value;
     constexpr int k = t.a, pq = k >> 4, idx = k & 15, pu = idx >> 3, r0 = (idx & 7) * 2;
@@ -1161,7 +1175,7 @@ __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
   // LAST: the item's last tile - no S(t+1), no exponentials of it.  The K registers must hold K'(0) of the next item when its
   // first step runs: the step TWO positions before it reads them (a regular tile's K(t+2) read; with one empty step after the
   // last tile that is the last tile itself: J = 1), the step in between reads none.
-  auto tile_s = [&](auto Jc, auto LASTc, int kt) {
+  auto tile_s = [&](auto Jc, auto LASTc, int kt) __attribute__((always_inline)) {
     constexpr int J = decltype(Jc)::value;
     constexpr bool LAST = decltype(LASTc)::value;
     using RKc = std::integral_constant<bool, !LAST || J == 1>;
@@ -1178,7 +1192,7 @@ __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
     const bool msk = !LAST && tile_masked(kt + 1);
     uint32_t k_bd;
     uint32_t k_sc = k_src(kt + 4, k_bd), v_sc = v_src(kt + 2);           // the stream's look-ahead: V^T(kt+2), K(kt+4)
-    asm volatile("" : "+s"(k_sc), "+s"(v_sc), "+s"(k_bd));                // (materialised HERE, not sunk into the gap of their first use)
+    VC_STREAM_PIN(k_sc, v_sc, k_bd);                                      // (materialised HERE, not sunk into the gap of their first use)
     SB();
     sfor<0, 32>([&](auto Gp) {
       constexpr int g = decltype(Gp)::value, c = g >> 3, t = g & 7;
@@ -1208,13 +1222,36 @@ __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
 #endif
     SB();
   };
-  auto tile_any = [&](auto Jc, auto LASTc, int kt) {
+  // a dead wave's step: the wave's share of the stream's LDS-DMA (same pieces, same order as the tokens of a live tile), the K'(0)
+  // fragments where a live step reads them (stream tile kt + 2 = the next item's first tile), the step's waits and its barrier
+  auto dead_tile = [&](auto Jc, auto LASTc, int kt) __attribute__((always_inline)) {
+    constexpr int J = decltype(Jc)::value;
+    constexpr bool LAST = decltype(LASTc)::value;
+    using SLOT_K2 = std::integral_constant<int, (J + 2) % 3>;
+    using SLOT_K4 = std::integral_constant<int, (J + 1) % 3>;
+    uint32_t k_bd;
+    const uint32_t k_sc = k_src(kt + 4, k_bd), v_sc = v_src(kt + 2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_v_at(SLOT_K2{}, v_sc, i);
+    if (kt + 2 == pad1) sfor<0, 16>([&](auto UT) { read_k(SLOT_K2{}, UT); });      // the step two positions before the next item's first one
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_k_at(SLOT_K4{}, k_sc, k_bd, i);
+#ifndef VC_A64_NO_DMA
+    wait_vm<8>();
+#endif
+    wait_lgkm<0>();
+#ifndef VC_A64_NO_BARRIER
+    __builtin_amdgcn_s_barrier();
+#endif
+    SB();
+  };
+  auto tile_any = [&](auto Jc, auto LASTc, int kt) __attribute__((always_inline)) {
     if constexpr (BOUNDED) tile_s(Jc, LASTc, kt);
     else tile_rs(Jc, LASTc, kt);
   };
   // ---- an EMPTY step of rotation J at stream position n (between an item's last tile and the rotation boundary): only the
   // stream's LDS-DMA (V^T(n+2), K(n+4): the next item's first tiles) and the step's waits; READ_K: the K'(0) fragments ----
-  auto empty_s = [&](auto Jc, auto RKc, int n) {
+  auto empty_s = [&](auto Jc, auto RKc, int n) __attribute__((always_inline)) {
     constexpr int J = decltype(Jc)::value;
     using SLOT_K2 = std::integral_constant<int, (J + 2) % 3>;
     using SLOT_K4 = std::integral_constant<int, (J + 1) % 3>;
@@ -1231,7 +1268,7 @@ __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
   // ---- the first step of an item (always rotation J = 0): S(kt0) = K(kt0) . Q^T from the K fragments in a[192:255], O
   // cleared in the MFMA gaps; then the K fragments of the item's second tile (ring slot 1) and the pairs that the P.V phase
   // of a previous tile would have exponentiated ----
-  auto first_s = [&](bool hard_start) {
+  auto first_s = [&](bool hard_start) __attribute__((always_inline)) {
     const bool msk0 = tile_masked(c_kt0);
     SB();
     sfor<0, 32>([&](auto Gp) {
@@ -1275,7 +1312,7 @@ __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
     SB();
   };
   // ---- O of cur -> out (or the partial of a tail piece); no wait: the stores drain behind the next tiles ----
-  auto store_out = [&]() {
+  auto store_out = [&]() __attribute__((always_inline)) {
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");               // the last P.V MFMAs retired before a[0:127] is read
     const int qb_i = c_id % a.qblocks;
     const int bh = c_id / a.qblocks;
@@ -1330,7 +1367,7 @@ __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
   // ---- a.inmerge: a piece is PUBLISHED (flag = 1 for both query blocks) once its stores are complete in every wave: not by
   // draining the LDS-DMA stream behind store_out, but one item later - every step in between ended with a counted vmcnt
   // that covers the (older) stores and a barrier ----
-  auto publish = [&](int piece) {
+  auto publish = [&](int piece) __attribute__((always_inline)) {
     if (tid == 0) {
       __hip_atomic_store(a.flags + piece * 2 + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(a.flags + piece * 2 + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1345,6 +1382,7 @@ __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
   bool hard = true;
   for (;;) {
     pad1 = c_kt0 + (c_kt1 - c_kt0 + 2) / 3 * 3;
+    dead = VC_DEAD_OF(c_id);
 #ifdef VC_ATTN_TIMESTAMPS
     ts_tiles += c_kt1 - c_kt0;
     if (a.debug_ts && tid == 0 && ts_seg < 3) a.debug_ts[blockIdx.x * 32 + 8 + ts_seg * 8 + 5] = c_kt1 - c_kt0;
@@ -1357,7 +1395,7 @@ __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
       const int kt0 = c_kt0;
 #pragma unroll
       for (int i = 0; i < 4; ++i) dma_k(I0{}, kt0, i);
-      load_queries(c_id);
+      if (!dead) load_queries(c_id);
 #pragma unroll
       for (int i = 0; i < 4; ++i) dma_k(I1{}, kt0 + 1, i);
 #pragma unroll
@@ -1377,11 +1415,46 @@ __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
       SB();
     }
     TS_S(1);
+    const bool soft = have_next && (c_kt1 - c_kt0) >= 4;     // the look-ahead of a shorter item was issued before its successor was known
+    const int kt_last = c_kt1 - 1;
+    int kt = c_kt0, exit_j;
+    if (__builtin_expect(dead, 0)) {
+      // ---- the item of a DEAD wave: the skeleton of the live item below - every barrier, every wait, the wave's LDS-DMA, the
+      // next item's query and K'(0) fragments - without its arithmetic ----
+      if (hard) {
+        wait_vm<16>();
+        __builtin_amdgcn_s_barrier();
+        wait_vm<8>();
+      }
+      wait_lgkm<0>();
+      __builtin_amdgcn_s_barrier();
+      SB();
+      TS_S(2);
+      for (;;) {
+        if (kt >= kt_last) { exit_j = 0; break; }
+        dead_tile(I0{}, std::false_type{}, kt); ++kt;
+        if (kt >= kt_last) { exit_j = 1; break; }
+        dead_tile(I1{}, std::false_type{}, kt); ++kt;
+        if (kt >= kt_last) { exit_j = 2; break; }
+        dead_tile(I2{}, std::false_type{}, kt); ++kt;
+      }
+      if (soft && !VC_DEAD_OF(n_id)) load_queries(n_id);
+      if (exit_j == 0) {
+        dead_tile(I0{}, std::true_type{}, kt);
+        if (soft) { empty_s(I1{}, std::true_type{}, kt + 1); empty_s(I2{}, std::false_type{}, kt + 2); }
+      } else if (exit_j == 1) {
+        dead_tile(I1{}, std::true_type{}, kt);
+        if (soft) empty_s(I2{}, std::false_type{}, kt + 1);
+      } else {
+        dead_tile(I2{}, std::true_type{}, kt);
+      }
+      TS_S(3);
+      if (pub >= 0) { publish(pub); pub = -1; }
+      if (c_piece >= 0) pub = c_piece;           // (no row of this wave exists; `pub` stays uniform across the workgroup)
+    } else {
     first_s(hard);
     TS_S(2);
     // ---- the item's tiles but the last: a single-entry loop over the three rotations ----
-    int kt = c_kt0, exit_j;
-    const int kt_last = c_kt1 - 1;
     for (;;) {
       if (kt >= kt_last) { exit_j = 0; break; }
       tile_any(I0{}, std::false_type{}, kt); ++kt;
@@ -1391,8 +1464,7 @@ __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
       tile_any(I2{}, std::false_type{}, kt); ++kt;
     }
     // ---- the last tile (P.V only), the empty steps up to the rotation boundary, O out ----
-    const bool soft = have_next && (c_kt1 - c_kt0) >= 4;     // the look-ahead of a shorter item was issued before its successor was known
-    if (soft) load_queries(n_id);            // the Q registers are idle: the last tile computes no S(t+1)
+    if (soft && !VC_DEAD_OF(n_id)) load_queries(n_id);            // the Q registers are idle: the last tile computes no S(t+1)
     if (exit_j == 0) {
       tile_any(I0{}, std::true_type{}, kt);
       if (soft) { empty_s(I1{}, std::true_type{}, kt + 1); empty_s(I2{}, std::false_type{}, kt + 2); }
@@ -1405,6 +1477,7 @@ __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
     TS_S(3);
     if (pub >= 0) { publish(pub); pub = -1; }
     store_out();
+    }
     TS_S(4);
 #ifdef VC_ATTN_TIMESTAMPS
     ++ts_seg;
@@ -1436,7 +1509,7 @@ __global__ __launch_bounds__(256, 1) void attn64s_kernel(const Attn64Args a) {
       while (c > 0 && chunk_begin64(c, sc.units, sc.W) > u0) --c;
       while (c + 1 < sc.W && chunk_begin64(c + 1, sc.units, sc.W) <= u0) ++c;
       if (chunk_begin64(c + 1, sc.units, sc.W) >= u1) continue;      // the whole item ran inside one chunk: already written
-      auto next_chunk = [&](int cc) {
+      auto next_chunk = [&](int cc) __attribute__((always_inline)) {
         while (cc < sc.W && chunk_begin64(cc, sc.units, sc.W) < u1 && chunk_begin64(cc + 1, sc.units, sc.W) == chunk_begin64(cc, sc.units, sc.W)) ++cc;
         return (cc < sc.W && chunk_begin64(cc, sc.units, sc.W) < u1) ? cc : -1;
       };
@@ -1535,11 +1608,11 @@ __global__ __launch_bounds__(256) void attn64_merge_kernel(const Attn64Args a, i
   const long ml_off = PART64_O_BYTES + ((wave * 2 + qb) * 64 + lane) * 8;
   const long o_off = ((long)(wave * 2 + qb) * 16 * 64 + lane) * 8;
   // chunk cc holds units of this item iff it is not empty (fewer units than blocks) and begins before u1
-  auto next_chunk = [&](int cc) {
+  auto next_chunk = [&](int cc) __attribute__((always_inline)) {
     while (cc < sc.W && chunk_begin64(cc, sc.units, sc.W) < u1 && chunk_begin64(cc + 1, sc.units, sc.W) == chunk_begin64(cc, sc.units, sc.W)) ++cc;
     return (cc < sc.W && chunk_begin64(cc, sc.units, sc.W) < u1) ? cc : -1;
   };
-  auto piece_ptr = [&](int cc) {
+  auto piece_ptr = [&](int cc) __attribute__((always_inline)) {
     const int piece = (cc * 8 + xcd) * 2 + (it - chunk_begin64(cc, sc.units, sc.W) / nkt);
     return base + (long)piece * PART64_BYTES;
   };

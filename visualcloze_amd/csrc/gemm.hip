@@ -419,6 +419,18 @@ __global__ __launch_bounds__((WM * WN + (PP == 2 ? 4 : 0)) * 64) void gemm_bf16_
       bar();
       VC_PHASE_STAMP(1);
       if (grp == 1) bar();
+      // A compute wave whose TM rows all lie past row M - 1 (the last m-tile of M = 3968 rows: two of its four wave rows) has
+      // nothing to accumulate: it keeps the K loop's barriers - four per K-tile - and skips its fragment reads and MFMAs.  Its
+      // SIMD's other waves run on; what comes back is power (the board runs at its cap), not time.  The epilogue is the same
+      // for every wave (rows >= M are never stored).
+#ifdef VC_GEMM_NO_DEAD_WAVES      // A/B builds
+      constexpr bool wdead = false;
+#else
+      const bool wdead = __builtin_amdgcn_readfirstlane((int)(m0 + wm * TM >= M)) != 0;
+#endif
+      if (wdead) {
+        for (int kt = 0; kt < nk; ++kt) { bar(); bar(); bar(); bar(); }
+      } else
 #if !defined(VC_GEMM_NO_LDSREAD) && !defined(VC_GEMM_NO_MFMA) && !defined(VC_GEMM_NO_SLOT_UNROLL)
       // The K loop unrolled over the ring period (A: 2 slots, W: 3 slots -> 6 K-tiles), so that every fragment address is ONE of
       // six lane-constant base registers + an immediate: no vector instruction at all in the MEMORY segment, which runs beside

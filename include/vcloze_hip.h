@@ -360,9 +360,11 @@ int64_t vc_flux_mod_offset(void* handle, const char* module_name);
  * 3 * hidden rows of every `linear1`, with their biases, in the row order VcGemmProblem.kn_heads describes) and, with it,
  * "fuse_knorm" (0; 1: QKNorm + RoPE of the key heads inside the qkv GEMM's epilogue - with fuse_qnorm and fuse_vt the
  * projection, the norms, RoPE and the V transpose are then ONE GEMM launch + the attention kernel: no pre-pass, no prologue);
- * "logit_bound_milli" (0; 1000 * VcAttention.logit_bound for every attention call of the model, from the bound QK-norm
- * scales: 16330 * max|query_norm.scale| * max|key_norm.scale| over all blocks, rounded up); "mlp_first", "splitk" (1: split-K /
- * stream remainders where the launcher takes them). */
+ * "logit_bound_milli" (0 = every attention launch keeps a running max; > 0: the softmax without one where the logits are bounded -
+ * the value, 16330 * max|query_norm.scale| * max|key_norm.scale| over all blocks rounded up, is a CAP: each attention launch gets
+ * the smaller of it and its OWN block's bound, which the library computes from the bound QK-norm scales when it resolves the
+ * weights (one 256-byte read-back per scale vector), so a checkpoint with outlier scales in a few blocks runs the running-max
+ * template in those blocks only); "mlp_first", "splitk" (1: split-K / stream remainders where the launcher takes them). */
 int vc_flux_set_option(void* handle, const char* name, int32_t value);
 int64_t vc_flux_workspace_bytes(void* handle, int32_t B, int32_t T, int32_t N, int32_t max_steps);
 

@@ -149,14 +149,16 @@ def test_full_width_one_plus_one_blocks_vs_oracle(small_model, geom):
     assert e32 < max(3e-2, 4 * floor)
 
 
-@pytest.mark.parametrize("qmax,kmax,bounded", [(1.5, 1.5, True), (3.0, 3.0, False)])
-def test_full_width_non_unit_norm_scales_both_sides_of_the_logit_bound(qmax, kmax, bounded):
-    """Which attention instantiation runs is a property of the WEIGHTS: the bounded-logit kernels (no running max; attn64s_kernel, the
-    stream form, with the queries finished by the qkv GEMM's epilogue) while
-    16.65 * max|query_norm.scale| * max|key_norm.scale| <= 100 (model.prepare; every other full-size test and the bench use unit
-    scales and therefore always take it), attn64_kernel<false> (running max) beyond - a real checkpoint may sit on either side.
-    One full-width evaluation (cfg 2 geometry, 1 + 1 blocks) with NON-UNIT scales on each side of the switch against the oracle
-    (layers.py:63-84; bounds as test_full_width_one_plus_one_blocks_vs_oracle)."""
+@pytest.mark.parametrize("qmax,kmax,single_max,bounded", [(1.5, 1.5, None, True), (3.0, 3.0, None, False), (1.5, 1.5, 3.0, "mixed")])
+def test_full_width_non_unit_norm_scales_both_sides_of_the_logit_bound(qmax, kmax, single_max, bounded):
+    """Which attention instantiation runs is a property of the WEIGHTS, block by block: the bounded-logit kernels (no running max;
+    attn64s_kernel<true>, the stream form, with the queries finished by the qkv GEMM's epilogue) while
+    16.65 * max|query_norm.scale| * max|key_norm.scale| of the BLOCK is <= 100 (model.prepare / flux_engine.hip resolve(); every
+    other full-size test and the bench use unit scales and therefore always take it), the running-max template beyond - a real
+    checkpoint may sit on either side, or on both: "mixed" gives the double block scales up to 1.5 and the single block scales up
+    to 3, so ONE evaluation runs both templates (the C handle and the Python-ordered plan must pick the same ones: bit-equal).
+    One full-width evaluation (cfg 2 geometry, 1 + 1 blocks) with NON-UNIT scales against the oracle (layers.py:63-84; bounds as
+    test_full_width_one_plus_one_blocks_vs_oracle)."""
     import oracle.flux_oracle as O
     from tests.helpers import parity_log
     m = _build(1, 1, seed=7)
@@ -165,6 +167,8 @@ def test_full_width_non_unit_norm_scales_both_sides_of_the_logit_bound(qmax, kma
         for name, p in m.named_parameters():
             if name.endswith("norm.scale"):
                 hi = qmax if "query_norm" in name else kmax
+                if single_max is not None and name.startswith("single_blocks."):
+                    hi = single_max
                 p.copy_(0.5 + (hi - 0.5) * torch.rand(p.shape, device=DEV, generator=g).to(p.dtype))
                 p[0] = hi
     sd = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
@@ -172,11 +176,23 @@ def test_full_width_non_unit_norm_scales_both_sides_of_the_logit_bound(qmax, kma
     t = torch.tensor([0.62])
     got = _call(m, inp, t)
     eng = m.engine()
-    assert (0.0 < eng.W.logit_bound <= 100.0) == bounded, eng.W.logit_bound
+    bd, bs = eng.W.logit_bounds["double_blocks.0"], eng.W.logit_bounds["single_blocks.0"]
+    assert eng.W.logit_bound == max(bd, bs)
+    if bounded == "mixed":
+        assert 0.0 < bd <= 100.0 < bs, (bd, bs)
+        m.use_handle = False                       # the Python-ordered plan picks its templates from model.prepare's per-block bounds,
+        try:                                       # the C handle from its own read-back of the bound scales: the same bits
+            twin = _call(m, inp, t)
+        finally:
+            m.use_handle = True
+        assert torch.equal(twin, got)
+    else:
+        assert (0.0 < eng.W.logit_bound <= 100.0) == bounded, eng.W.logit_bound
     assert eng.attention_variant(eng.workspace(T, inp["x"].shape[1], 1, 1)) == 28      # 12 + 16: tail pieces combined in the launch where the stream form runs
     want_bf16, want_fp32 = _oracle_pair(sd, O.FluxGeometry(depth=1, depth_single_blocks=1), inp, t)
     floor, e16, e32 = rel_l2(want_bf16, want_fp32), rel_l2(got, want_bf16), rel_l2(got, want_fp32)
-    parity_log(f"[1+1 blocks, cfg2, norm scales up to {qmax} / {kmax}: logit bound {eng.W.logit_bound:.1f} -> attn64_kernel<{str(bounded).lower()}>] "
+    parity_log(f"[1+1 blocks, cfg2, norm scales up to {qmax} / {kmax}" + (f" (single block {single_max})" if single_max else "") +
+               f": logit bounds {bd:.1f} / {bs:.1f} -> attn64s_kernel<{str(bd <= 100).lower()}> / <{str(bs <= 100).lower()}>] "
                f"HIP vs bf16 oracle {e16:.3e}, vs fp32 oracle {e32:.3e}, oracle bf16-vs-fp32 floor {floor:.3e}")
     assert e16 < 1.5e-2 and e32 < max(3e-2, 4 * floor)
     del m

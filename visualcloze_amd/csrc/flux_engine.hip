@@ -28,8 +28,9 @@ struct Lin {
   int64_t ldw = 0;
 };
 
-struct DoubleW { Lin qkv[2], proj[2], mlp0[2], mlp2[2]; const void* qs[2]; const void* ks[2]; int64_t mod[2]; };  // [0] = img, [1] = txt
-struct SingleW { Lin qkv, mlp, lin2; const void* qs; const void* ks; int64_t mod; };
+// bound: the block's own logit bound, 1.02 sqrt(128) log2(e) max|query_norm.scale| max|key_norm.scale| (both streams of a double block)
+struct DoubleW { Lin qkv[2], proj[2], mlp0[2], mlp2[2]; const void* qs[2]; const void* ks[2]; int64_t mod[2]; float bound; };  // [0] = img, [1] = txt
+struct SingleW { Lin qkv, mlp, lin2; const void* qs; const void* ks; int64_t mod; float bound; };
 
 struct Err {
   char* buf; int len;
@@ -180,6 +181,27 @@ void layout_modulation(Flux& f) {
   f.n_mod = o;
 }
 
+// max |scale| of a bound QK-norm scale vector (128 bf16 on the device): read back ONCE, when the weights are resolved
+int scale_absmax(const void* dev, double& out, Err e) {
+  uint16_t h[128];
+  HIP(hipMemcpy(h, dev, sizeof(h), hipMemcpyDeviceToHost), "hipMemcpy (QK-norm scale)");
+  out = 0;
+  bool nan = false;
+  for (int i = 0; i < 128; ++i) {
+    uint32_t u = (uint32_t)h[i] << 16;
+    float v;
+    memcpy(&v, &u, 4);
+    const double a = v < 0 ? -(double)v : (double)v;
+    if (a != a) nan = true;
+    else if (a > out) out = a;
+  }
+  if (nan) out = 1e30;                 // (no bound: the running-max template)
+  return VC_OK;
+}
+// |q|, |k| <= sqrt(128) max|scale| after QKNorm (RoPE is a rotation), so |128^-0.5 log2(e) q.k| <= this; + 2 % for the six bf16
+// roundings on the way (model.py / engine.py compute the same number for the Python-ordered plan)
+inline float logit_bound_of(double qmax, double kmax) { return (float)(1.02 * 11.313708498984761 * 1.4426950408889634 * qmax * kmax); }
+
 int resolve(Flux& f, Err e) {
   if (f.resolved) return VC_OK;
   const int D = f.D, mlp = f.mlp;
@@ -209,6 +231,9 @@ int resolve(Flux& f, Err e) {
       TRY(find_scale(f, a + "norm.key_norm.scale", f.dbl[i].ks[k], e));
       f.dbl[i].mod[k] = f.mod_off[pf + st[k] + "_mod.lin"];
     }
+    double q[2], k2[2];
+    for (int k = 0; k < 2; ++k) { TRY(scale_absmax(f.dbl[i].qs[k], q[k], e)); TRY(scale_absmax(f.dbl[i].ks[k], k2[k], e)); }
+    f.dbl[i].bound = logit_bound_of(q[0] > q[1] ? q[0] : q[1], k2[0] > k2[1] ? k2[0] : k2[1]);
   }
   f.sgl.assign(f.cfg.depth_single_blocks, SingleW{});
   for (int i = 0; i < f.cfg.depth_single_blocks; ++i) {
@@ -224,6 +249,9 @@ int resolve(Flux& f, Err e) {
     TRY(find_scale(f, pf + "norm.query_norm.scale", w.qs, e));
     TRY(find_scale(f, pf + "norm.key_norm.scale", w.ks, e));
     w.mod = f.mod_off[pf + "modulation.lin"];
+    double q, k;
+    TRY(scale_absmax(w.qs, q, e)); TRY(scale_absmax(w.ks, k, e));
+    w.bound = logit_bound_of(q, k);
   }
   f.final_mod = f.mod_off["final_layer.adaLN_modulation.1"];
   f.resolved = true;
@@ -327,7 +355,7 @@ int attention_variant(const Flux& f) {
 }
 
 // QKNorm + RoPE (+ V^T) and the joint attention over QKV -> CAT[:, :D] (layers.py:165-185 / 236-241)
-int attention(Flux& f, const Ctx& c, const void* q1, const void* k1, const void* q2, const void* k2, int split, Err e) {
+int attention(Flux& f, const Ctx& c, const void* q1, const void* k1, const void* q2, const void* k2, int split, float block_bound, Err e) {
   const int variant = attention_variant(f);
   const bool fused_q = (variant & 8) && f.fuse_qnorm, q_done = qn_in_gemm(f);     // q_done: by the projection's epilogue, prescaled
   const int64_t ld = 3 * f.D, ldo = f.D + f.mlp;
@@ -345,7 +373,11 @@ int attention(Flux& f, const Ctx& c, const void* q1, const void* k1, const void*
   a.scratch = f.ATT_SCRATCH; a.scratch_bytes = f.att_scratch_bytes;
   if (q_done) a.q_prescaled = 1;
   else if (fused_q) { a.q_scale = q1; a.q_scale2 = q2; a.split = split; a.rope = f.ROPE; a.rope_bstride = (int64_t)f.L * 128; }
-  a.logit_bound = (float)f.logit_bound_milli * 1e-3f;
+  // option logit_bound_milli > 0 switches the bounded softmax on; every block is then held to ITS OWN bound (never above the
+  // caller's): a checkpoint with a few outlier QK-norm scales runs the running-max template in those blocks only
+  const float cap = (float)f.logit_bound_milli * 1e-3f;
+  a.logit_bound = f.logit_bound_milli > 0 ? (block_bound < cap ? block_bound : cap) : 0.0f;
+  if (f.logit_bound_milli > 0 && !(block_bound < 1e30f)) a.logit_bound = 1e30f;       // (non-finite scales: no bound)
   TRY(prof_open(f, c.s, VC_LAUNCH_ATTENTION, variant, 0, 0, 4.0 * f.L * f.L * f.D * f.B, 0, e));     // the attention launch(es) alone
   TRY(vc_attention_launch(a, c.s, e.buf, e.len));
   return prof_close(f, c.s, e);
@@ -367,7 +399,7 @@ int double_block(Flux& f, const Ctx& c, const DoubleW& w, Err e) {
     with_vt(f, p[0], N, T, w.qs[0], w.ks[0]); with_vt(f, p[1], T, 0, w.qs[1], w.ks[1]);
     TRY(gemm(f, p, 2, qkv_epi(f), nullptr, 0, c.s, e));
   }
-  TRY(attention(f, c, w.qs[1], w.ks[1], w.qs[0], w.ks[0], T, e));   // rows < T: the text stream's scales
+  TRY(attention(f, c, w.qs[1], w.ks[1], w.qs[0], w.ks[0], T, w.bound, e));   // rows < T: the text stream's scales
   {  // x += gate * proj(attn): A rows are batch-strided views of CAT[:, :D]
     VcGemmProblem p[2] = {prob(f.CAT + (int64_t)T * ldc, ldc, w.proj[0], f.XI, D, B * N), prob(f.CAT, ldc, w.proj[1], f.XT, D, B * T)};
     for (int k = 0; k < 2; ++k) {
@@ -404,7 +436,7 @@ int single_block(Flux& f, const Ctx& c, const SingleW& w, Err e) {
   // the attention kernel runs right behind the projection that wrote its operands, and the MLP-up GEMM right in front of the
   // linear2 that reads its 97 MB (option mlp_first = the reference's textual order, layers.py:236-243)
   if (f.mlp_first) TRY(lin(f, w.mlp, f.XH, D, f.CAT + D, ldc, M, VC_EPI_GELU, c.s, e));
-  TRY(attention(f, c, w.qs, w.ks, nullptr, nullptr, 0, e));
+  TRY(attention(f, c, w.qs, w.ks, nullptr, nullptr, 0, w.bound, e));
   if (!f.mlp_first) TRY(lin(f, w.mlp, f.XH, D, f.CAT + D, ldc, M, VC_EPI_GELU, c.s, e));
   VcGemmProblem p = prob(f.CAT, ldc, w.lin2, f.X, D, M);
   p.res = f.X; p.ldres = D; p.gate = modp(f, w.mod, 2); p.gate_bstride = f.n_mod; p.rows_per_batch = f.L;

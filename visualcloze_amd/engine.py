@@ -72,6 +72,7 @@ class PreparedWeights:
     ref: Optional[Dict[str, RefLinear]] = None    # lora_mode="ref": un-merged factors of every Linear (incl. the modulation ones)
     qkv_heads: int = 0           # H > 0: every qkv weight / bias (linear1's first 3D rows) is HEAD-PERMUTED (hip.qkv_head_permutation)
     logit_bound: float = 0.0     # 16.33 * max|query_norm.scale| * max|key_norm.scale| over all blocks: |q.k| 128^-0.5 log2(e) <= this
+    logit_bounds: Optional[Dict[str, float]] = None      # the same per block ("double_blocks.3", "single_blocks.17"): what each launch gets
 
 
 class Workspace:
@@ -348,7 +349,19 @@ class FluxEngine:
         items = ((ws.L + 255) // 256) * self.H * ws.B
         return 28 if items >= self.n_cu else 8 if 2 * items >= self.n_cu else 3
 
-    def _attention(self, c, scales, split):
+    def _block_bound(self, pf: str) -> float:
+        """VcAttention.logit_bound of block `pf`: its own bound, capped by the model's (csrc/flux_engine.hip attention())"""
+        if not self.bounded_softmax:
+            return 0.0
+        cap = float(self.W.logit_bound)
+        if not cap > 0:
+            return 0.0
+        b = (self.W.logit_bounds or {}).get(pf, cap)
+        if not b < 1e30:            # non-finite scales: no bound
+            return 1e30
+        return min(b, cap)
+
+    def _attention(self, c, scales, split, pf=None):
         """QKNorm + RoPE (+ V^T) and the joint attention over ws.QKV -> CAT[:, :D] (layers.py:165-185 / 236-241).  With the
         one-wave-per-SIMD kernel (variants 8 / 12) the query rows are normalised where they are loaded, inside the
         attention kernel, and the pre-pass touches only K and V."""
@@ -367,7 +380,7 @@ class FluxEngine:
             e0.record(s)
         hip.attention(ws.QKV, ws.VT, c.ATT, ws.L, self.H, kv_len=c.kvl, variant=variant, stream=s, B=ws.B,
                       scratch=self.attn_scratch, q_norm=(q1, q2, split, ws.ROPE) if fused_q and not q_done else None, kv_gap=c.kvgap,
-                      logit_bound=self.W.logit_bound if self.bounded_softmax else 0.0, q_prescaled=q_done)
+                      logit_bound=self._block_bound(pf), q_prescaled=q_done)
         if ev is not None:
             e1 = hip.Event()
             e1.record(s)
@@ -415,7 +428,7 @@ class FluxEngine:
         self._gemm([self._prob(pf + ".img_attn.qkv", c.XH_I, ws.QKV[T:], **c.qkv_i, **kv_i),
                     self._prob(pf + ".txt_attn.qkv", c.XH_T, ws.QKV[:T], **c.qkv_t, **kv_t)], epi=epi, s=s)
         self._attention(c, (Wn[pf + ".txt_attn.norm.query_norm.scale"], Wn[pf + ".txt_attn.norm.key_norm.scale"],
-                            Wn[pf + ".img_attn.norm.query_norm.scale"], Wn[pf + ".img_attn.norm.key_norm.scale"]), T)
+                            Wn[pf + ".img_attn.norm.query_norm.scale"], Wn[pf + ".img_attn.norm.key_norm.scale"]), T, pf)
         self._gated(c, (pf + ".img_attn.proj", pf + ".txt_attn.proj"), (c.ATT[T:], c.ATT[:T]), (ws.XI, ws.XT),
                     (self._mod(ws, im, 2), self._mod(ws, tm, 2)), (N, T), (c.att_i, c.att_t))
         self._ln2(c, im, tm, 3)
@@ -442,7 +455,7 @@ class FluxEngine:
         self._lin(pf + ".linear1.qkv", ws.XH, ws.QKV, epi=epi, s=s, **kv)
         if self.mlp_first:      # (the reference's textual order; the product runs the attention right behind its projection)
             self._lin(pf + ".linear1.mlp", ws.XH, ws.CAT[:, D:], epi=hip.EPI_GELU, s=s)
-        self._attention(c, (Wn[pf + ".norm.query_norm.scale"], Wn[pf + ".norm.key_norm.scale"], None, None), 0)
+        self._attention(c, (Wn[pf + ".norm.query_norm.scale"], Wn[pf + ".norm.key_norm.scale"], None, None), 0, pf)
         if not self.mlp_first:
             self._lin(pf + ".linear1.mlp", ws.XH, ws.CAT[:, D:], epi=hip.EPI_GELU, s=s)
         self._gated(c, (pf + ".linear2",), (ws.CAT,), (ws.X,), (self._mod(ws, mn, 2),), (ws.L,), ({},))

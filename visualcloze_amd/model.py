@@ -406,11 +406,21 @@ class Flux(nn.Module):
         # |q|, |k| <= sqrt(128) * max|scale| after QKNorm (layers.py:75-84; RoPE is a rotation), so with c = 128^-0.5 * log2(e)
         # every attention logit obeys |c q.k| <= 128 c max|q scale| max|k scale| (+2 %: q and k pass three bf16 roundings each - norm, scale, RoPE -
         # worth (1 + 2^-9)^6 = 1.012 on the product; the kernel only compares the bound with its <= 100 cutoff)
-        qmax = max(float(t.float().abs().max()) for n, t in w.items() if n.endswith("query_norm.scale"))
-        kmax = max(float(t.float().abs().max()) for n, t in w.items() if n.endswith("key_norm.scale"))
-        logit_bound = 1.02 * 128 ** 0.5 * 1.4426950408889634 * qmax * kmax
+        # The bound is kept per BLOCK (a double block: both streams share one attention): each launch gets its own, so outlier
+        # scales in a few blocks of a checkpoint cost the running-max template there and nowhere else; `logit_bound` = the
+        # largest of them, the cap handed to the C handle (which computes the per-block values itself: flux_engine.hip resolve()).
+        amax = {n: float(t.float().abs().max()) for n, t in w.items() if n.endswith(("query_norm.scale", "key_norm.scale"))}
+        blocks = sorted({n.split(".img_attn.")[0].split(".txt_attn.")[0].split(".norm.")[0] for n in amax})
+        c_log = 1.02 * 11.313708498984761 * 1.4426950408889634          # 1.02 sqrt(128) log2(e), the constant of flux_engine.hip
+        logit_bounds = {}
+        for pf in blocks:
+            qm = max(v for n, v in amax.items() if n.startswith(pf + ".") and n.endswith("query_norm.scale"))
+            km = max(v for n, v in amax.items() if n.startswith(pf + ".") and n.endswith("key_norm.scale"))
+            bnd = c_log * qm * km
+            logit_bounds[pf] = float(torch.tensor(bnd, dtype=torch.float32)) if bnd == bnd else 1e30      # (f32, as the C plan holds it)
+        logit_bound = max(logit_bounds.values())
         pw = PreparedWeights(w=w, b=b, mod_w=mod_w, mod_b=mod_b, mod_off=off, n_mod=o, temb_freqs=freqs, ref=ref, qkv_heads=qkv_heads,
-                             logit_bound=logit_bound)
+                             logit_bound=logit_bound, logit_bounds=logit_bounds)
         self._engine = FluxEngine(self.params, pw, dev)
         self._handle = None
         if free_parameters:

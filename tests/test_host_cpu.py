@@ -413,3 +413,34 @@ def test_stream_remainder_partition_properties():
             assert reducer(r, rem, nk, n) == [s for _, _, s in pieces], (rem, nk, n, r)     # the reducer's list = the writers' slots, in K order
             if 2 * rem > n:
                 assert len(pieces) <= 3
+
+
+def test_bench_roofline_legs_from_a_handle_profile():
+    """bench.py's roofline legs are arithmetic on vc_flux_profile records (ABI 10): with a synthetic profile of one evaluation's
+    launch classes the GATE_RES leg sums its three shapes, the table keeps every class with the fraction of ITS bound, and an
+    attention class of 57 launches of 4 L^2 D FLOPs at 170 us reads 0.455 of the 2.5 PFLOP/s peak."""
+    import bench
+    from visualcloze_amd import hip
+    L, D, mlp = 3968, 3072, 12288
+    mk = lambda kind, epi, n, k, launches, flops, nbytes, us: dict(kind=kind, epi=epi, n=n, k=k, launches=launches, flops=flops, bytes=nbytes,  # noqa: E731
+                                                                 total_us=us * launches, min_us=us * 0.98, max_us=us * 1.05, evaluations=1)
+    recs = [mk(hip.LAUNCH_LN_MODULATE, 0, 0, 0, 77, 0.0, 77 * 4.0 * L * D, 15.0),
+            mk(hip.LAUNCH_GEMM, hip.EPI_QKV, 3 * D, D, 57, 57 * 2.0 * L * 3 * D * D, 0.0, 180.0),
+            mk(hip.LAUNCH_ATTENTION, 28, 0, 0, 57, 57 * 4.0 * L * L * D, 0.0, 170.0),
+            mk(hip.LAUNCH_GEMM, hip.EPI_GATE_RES, D, D, 19, 19 * 2.0 * L * D * D, 0.0, 66.0),
+            mk(hip.LAUNCH_GEMM, hip.EPI_GATE_RES, D, mlp, 19, 19 * 2.0 * L * D * mlp, 0.0, 224.0),
+            mk(hip.LAUNCH_GEMM, hip.EPI_GATE_RES, D, D + mlp, 38, 38 * 2.0 * L * D * (D + mlp), 0.0, 265.0)]
+    rows = bench.launch_classes(recs)
+    assert [r["launch"] for r in rows] == ["ln_modulate", "gemm QKV N=9216 K=3072", "attention variant 28", "gemm GATE_RES N=3072 K=3072",
+                                          "gemm GATE_RES N=3072 K=12288", "gemm GATE_RES N=3072 K=15360"]
+    assert rows[0]["per_eval"] == 77 and rows[0]["frac_hbm"] == pytest.approx(4.0 * L * D / 15e-6 / 8e12, rel=1e-3) and "frac_mfma" not in rows[0]
+    assert rows[2]["frac_mfma"] == pytest.approx(4.0 * L * L * D / 170e-6 / 2.5e15, rel=1e-3) and 0.45 < rows[2]["frac_mfma"] < 0.46
+
+    class Job:
+        pass
+    g = bench.roofline_gemm_handle(Job(), recs)
+    fl = 19 * 2.0 * L * D * D + 19 * 2.0 * L * D * mlp + 38 * 2.0 * L * D * (D + mlp)
+    us = 19 * 66.0 + 19 * 224.0 + 38 * 265.0
+    assert g["launches_per_eval"] == 76 and g["flops_per_launch"] == pytest.approx(fl / 76)
+    assert g["avg_launch_us"] == pytest.approx(us / 76, abs=0.01) and g["frac"] == pytest.approx(fl / (us * 1e-6) / 2.5e15, abs=1e-4)
+    assert g["bound"] == "mfma" and g["unit"] == "TFLOP/s" and "vc_flux_profile" in g["timed"]

@@ -200,7 +200,7 @@ def flops_per_eval(T, N, D=3072, H=24, mlp=12288, depth=19, single=38, in_ch=384
     return lin, attn
 
 
-PMC_FILE = "profiles/r04_pmc_summary.json"
+PMC_FILE = "profiles/r07z_pmc_summary.json"      # the committed `rocprofv3 --pmc` passes over bench.py on the final code
 
 
 def pmc_traffic(kernel):
@@ -208,7 +208,7 @@ def pmc_traffic(kernel):
     (FETCH_SIZE and WRITE_SIZE in separate --pmc runs, KiB units; FETCH_SIZE x2 on gfx950 for wide coalesced reads,
     MI355X_MICROARCH.md §HBM) - hardware counters cannot be sampled from inside bench.py, so this field is a file
     lookup (`measured_in_this_run: false`), null when the file does not hold the kernel."""
-    for rel in (PMC_FILE, "profiles/r03_pmc_summary.json", "profiles/r02_pmc_summary.json"):
+    for rel in (PMC_FILE, "profiles/r04_pmc_summary.json", "profiles/r03_pmc_summary.json", "profiles/r02_pmc_summary.json"):
         try:
             d = json.load(open(os.path.join(REPO, rel)))
             name = kernel
@@ -222,6 +222,21 @@ def pmc_traffic(kernel):
         except Exception:
             continue
     return None
+
+
+def pmc_mfma_busy(kernel):
+    """Matrix-pipe UTILISATION of `kernel` from the committed PMC passes of this same command on the final code: the share of the
+    kernel's shader cycles in which the MFMA pipe of a SIMD is busy, SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over GRBM_GUI_ACTIVE / 8
+    XCDs (MI355X_MICROARCH.md), and the clock the kernel held (cycles / duration).  A file lookup like pmc_traffic():
+    hardware counters cannot be sampled from inside bench.py."""
+    try:
+        k = json.load(open(os.path.join(REPO, PMC_FILE)))[kernel]
+        cyc = k["GRBM_GUI_ACTIVE"] / 8.0
+        return dict(frac=round(k["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / cyc, 4), clock_ghz=round(cyc / k["_dur_ns"], 3),
+                    duration_us=round(k["_dur_ns"] * 1e-3, 2), measured_in_this_run=False,
+                    source=f"{PMC_FILE} (rocprofv3 --pmc pass of bench.py: SQ_VALU_MFMA_BUSY_CYCLES / 1024 over GRBM_GUI_ACTIVE / 8)")
+    except Exception:
+        return None
 
 
 TRAFFIC_KERNEL = "gemm_bf16_kernel<256, 192, 4, 2, 2, 2"     # the GATE_RES instantiation of the loader-wave tile
@@ -249,14 +264,24 @@ def traffic_probe():
         hip.gemm(grouped(hid, wm), epi=hip.EPI_GATE_RES)
         for _ in range(2):
             hip.gemm(hip.make_problem(cat, wl, b, x, res=x, gate=gate), epi=hip.EPI_GATE_RES)
+    # the product's attention launch at cfg 2 (24 heads, variant 28 = stream form with the tail combined in the launch, finished
+    # prescaled query rows, bounded logits) on QK-normed random operands - for measure_mfma_busy()
+    H = D // 128
+    qkv = r(L, 3 * D)
+    ones = torch.ones(128, dtype=torch.bfloat16, device=dev)
+    pos = torch.arange(L, dtype=torch.float64)[:, None] * torch.linspace(0.01, 1.0, 64, dtype=torch.float64)[None]
+    rope = torch.stack([torch.cos(pos), torch.sin(pos)], -1).float().to(dev).contiguous()
+    vt = torch.zeros((1, H, 128, (L + 63) // 64 * 64), dtype=torch.bfloat16, device=dev)
+    hip.qknorm_rope_vt(qkv, ones, ones, rope, vt, L, H, parts=hip.QKN_Q | hip.QKN_K | hip.QKN_VT | hip.QKN_QPRE)
+    o = torch.empty((L, D), dtype=torch.bfloat16, device=dev)
+    for _ in range(6):
+        hip.attention(qkv, vt, o, L, H, variant=28, q_prescaled=True, logit_bound=16.65)
     torch.cuda.synchronize()
 
 
-def measure_traffic(timeout=90):
-    """HBM-side bytes per launch of the roofline kernel, MEASURED IN THIS RUN: two separate `rocprofv3 --pmc` passes
-    (FETCH_SIZE; WRITE_SIZE - they do not share a pass, MI355X_MICROARCH.md) over `bench.py --traffic-probe` in a child
-    process, KiB units, FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B on wide coalesced reads).  None when rocprofv3
-    is not on this machine or a pass fails (the committed PMC summary is then quoted instead, labelled as such)."""
+def _pmc_pass(counters, timeout=90):
+    """one `rocprofv3 --kernel-trace --pmc <counters>` pass over `bench.py --traffic-probe` in a child process ->
+    {(kernel name, counter): [values per dispatch]}, None when rocprofv3 is not here or the pass fails"""
     import csv
     import glob
     import shutil
@@ -265,28 +290,61 @@ def measure_traffic(timeout=90):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None
+    tmp = tempfile.mkdtemp(prefix="vc_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+    try:
+        env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+            env.pop(k, None)
+        r = subprocess.run([exe, "--kernel-trace", "--pmc"] + counters.split() + ["-d", tmp, "-o", "p", "--output-format", "csv", "--",
+                            sys.executable, os.path.abspath(__file__), "--traffic-probe"], cwd=tmp, env=env,
+                           capture_output=True, text=True, timeout=timeout)
+        files = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            return None
+        out = {}
+        for f in files:
+            for row in csv.DictReader(open(f)):
+                out.setdefault((row["Kernel_Name"].replace("(anonymous namespace)::", ""), row["Counter_Name"]), []).append(float(row["Counter_Value"]))
+        return out
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def measure_mfma_busy(timeout=90):
+    """Matrix-pipe utilisation MEASURED IN THIS RUN, for the roofline GEMM and the product's attention launch: one `rocprofv3
+    --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES` pass over `bench.py --traffic-probe` (isolated launches on cfg-2-sized
+    QK-normed / random operands, child process): busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs.
+    -> {"gemm": frac, "attention": frac} (a key is missing when its kernel did not show up), None when the pass fails."""
+    vals = _pmc_pass("GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES", timeout)
+    if not vals:
+        return None
+    out = {}
+    for key, sub_ in (("gemm", TRAFFIC_KERNEL), ("attention", "attn64s_kernel<true>")):
+        busy = [v for (k, c), xs in vals.items() if sub_ in k and c == "SQ_VALU_MFMA_BUSY_CYCLES" for v in xs]
+        act = [v for (k, c), xs in vals.items() if sub_ in k and c == "GRBM_GUI_ACTIVE" for v in xs]
+        if len(busy) >= 4 and len(busy) == len(act) and sum(act) > 0:
+            out[key] = dict(frac=round((sum(busy) / 1024.0) / (sum(act) / 8.0), 4), dispatches=len(busy), measured_in_this_run=True,
+                            source="rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES over `bench.py --traffic-probe` (isolated launches, "
+                                   "cfg-2-sized operands) in a child process: SQ_VALU_MFMA_BUSY_CYCLES / 1024 over GRBM_GUI_ACTIVE / 8")
+    return out or None
+
+
+def measure_traffic(timeout=90):
+    """HBM-side bytes per launch of the roofline kernel, MEASURED IN THIS RUN: two separate `rocprofv3 --pmc` passes
+    (FETCH_SIZE; WRITE_SIZE - they do not share a pass, MI355X_MICROARCH.md) over `bench.py --traffic-probe` in a child
+    process, KiB units, FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B on wide coalesced reads).  None when rocprofv3
+    is not on this machine or a pass fails (the committed PMC summary is then quoted instead, labelled as such)."""
     vals = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-        tmp = tempfile.mkdtemp(prefix="vc_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
-        try:
-            env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
-            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
-                env.pop(k, None)
-            r = subprocess.run([exe, "--kernel-trace", "--pmc", ctr, "-d", tmp, "-o", "p", "--output-format", "csv", "--",
-                                sys.executable, os.path.abspath(__file__), "--traffic-probe"], cwd=tmp, env=env,
-                               capture_output=True, text=True, timeout=timeout)
-            files = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
-            if r.returncode != 0 or not files:
-                return None
-            xs = [float(row["Counter_Value"]) for f in files for row in csv.DictReader(open(f))
-                  if TRAFFIC_KERNEL in row["Kernel_Name"].replace("(anonymous namespace)::", "") and row["Counter_Name"] == ctr]
-            if len(xs) < 4:
-                return None
-            vals[ctr] = sum(xs) / len(xs)
-        except Exception:
+        got = _pmc_pass(ctr, timeout)
+        if not got:
             return None
-        finally:
-            shutil.rmtree(tmp, ignore_errors=True)
+        xs = [v for (k, c), vs in got.items() if TRAFFIC_KERNEL in k and c == ctr for v in vs]
+        if len(xs) < 4:
+            return None
+        vals[ctr] = sum(xs) / len(xs)
     fetch, write = 2.0 * vals["FETCH_SIZE"] * 1024.0, vals["WRITE_SIZE"] * 1024.0
     return dict(fetch_bytes=round(fetch), write_bytes=round(write), total_bytes=round(fetch + write), unit="bytes/launch",
                 measured_in_this_run=True,
@@ -468,6 +526,7 @@ def roofline_gemm_handle(job, recs):
                 frac=round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), traffic=pmc_traffic("gemm_bf16_kernel<256, 192, 4, 2, 2, 2, false, false, false, false>"),
                 kernel="gemm_bf16_kernel<EPI_GATE_RES>", launches_per_eval=n // g[0]["evaluations"],
                 flops_per_launch=flops / n, avg_launch_us=round(us / n, 2),
+                mfma_busy=pmc_mfma_busy("gemm_bf16_kernel<256, 192, 4, 2, 2, 2, false, false, false, false>"),
                 timed="vc_flux_profile: HIP events around each launch inside whole evaluations issued by the C handle's own plan")
 
 
@@ -508,6 +567,7 @@ def roofline_attention_handle(job, recs):
                 launches_timed=n, avg_launch_us=round(us / n, 2), min_launch_us=round(min(r["min_us"] for r in a), 2),
                 max_launch_us=round(max(r["max_us"] for r in a), 2),
                 achieved=round(tf, 1), unit="TFLOP/s", frac=round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
+                mfma_busy=pmc_mfma_busy("attn64s_kernel<true>") if (v & 8 and is_bounded and q_done) else None,
                 runmax_us=round(runmax, 2) if runmax else None,
                 runmax_frac=round(fl1 / (runmax * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4) if runmax else None,
                 runmax_note="the running-max template (attn64s_kernel<false> with prescaled queries) in situ on the same operands: what a "
@@ -783,7 +843,13 @@ def main(argv=None):
             live = measure_traffic()                      # (not when this very run is being profiled already)
             if live is not None:
                 rec["roofline"]["traffic"] = live
+            busy_live = measure_mfma_busy()               # matrix-pipe utilisation, one more counter pass over the same probe
         rec["attention_kernel"] = roofline_attention(job, recs=recs)
+        if world == 1 and not a.no_traffic and not profiled and busy_live:
+            if "gemm" in busy_live:
+                rec["roofline"]["mfma_busy"] = busy_live["gemm"]
+            if "attention" in busy_live and rec["attention_kernel"].get("mfma_busy") is not None:
+                rec["attention_kernel"]["mfma_busy"] = busy_live["attention"]
         if world == 1 and not a.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(T, N, wl)
             rec["gpu_over_cpu"] = round(rec["value"] / rec["cpu_baseline"]["value"], 1)
